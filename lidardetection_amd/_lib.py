@@ -1,0 +1,80 @@
+"""ctypes binding of csrc/liblidar_hip.so — the only way the Python host side reaches the kernels.
+
+Deliberately no fallback: if the shared library is missing or a symbol is absent we raise, so a
+silent eager/PyTorch path can never stand in for the HIP path.
+"""
+import ctypes as C
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+SO_PATH = os.path.join(_HERE, "csrc", "liblidar_hip.so")
+
+vp, i32, f32, sz = C.c_void_p, C.c_int, C.c_float, C.c_size_t
+
+# name -> (restype, argtypes); must cover every function declared in include/lidar_hip.h
+SIGNATURES = {
+    "lidar_voxelize_workspace_bytes": (sz, [i32, i32, i32]),
+    "lidar_voxelize_workspace_init": (i32, [vp, sz, i32, i32, i32, vp]),
+    "lidar_voxelize": (i32, [vp, vp, i32, i32, i32, vp, vp, vp, i32, i32, i32, vp, vp, vp, vp, vp, sz, vp]),
+    "lidar_pillar_vfe": (i32, [vp, vp, vp, i32, vp, i32, i32, vp, vp, vp, i32, vp, vp, i32, i32, i32, vp, vp]),
+    "lidar_mean_vfe": (i32, [vp, vp, i32, i32, i32, i32, vp, vp]),
+    "lidar_pillar_scatter_workspace_bytes": (sz, [i32, i32, i32]),
+    "lidar_pillar_scatter": (i32, [vp, vp, i32, i32, vp, i32, i32, i32, i32, vp, vp, sz, vp]),
+    "lidar_iou_workspace_bytes": (sz, [i32, i32]),
+    "lidar_boxes_pairwise_bev": (i32, [vp, i32, vp, i32, i32, vp, vp, sz, vp]),
+    "lidar_nms_workspace_bytes": (sz, [i32, i32]),
+    "lidar_nms_batch": (i32, [vp, vp, i32, i32, f32, i32, vp, vp, vp, sz, vp]),
+    "lidar_nms_mask_ptr": (vp, [vp, i32, i32]),
+}
+
+_lib = None
+
+
+class LidarHipError(RuntimeError):
+    pass
+
+
+def lib():
+    global _lib
+    if _lib is None:
+        if not os.path.exists(SO_PATH):
+            raise LidarHipError(
+                f"{SO_PATH} is missing: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
+                "(hipcc --offload-arch=gfx950). There is no CPU fallback.")
+        _lib = C.CDLL(SO_PATH)
+        for name, (res, args) in SIGNATURES.items():
+            fn = getattr(_lib, name)  # AttributeError if the symbol is not exported
+            fn.restype = res
+            fn.argtypes = args
+    return _lib
+
+
+def check(status, what):
+    if status != 0:
+        raise LidarHipError(f"{what} failed with status {status}")
+
+
+def ptr(t):
+    """device (or host) address of a torch tensor / None."""
+    return None if t is None else C.c_void_p(t.data_ptr())
+
+
+def stream():
+    import torch
+    return C.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def host_f32(vals):
+    return (C.c_float * len(vals))(*[float(v) for v in vals])
+
+
+def host_i32(vals):
+    return (C.c_int * len(vals))(*[int(v) for v in vals])
+
+
+def require_cuda(*tensors):
+    for t in tensors:
+        if t is not None and not t.is_cuda:
+            raise LidarHipError("expected a CUDA (ROCm) tensor; this library has no CPU path")
+        if t is not None and not t.is_contiguous():
+            raise LidarHipError("expected a contiguous tensor")

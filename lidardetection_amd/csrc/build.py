@@ -1,0 +1,51 @@
+"""Builds lidardetection_amd/csrc/liblidar_hip.so for gfx950 with hipcc (cross-compiles without a GPU).
+
+-ffp-contract=off: the integer-producing geometry (voxel cells, IoU > thresh, d2 < r2) must evaluate the
+reference's fp32 expressions without fused multiply-adds; throughput code uses explicit fmaf().
+"""
+import glob
+import os
+import subprocess
+import sys
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+SO = os.path.join(HERE, "liblidar_hip.so")
+HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
+FLAGS = ["--offload-arch=gfx950", "-O3", "-fPIC", "-std=c++17", "-ffp-contract=off", "-fvisibility=hidden",
+         "-Wall", "-Wno-unused-function"]
+
+
+def sources():
+    return sorted(glob.glob(os.path.join(HERE, "*.hip")))
+
+
+def build(force=False, verbose=False):
+    srcs = sources()
+    deps = srcs + glob.glob(os.path.join(HERE, "*.h")) + [os.path.abspath(__file__)]
+    if not force and os.path.exists(SO) and all(os.path.getmtime(SO) >= os.path.getmtime(d) for d in deps):
+        return SO
+    objs = []
+    procs = []
+    for s in srcs:
+        o = s[:-4] + ".o"
+        if (not force and os.path.exists(o)
+                and all(os.path.getmtime(o) >= os.path.getmtime(d) for d in [s] + deps[len(srcs):])):
+            objs.append(o)
+            continue
+        cmd = [HIPCC, *FLAGS, "-c", s, "-o", o]
+        if verbose:
+            print(" ".join(cmd))
+        procs.append((s, subprocess.Popen(cmd)))
+        objs.append(o)
+    for s, p in procs:
+        if p.wait() != 0:
+            raise RuntimeError(f"hipcc failed on {s}")
+    cmd = [HIPCC, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", SO, *objs]
+    if verbose:
+        print(" ".join(cmd))
+    subprocess.check_call(cmd)
+    return SO
+
+
+if __name__ == "__main__":
+    print(build(force="--force" in sys.argv, verbose=True))

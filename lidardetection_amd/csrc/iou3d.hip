@@ -1,0 +1,384 @@
+// Rotated BEV overlap / IoU matrices and rotated / axis-aligned NMS on gfx950.
+// Reference: pcdet/ops/iou3d_nms/src/iou3d_nms_kernel.cu (geometry :14-234, kernels :236-372),
+//            pcdet/ops/iou3d_nms/src/iou3d_nms.cpp:49-186 (host entry points; NMS greedy :116-132).
+//
+// The arithmetic of one box pair follows the reference expression by expression in fp32 (the
+// library is built with -ffp-contract=off) so that `iou > thresh` decisions are reproducible.
+// What is organised differently for CDNA4:
+//   * everything that depends on ONE box (cos/sin of the heading, the 4 rotated corners, area,
+//     bounding radius) is computed once per box in a prologue (the reference redoes it per pair);
+//   * an exact-zero early-out: boxes whose bounding circles (inflated by the reference's own 1e-2
+//     in-box margin) do not touch have no crossings and no contained corners, so the reference
+//     returns exactly 0 for them — skipped without evaluating the polygon code;
+//   * wave64: one wave owns a 64x64 tile, lane = row, the 64-bit ballot-sized word is the mask
+//     word; candidate pairs are compacted per lane before the divergent polygon code runs;
+//   * the greedy keep runs on the device (no D2H of the N x N/64 mask, no host loop).
+#include "common.h"
+#include <math.h>
+
+#define IOU_EPS 1e-8f
+
+struct __attribute__((aligned(16))) BoxPre {
+    float cx, cy, hx, hy;     // centre, dx/2, dy/2  (hx,hy as computed by the reference: box[3]/2)
+    float c, s;               // cosf(heading), sinf(heading)
+    float area, rad;          // dx*dy ; conservative bounding radius incl. margins
+    float px[4], py[4];       // rotated corners, reference order
+};
+
+struct pt2 { float x, y; };
+
+__device__ __forceinline__ float cross3(pt2 p1, pt2 p2, pt2 p0) {
+    return (p1.x - p0.x) * (p2.y - p0.y) - (p2.x - p0.x) * (p1.y - p0.y);
+}
+
+// float trig of the heading.  Evaluated in double and rounded once: this is the correctly rounded
+// fp32 result except in ~1e-8 of cases, which is what a good host libm returns as well.
+__device__ __forceinline__ void heading_cs(float a, float &c, float &s) {
+    c = (float)cos((double)a);
+    s = (float)sin((double)a);
+}
+
+__device__ __forceinline__ BoxPre make_pre(const float *b) {
+    BoxPre r;
+    r.cx = b[0]; r.cy = b[1];
+    r.hx = b[3] / 2; r.hy = b[4] / 2;
+    heading_cs(b[6], r.c, r.s);
+    r.area = b[3] * b[4];
+    const float x1 = r.cx - r.hx, y1 = r.cy - r.hy, x2 = r.cx + r.hx, y2 = r.cy + r.hy;
+    const float xs[4] = {x1, x2, x2, x1}, ys[4] = {y1, y1, y2, y2};
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {  // rotate_around_center, kernel.cu:94-98
+        r.px[k] = (xs[k] - r.cx) * r.c + (ys[k] - r.cy) * (-r.s) + r.cx;
+        r.py[k] = (xs[k] - r.cx) * r.s + (ys[k] - r.cy) * r.c + r.cy;
+    }
+    r.rad = sqrtf(r.hx * r.hx + r.hy * r.hy) * 1.0001f + 0.02f;
+    return r;
+}
+
+// check_in_box2d (kernel.cu:51-61): cos(-h) == cos(h), sin(-h) == -sin(h) bit for bit
+__device__ __forceinline__ bool in_box2d(const BoxPre &B, float px, float py) {
+    const float MARGIN = 1e-2f;
+    const float ac = B.c, as = -B.s;
+    const float rx = (px - B.cx) * ac + (py - B.cy) * (-as);
+    const float ry = (px - B.cx) * as + (py - B.cy) * ac;
+    return (fabsf(rx) < B.hx + MARGIN) && (fabsf(ry) < B.hy + MARGIN);
+}
+
+// intersection (kernel.cu:63-92)
+__device__ __forceinline__ bool seg_intersect(pt2 p1, pt2 p0, pt2 q1, pt2 q0, pt2 &ans) {
+    const bool rc = fminf(p0.x, p1.x) <= fmaxf(q0.x, q1.x) && fminf(q0.x, q1.x) <= fmaxf(p0.x, p1.x) &&
+                    fminf(p0.y, p1.y) <= fmaxf(q0.y, q1.y) && fminf(q0.y, q1.y) <= fmaxf(p0.y, p1.y);
+    if (!rc) return false;
+    const float s1 = cross3(q0, p1, p0);
+    const float s2 = cross3(p1, q1, p0);
+    const float s3 = cross3(p0, q1, q0);
+    const float s4 = cross3(q1, p1, q0);
+    if (!(s1 * s2 > 0 && s3 * s4 > 0)) return false;
+    const float s5 = cross3(q1, p1, p0);
+    if (fabsf(s5 - s1) > IOU_EPS) {
+        ans.x = (s5 * q0.x - s1 * q1.x) / (s5 - s1);
+        ans.y = (s5 * q0.y - s1 * q1.y) / (s5 - s1);
+    } else {
+        const float a0 = p0.y - p1.y, b0 = p1.x - p0.x, c0 = p0.x * p1.y - p1.x * p0.y;
+        const float a1 = q0.y - q1.y, b1 = q1.x - q0.x, c1 = q0.x * q1.y - q1.x * q0.y;
+        const float D = a0 * b1 - a1 * b0;
+        ans.x = (b0 * c1 - b1 * c0) / D;
+        ans.y = (a1 * c0 - a0 * c1) / D;
+    }
+    return true;
+}
+
+__device__ __forceinline__ bool circles_apart(const BoxPre &A, const BoxPre &B) {
+    const float dx = A.cx - B.cx, dy = A.cy - B.cy;
+    const float rr = A.rad + B.rad;
+    return dx * dx + dy * dy > rr * rr;
+}
+
+// Per-thread vertex scratch lives in LDS, laid out [slot][thread] (conflict-free): 16 slots of
+// (x, y, angle).  TPB = threads per block of the calling kernel.
+template <int TPB>
+struct VertScratch {
+    float x[16][TPB], y[16][TPB], a[16][TPB];
+};
+
+// box_overlap (kernel.cu:104-225) on pre-computed boxes.  Polygon of at most 16 vertices.
+template <int TPB>
+__device__ float box_overlap_pre(const BoxPre &A, const BoxPre &B, VertScratch<TPB> &S, int t) {
+    int cnt = 0;
+    float sumx = 0.f, sumy = 0.f;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const pt2 a0 = {A.px[i], A.py[i]}, a1 = {A.px[(i + 1) & 3], A.py[(i + 1) & 3]};
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const pt2 b0 = {B.px[j], B.py[j]}, b1 = {B.px[(j + 1) & 3], B.py[(j + 1) & 3]};
+            pt2 ans;
+            if (seg_intersect(a1, a0, b1, b0, ans)) {
+                sumx = sumx + ans.x;
+                sumy = sumy + ans.y;
+                if (cnt < 16) { S.x[cnt][t] = ans.x; S.y[cnt][t] = ans.y; }
+                cnt++;
+            }
+        }
+    }
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        if (in_box2d(A, B.px[k], B.py[k])) {
+            sumx = sumx + B.px[k]; sumy = sumy + B.py[k];
+            if (cnt < 16) { S.x[cnt][t] = B.px[k]; S.y[cnt][t] = B.py[k]; }
+            cnt++;
+        }
+        if (in_box2d(B, A.px[k], A.py[k])) {
+            sumx = sumx + A.px[k]; sumy = sumy + A.py[k];
+            if (cnt < 16) { S.x[cnt][t] = A.px[k]; S.y[cnt][t] = A.py[k]; }
+            cnt++;
+        }
+    }
+    if (cnt == 0) return 0.f;
+    if (cnt > 16) cnt = 16;  // the reference's buffer is Point[16]; unreachable for convex quads
+    const float ctrx = sumx / cnt, ctry = sumy / cnt;
+    for (int k = 0; k < cnt; ++k) S.a[k][t] = atan2f(S.y[k][t] - ctry, S.x[k][t] - ctrx);
+    // bubble sort, strict > (kernel.cu:199-209)
+    for (int j = 0; j < cnt - 1; ++j)
+        for (int i = 0; i < cnt - j - 1; ++i) {
+            const float a0 = S.a[i][t], a1 = S.a[i + 1][t];
+            if (a0 > a1) {
+                const float x0 = S.x[i][t], y0 = S.y[i][t];
+                S.x[i][t] = S.x[i + 1][t]; S.y[i][t] = S.y[i + 1][t]; S.a[i][t] = a1;
+                S.x[i + 1][t] = x0; S.y[i + 1][t] = y0; S.a[i + 1][t] = a0;
+            }
+        }
+    float area = 0.f;
+    const float x0 = S.x[0][t], y0 = S.y[0][t];
+    for (int k = 0; k < cnt - 1; ++k) {
+        const float ax = S.x[k][t] - x0, ay = S.y[k][t] - y0;
+        const float bx = S.x[k + 1][t] - x0, by = S.y[k + 1][t] - y0;
+        area += ax * by - ay * bx;
+    }
+    return fabsf(area) * 0.5f;
+}
+
+__device__ __forceinline__ float iou_from_overlap(float sa, float sb, float s) {
+    return s / fmaxf(sa + sb - s, IOU_EPS);
+}
+
+// iou_normal (kernel.cu:314-325)
+__device__ __forceinline__ float iou_normal_dev(const float *a, const float *b) {
+    const float left = fmaxf(a[0] - a[3] / 2, b[0] - b[3] / 2), right = fminf(a[0] + a[3] / 2, b[0] + b[3] / 2);
+    const float top = fmaxf(a[1] - a[4] / 2, b[1] - b[4] / 2), bottom = fminf(a[1] + a[4] / 2, b[1] + b[4] / 2);
+    const float width = fmaxf(right - left, 0.f), height = fmaxf(bottom - top, 0.f);
+    const float interS = width * height;
+    const float Sa = a[3] * a[4], Sb = b[3] * b[4];
+    return interS / fmaxf(Sa + Sb - interS, IOU_EPS);
+}
+
+// ------------------------------------------------------------------ prologue
+__global__ void iou_prep_kernel(const float *__restrict__ boxes, int n, BoxPre *__restrict__ pre) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) pre[i] = make_pre(boxes + (size_t)i * 7);
+}
+
+// ------------------------------------------------------------------ pairwise matrices
+// mode 0: overlap area (boxes_overlap_kernel :236-249); 1: IoU (boxes_iou_bev_kernel :251-265)
+// block = 256 threads = 4 rows x 64 cols of the (N, M) matrix; cols on lanes -> coalesced stores.
+__global__ __launch_bounds__(256) void iou_pairwise_kernel(const BoxPre *__restrict__ pa, int na,
+                                                           const BoxPre *__restrict__ pb, int nb, int mode,
+                                                           float *__restrict__ out) {
+    __shared__ VertScratch<256> S;
+    const int t = threadIdx.x;
+    const int col = blockIdx.x * 64 + (t & 63);
+    const int row = blockIdx.y * 4 + (t >> 6);
+    if (row >= na || col >= nb) return;
+    const BoxPre A = pa[row];
+    const BoxPre B = pb[col];
+    float v = 0.f;
+    if (!circles_apart(A, B)) {
+        const float s = box_overlap_pre<256>(A, B, S, t);
+        v = mode == 0 ? s : iou_from_overlap(A.area, B.area, s);
+    }
+    out[(size_t)row * nb + col] = v;
+}
+
+// ------------------------------------------------------------------ NMS suppression mask
+// grid = (col_block, row_block, frame); one wave per 64x64 tile; only tiles with col_block >=
+// row_block are computed (the greedy never reads the others).  mask is (n, cb) u64 per frame.
+template <bool NORMAL>
+__global__ __launch_bounds__(64) void nms_mask_kernel(const float *__restrict__ boxes_all, const BoxPre *__restrict__ pre_all,
+                                                      const int *__restrict__ counts, int n_max, float thresh,
+                                                      unsigned long long *__restrict__ mask_all) {
+    const int rb = blockIdx.y, cbk = blockIdx.x, f = blockIdx.z;
+    if (cbk < rb) return;
+    const int n = counts ? min(counts[f], n_max) : n_max;
+    if (rb * 64 >= n || cbk * 64 >= n) return;
+    const int cb_total = (n_max + 63) / 64;
+    const float *boxes = boxes_all + (size_t)f * n_max * 7;
+    const BoxPre *pre = pre_all + (size_t)f * n_max;
+    unsigned long long *mask = mask_all + (size_t)f * n_max * cb_total;
+    const int l = threadIdx.x;
+    const int row = rb * 64 + l, colbase = cbk * 64;
+    const int col_size = min(n - colbase, 64);
+    const bool rvalid = row < n;
+    unsigned long long word = 0ull;
+    if (NORMAL) {
+        __shared__ float s_b[64 * 7];
+        for (int k = l; k < col_size * 7; k += 64) s_b[k] = boxes[(size_t)colbase * 7 + k];
+        __syncthreads();
+        if (rvalid) {
+            float a[7];
+#pragma unroll
+            for (int k = 0; k < 7; ++k) a[k] = boxes[(size_t)row * 7 + k];
+            const int start = (rb == cbk) ? l + 1 : 0;
+            for (int j = start; j < col_size; ++j)
+                if (iou_normal_dev(a, s_b + j * 7) > thresh) word |= 1ull << j;
+        }
+    } else {
+        __shared__ BoxPre s_pre[64];
+        __shared__ VertScratch<64> S;
+        if (l < col_size) s_pre[l] = pre[colbase + l];
+        __syncthreads();
+        BoxPre A;
+        if (rvalid) A = pre[row];
+        else A = s_pre[0];
+        // phase 1: cheap circle test -> per-lane candidate set
+        unsigned long long cand = 0ull;
+        const int start = (rb == cbk) ? l + 1 : 0;
+        if (rvalid)
+            for (int j = start; j < col_size; ++j)
+                if (!circles_apart(A, s_pre[j])) cand |= 1ull << j;
+        // a negative threshold makes every pair (even disjoint ones, IoU == 0) a hit
+        if (rvalid && thresh < 0.f) {
+            for (int j = start; j < col_size; ++j)
+                if (!(cand >> j & 1ull)) word |= 1ull << j;
+        }
+        // phase 2: polygon code only for candidates
+        while (cand) {
+            const int j = __ffsll((long long)cand) - 1;
+            cand &= cand - 1ull;
+            const BoxPre B = s_pre[j];
+            const float s = box_overlap_pre<64>(A, B, S, l);
+            if (iou_from_overlap(A.area, B.area, s) > thresh) word |= 1ull << j;
+        }
+    }
+    if (rvalid) mask[(size_t)row * cb_total + cbk] = word;
+}
+
+// ------------------------------------------------------------------ device-side greedy keep
+// one block per frame (iou3d_nms.cpp:116-132).  keep: int64 positions; num_keep: int per frame.
+#define GREEDY_TPB 1024
+__global__ __launch_bounds__(GREEDY_TPB) void nms_greedy_kernel(const unsigned long long *__restrict__ mask_all,
+                                                                const int *__restrict__ counts, int n_max,
+                                                                long long *__restrict__ keep_all,
+                                                                int *__restrict__ num_keep) {
+    __shared__ unsigned long long s_remv[1024];  // cb words (n_max <= 65536)
+    __shared__ unsigned long long s_keepmask;
+    __shared__ int s_nkeep;
+    const int f = blockIdx.x;
+    const int n = counts ? min(counts[f], n_max) : n_max;
+    const int cb_total = (n_max + 63) / 64;
+    const int cb = (n + 63) / 64;
+    const unsigned long long *mask = mask_all + (size_t)f * n_max * cb_total;
+    long long *keep = keep_all + (size_t)f * n_max;
+    const int t = threadIdx.x, l = t & 63;
+    for (int c = t; c < cb; c += GREEDY_TPB) s_remv[c] = 0ull;
+    if (t == 0) s_nkeep = 0;
+    __syncthreads();
+    for (int rb = 0; rb < cb; ++rb) {
+        const int row0 = rb * 64;
+        if (t < 64) {
+            const int row = row0 + l;
+            const bool valid = row < n;
+            const unsigned long long diag = valid ? mask[(size_t)row * cb_total + rb] : 0ull;
+            unsigned long long r = s_remv[rb];
+            unsigned long long km = 0ull;
+            const int lim = min(64, n - row0);
+            for (int i = 0; i < lim; ++i) {
+                const unsigned long long d = __shfl(diag, i, 64);
+                if (!((r >> i) & 1ull)) {
+                    km |= 1ull << i;
+                    r |= d;
+                }
+            }
+            const int base = s_nkeep;
+            if ((km >> l) & 1ull) keep[base + __popcll(km & lanemask_lt())] = row;
+            if (l == 0) {
+                s_keepmask = km;
+                s_nkeep = base + __popcll(km);
+            }
+        }
+        __syncthreads();
+        const unsigned long long km = s_keepmask;
+        for (int c = rb + 1 + t; c < cb; c += GREEDY_TPB) {
+            unsigned long long acc = 0ull;
+            unsigned long long m = km;
+            while (m) {
+                const int i = __ffsll((long long)m) - 1;
+                m &= m - 1ull;
+                acc |= mask[(size_t)(row0 + i) * cb_total + c];
+            }
+            s_remv[c] |= acc;
+        }
+        __syncthreads();
+    }
+    if (t == 0) num_keep[f] = s_nkeep;
+}
+
+// ------------------------------------------------------------------ C ABI
+LIDAR_EXPORT size_t lidar_iou_workspace_bytes(int n_a, int n_b) {
+    return align_up((size_t)(n_a > 0 ? n_a : 1) * sizeof(BoxPre), 256) + align_up((size_t)(n_b > 0 ? n_b : 1) * sizeof(BoxPre), 256);
+}
+
+// mode 0: boxes_overlap_bev_gpu (iou3d_nms.cpp:49-68); mode 1: boxes_iou_bev_gpu (:70-88)
+LIDAR_EXPORT int lidar_boxes_pairwise_bev(const float *boxes_a, int n_a, const float *boxes_b, int n_b, int mode,
+                                          float *out, void *ws, size_t ws_bytes, void *stream) {
+    if (n_a < 0 || n_b < 0 || (mode != 0 && mode != 1)) return LIDAR_ERR_ARG;
+    if (n_a == 0 || n_b == 0) return LIDAR_OK;
+    if (!boxes_a || !boxes_b || !out || !ws) return LIDAR_ERR_ARG;
+    if (ws_bytes < lidar_iou_workspace_bytes(n_a, n_b)) return LIDAR_ERR_WORKSPACE;
+    hipStream_t s = (hipStream_t)stream;
+    BoxPre *pa = (BoxPre *)ws;
+    BoxPre *pb = (BoxPre *)((char *)ws + align_up((size_t)n_a * sizeof(BoxPre), 256));
+    hipLaunchKernelGGL(iou_prep_kernel, dim3(divup(n_a, 256)), dim3(256), 0, s, boxes_a, n_a, pa);
+    hipLaunchKernelGGL(iou_prep_kernel, dim3(divup(n_b, 256)), dim3(256), 0, s, boxes_b, n_b, pb);
+    hipLaunchKernelGGL(iou_pairwise_kernel, dim3(divup(n_b, 64), divup(n_a, 4)), dim3(256), 0, s, pa, n_a, pb, n_b,
+                       mode, out);
+    return lidar_check_launch("lidar_boxes_pairwise_bev");
+}
+
+LIDAR_EXPORT size_t lidar_nms_workspace_bytes(int batch, int n_max) {
+    if (batch <= 0 || n_max <= 0) return 256;
+    const size_t cb = (size_t)(n_max + 63) / 64;
+    return align_up((size_t)batch * n_max * sizeof(BoxPre), 256) + align_up((size_t)batch * n_max * cb * 8, 256);
+}
+
+// Batched NMS on already score-sorted boxes.  boxes (batch, n_max, 7); counts (batch) device ints or
+// NULL (= n_max for every frame); keep (batch, n_max) int64 device; num_keep (batch) int device.
+// normal = 0: nms_gpu (iou3d_nms.cpp:90-136), 1: nms_normal_gpu (:139-186).
+LIDAR_EXPORT int lidar_nms_batch(const float *boxes, const int *counts, int batch, int n_max, float thresh, int normal,
+                                 long long *keep, int *num_keep, void *ws, size_t ws_bytes, void *stream) {
+    if (batch <= 0 || n_max < 0 || !num_keep) return LIDAR_ERR_ARG;
+    hipStream_t s = (hipStream_t)stream;
+    if (n_max == 0) return hipMemsetAsync(num_keep, 0, sizeof(int) * batch, s) == hipSuccess ? LIDAR_OK : LIDAR_ERR_LAUNCH;
+    if (!boxes || !keep || !ws) return LIDAR_ERR_ARG;
+    if (ws_bytes < lidar_nms_workspace_bytes(batch, n_max)) return LIDAR_ERR_WORKSPACE;
+    const int cb = (n_max + 63) / 64;
+    if (cb > 1024) return LIDAR_ERR_ARG;  // greedy keeps remv[] in LDS
+    BoxPre *pre = (BoxPre *)ws;
+    unsigned long long *mask = (unsigned long long *)((char *)ws + align_up((size_t)batch * n_max * sizeof(BoxPre), 256));
+    if (!normal)
+        hipLaunchKernelGGL(iou_prep_kernel, dim3(divup((long long)batch * n_max, 256)), dim3(256), 0, s, boxes,
+                           batch * n_max, pre);
+    const dim3 grid(cb, cb, batch);
+    if (normal)
+        hipLaunchKernelGGL(nms_mask_kernel<true>, grid, dim3(64), 0, s, boxes, pre, counts, n_max, thresh, mask);
+    else
+        hipLaunchKernelGGL(nms_mask_kernel<false>, grid, dim3(64), 0, s, boxes, pre, counts, n_max, thresh, mask);
+    hipLaunchKernelGGL(nms_greedy_kernel, dim3(batch), dim3(GREEDY_TPB), 0, s, mask, counts, n_max, keep,
+                       num_keep);
+    return lidar_check_launch("lidar_nms_batch");
+}
+
+// test hook: copy of the suppression mask words (row-major (n_max, cb)) of frame 0 left in ws by
+// the last lidar_nms_batch call with the same (batch, n_max).
+LIDAR_EXPORT const void *lidar_nms_mask_ptr(void *ws, int batch, int n_max) {
+    return (char *)ws + align_up((size_t)batch * n_max * sizeof(BoxPre), 256);
+}

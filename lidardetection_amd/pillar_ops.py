@@ -1,0 +1,59 @@
+"""Host side of the PillarVFE / MeanVFE / PointPillarScatter kernels (include/lidar_hip.h)."""
+import torch
+
+from . import _lib, workspace
+
+
+def fold_bn(gamma, beta, mean, var, eps):
+    """BatchNorm1d (eval) -> per-channel scale/shift: y = x*scale + shift."""
+    scale = gamma / torch.sqrt(var + eps)
+    return scale.contiguous(), (beta - mean * scale).contiguous()
+
+
+def pillar_vfe(voxels, num_points, coords, weight, scale, shift, voxel_size, point_cloud_range,
+               with_distance=False, num_voxels_dev=None):
+    """Fused PillarVFE (single PFN layer, eval).  voxels (V,P,C) f32; num_points (V) i32|f32;
+    coords (V,4) [b,z,y,x] i32|f32; weight (cout, C+6[+1]); -> (V, cout) f32.
+    Reference: pcdet/models/backbones_3d/vfe/pillar_vfe.py:94-123 + PFNLayer :29-49."""
+    _lib.require_cuda(voxels, num_points, coords, weight, scale, shift)
+    V, P, C = voxels.shape
+    cout = weight.shape[0]
+    if weight.shape[1] != C + 6 + int(bool(with_distance)):
+        raise _lib.LidarHipError("weight must be (cout, C + 6 [+1 with_distance]) — use_absolute_xyz layout")
+    if coords.dtype not in (torch.int32, torch.float32) or num_points.dtype not in (torch.int32, torch.float32):
+        raise _lib.LidarHipError("coords / num_points must be int32 or float32")
+    out = torch.empty((V, cout), dtype=torch.float32, device=voxels.device)
+    L = _lib.lib()
+    _lib.check(L.lidar_pillar_vfe(_lib.ptr(voxels), _lib.ptr(num_points), _lib.ptr(coords), V, _lib.ptr(num_voxels_dev),
+                                  P, C, _lib.ptr(weight), _lib.ptr(scale), _lib.ptr(shift), cout,
+                                  _lib.host_f32(voxel_size), _lib.host_f32(point_cloud_range), int(bool(with_distance)),
+                                  int(coords.dtype == torch.float32), int(num_points.dtype == torch.float32),
+                                  _lib.ptr(out), _lib.stream()), "lidar_pillar_vfe")
+    return out
+
+
+def mean_vfe(voxels, num_points):
+    """MeanVFE (pcdet/models/backbones_3d/vfe/mean_vfe.py:14-31) -> (V, C)."""
+    _lib.require_cuda(voxels, num_points)
+    V, P, C = voxels.shape
+    out = torch.empty((V, C), dtype=torch.float32, device=voxels.device)
+    L = _lib.lib()
+    _lib.check(L.lidar_mean_vfe(_lib.ptr(voxels), _lib.ptr(num_points), V, P, C, int(num_points.dtype == torch.float32),
+                                _lib.ptr(out), _lib.stream()), "lidar_mean_vfe")
+    return out
+
+
+def pillar_scatter(pillar_features, coords, batch_size, nx, ny, num_voxels_dev=None, out=None):
+    """PointPillarScatter (pcdet/models/backbones_2d/map_to_bev/pointpillar_scatter.py:14-37), nz == 1.
+    pillar_features (V, C) f32, coords (V,4) [b,z,y,x] i32|f32 -> (B, C, ny, nx) f32."""
+    _lib.require_cuda(pillar_features, coords)
+    V, C = pillar_features.shape
+    if out is None:
+        out = torch.empty((batch_size, C, ny, nx), dtype=torch.float32, device=pillar_features.device)
+    L = _lib.lib()
+    wsb = L.lidar_pillar_scatter_workspace_bytes(batch_size, nx, ny)
+    ws = workspace.get("scatter", wsb, pillar_features.device)
+    _lib.check(L.lidar_pillar_scatter(_lib.ptr(pillar_features), _lib.ptr(coords), int(coords.dtype == torch.float32), V,
+                                      _lib.ptr(num_voxels_dev), C, batch_size, nx, ny, _lib.ptr(out), _lib.ptr(ws), wsb,
+                                      _lib.stream()), "lidar_pillar_scatter")
+    return out

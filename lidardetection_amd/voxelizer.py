@@ -1,0 +1,88 @@
+"""Batched on-device voxeliser (host side of lidar_voxelize, include/lidar_hip.h).
+
+Replaces, for a whole batch in one launch sequence, what the reference does per frame on the CPU
+inside DataLoader workers: spconv's VoxelGeneratorV2.generate (pcdet/datasets/processor/
+data_processor.py:48-80) followed by collate_batch's concatenation + batch-index column
+(pcdet/datasets/dataset.py:153-185).  Output is identical to that sequential path.
+"""
+import numpy as np
+import torch
+
+from . import _lib
+
+
+def grid_size_of(voxel_size, point_cloud_range):
+    """grid = round((range[3:6] - range[0:3]) / voxel_size) in fp32 (data_processor.py:61-62)."""
+    r = np.asarray(point_cloud_range, np.float32)
+    v = np.asarray(voxel_size, np.float32)
+    return np.round((r[3:6] - r[0:3]) / v).astype(np.int64)
+
+
+class BatchVoxelizer:
+    def __init__(self, voxel_size, point_cloud_range, max_num_points, max_voxels, num_point_features=4):
+        self.voxel_size = [float(np.float32(v)) for v in voxel_size]
+        self.point_cloud_range = [float(np.float32(v)) for v in point_cloud_range]
+        self.grid_size = grid_size_of(voxel_size, point_cloud_range)  # nx, ny, nz
+        self.max_num_points = int(max_num_points)
+        self.max_voxels = int(max_voxels)
+        self.C = int(num_point_features)
+        self._range_h = _lib.host_f32(self.point_cloud_range)
+        self._vs_h = _lib.host_f32(self.voxel_size)
+        self._grid_h = _lib.host_i32(self.grid_size)
+        self._ws = {}
+
+    def _workspace(self, batch, n_max, device):
+        key = (str(device), batch, n_max)
+        ent = self._ws.get(key)
+        if ent is None:
+            L = _lib.lib()
+            nbytes = L.lidar_voxelize_workspace_bytes(batch, n_max, self.max_voxels)
+            ws = torch.empty(nbytes, dtype=torch.uint8, device=device)
+            _lib.check(L.lidar_voxelize_workspace_init(_lib.ptr(ws), nbytes, batch, n_max, self.max_voxels,
+                                                       _lib.stream()), "lidar_voxelize_workspace_init")
+            ent = (ws, nbytes)
+            self._ws = {key: ent}  # keep one workspace alive
+        return ent
+
+    def alloc_outputs(self, batch, device):
+        rows = batch * self.max_voxels
+        return {
+            "voxels": torch.empty((rows, self.max_num_points, self.C), dtype=torch.float32, device=device),
+            "voxel_coords": torch.empty((rows, 4), dtype=torch.int32, device=device),
+            "voxel_num_points": torch.empty((rows,), dtype=torch.int32, device=device),
+            "voxel_offsets": torch.empty((batch + 1,), dtype=torch.int32, device=device),
+        }
+
+    def __call__(self, points, point_offsets, n_max, compact=True, out=None):
+        """points (sum N, C) f32 cuda; point_offsets (B+1) int32 cuda; n_max >= max frame size (host int).
+        Returns dict(voxels, voxel_coords [b,z,y,x], voxel_num_points, voxel_offsets); rows beyond
+        voxel_offsets[-1] are unspecified.  No host synchronisation."""
+        _lib.require_cuda(points, point_offsets)
+        if points.dtype != torch.float32 or point_offsets.dtype != torch.int32:
+            raise _lib.LidarHipError("points must be float32 and point_offsets int32")
+        if points.dim() != 2 or points.shape[1] != self.C:
+            raise _lib.LidarHipError(f"points must be (N, {self.C})")
+        batch = point_offsets.numel() - 1
+        n_max = max(int(n_max), 1)
+        ws, nbytes = self._workspace(batch, n_max, points.device)
+        if out is None:
+            out = self.alloc_outputs(batch, points.device)
+        L = _lib.lib()
+        _lib.check(L.lidar_voxelize(_lib.ptr(points), _lib.ptr(point_offsets), batch, n_max, self.C, self._range_h,
+                                    self._vs_h, self._grid_h, self.max_num_points, self.max_voxels, int(bool(compact)),
+                                    _lib.ptr(out["voxels"]), _lib.ptr(out["voxel_coords"]),
+                                    _lib.ptr(out["voxel_num_points"]), _lib.ptr(out["voxel_offsets"]), _lib.ptr(ws),
+                                    nbytes, _lib.stream()), "lidar_voxelize")
+        return out
+
+    def voxelize_frames(self, frames, device="cuda"):
+        """Convenience: list of (N_f, C) numpy/torch frames -> compact collated tensors, sliced to
+        the true row count (one host sync), as the reference's collate_batch would hand them over."""
+        ts = [torch.as_tensor(f, dtype=torch.float32) for f in frames]
+        sizes = [int(t.shape[0]) for t in ts]
+        offs = torch.tensor(np.concatenate([[0], np.cumsum(sizes)]), dtype=torch.int32)
+        pts = torch.cat(ts, 0).to(device).contiguous() if sum(sizes) > 0 else torch.zeros((1, self.C), device=device)
+        out = self(pts, offs.to(device), max(sizes) if sizes else 1, compact=True)
+        total = int(out["voxel_offsets"][-1].item())
+        return {"voxels": out["voxels"][:total], "voxel_coords": out["voxel_coords"][:total],
+                "voxel_num_points": out["voxel_num_points"][:total], "voxel_offsets": out["voxel_offsets"]}
