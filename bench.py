@@ -1,0 +1,174 @@
+"""bench.py — frames/s of PointPillar-KITTI forward + NMS (BASELINE.json metric) on N MI355X.
+
+Step  = one pass of the hot path over one batch of 16 synthetic KITTI-shaped frames resident in HBM:
+        HIP voxelise -> HIP PillarVFE -> HIP BEV scatter -> stock-torch 2D backbone + head (fp32)
+        -> masked top-k + decode -> HIP batched rotated NMS (device greedy).
+N > 1 = one process per GPU (torch.distributed / RCCL only for the barrier + max-over-ranks
+        timing); frames are independent, every rank processes its own batch: replicas, weak scaling,
+        no data-path collective.
+
+Prints ONE JSON line on rank 0 (contract in the task statement) with two extra objects:
+  roofline     — the voxeliser (the north-star HBM kernel sequence), timed with HIP events on the
+                 launch stream inside the timed region; algorithmic bytes per launch from SURVEY §8d.
+  cpu_baseline — the oracle (CPU restatement of the reference path) timed on a bounded sample.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+from lidardetection_amd import synth  # noqa: E402
+from lidardetection_amd.pointpillar import PointPillarKITTI  # noqa: E402
+
+HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
+
+
+def make_batch(batch, rank, device):
+    frames = [synth.cloud_uniform(1000 + rank * batch + f) for f in range(batch)]
+    sizes = [len(f) for f in frames]
+    pts = torch.from_numpy(np.concatenate(frames, 0)).to(device)
+    offs = torch.tensor(np.concatenate([[0], np.cumsum(sizes)]), dtype=torch.int32, device=device)
+    return frames, pts, offs, max(sizes)
+
+
+def cpu_baseline(frames, model, nframes):
+    """Reference CPU path restated (oracle/): sequential voxelise (C, 1 thread) + PillarVFE/scatter
+    (torch CPU) + dense backbone/head (torch CPU, all threads) + rotated NMS (C, 1 thread)."""
+    from oracle import c_oracle, pp_oracle
+    import copy
+    m = copy.deepcopy(model).to("cpu")
+    m.B = 1
+    m.anchors = m.anchors.cpu()
+    t0 = time.perf_counter()
+    for f in frames[:nframes]:
+        vox, coords, num = c_oracle.voxelize(f, synth.PP_VOXEL, synth.PP_RANGE, 32, model.voxelizer.max_voxels)
+        coords4 = np.pad(coords, ((0, 0), (1, 0)))
+        n = m.pfn_norm
+        with torch.no_grad():
+            feat = pp_oracle.pillar_vfe(torch.from_numpy(vox), torch.from_numpy(num).float(), torch.from_numpy(coords4).float(),
+                                        m.pfn_linear.weight, n.weight, n.bias, n.running_mean, n.running_var,
+                                        synth.PP_VOXEL, synth.PP_RANGE, eps=n.eps)
+            canvas = pp_oracle.pillar_scatter(feat, torch.from_numpy(coords4).float(), 1, m.nx, m.ny)
+            cls, box, dirs = m.backbone_head(canvas)
+            scores, _ = torch.sigmoid(cls[0]).max(dim=-1)
+            msk = scores >= m.score_thresh
+            sc, idx = torch.topk(scores[msk], k=min(m.nms_pre, int(msk.sum())))
+            oi = msk.nonzero().view(-1)[idx]
+            boxes = m.decode(box[0][oi], m.anchors[oi], dirs[0][oi])
+        c_oracle.nms_sorted(boxes.numpy(), m.nms_thresh)
+    dt = time.perf_counter() - t0
+    return {"value": nframes / dt, "unit": "frames/s", "cores": torch.get_num_threads(), "kind": "port",
+            "sample": f"{nframes} frame(s) of the same workload: C oracle voxelise+NMS (1 thread) + torch-CPU "
+                      f"PFN/scatter/backbone/head ({torch.get_num_threads()} threads), {dt:.1f} s"}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--batch", type=int, default=16)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-frames", type=int, default=2)
+    ap.add_argument("--stages", action="store_true", help="also print per-stage GPU times (stderr)")
+    args = ap.parse_args()
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group(backend="nccl")
+    torch.cuda.set_device(local)
+    device = torch.device("cuda", local)
+    torch.backends.cudnn.benchmark = True
+
+    frames, pts, offs, n_max = make_batch(args.batch, rank, device)
+    torch.manual_seed(0)
+    model = PointPillarKITTI(batch_size=args.batch, max_voxels=16000, n_max=n_max, device=device).randomize_for_bench(0)
+
+    def barrier():
+        torch.cuda.synchronize()
+        if dist is not None:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    with torch.no_grad():
+        for _ in range(args.warmup):
+            out = model(pts, offs)
+        barrier()
+        ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(args.steps)]
+        t0 = time.perf_counter()
+        for k in range(args.steps):
+            ev[k][0].record()                       # same stream the kernels are launched on
+            vox = model.voxelize(pts, offs)
+            ev[k][1].record()
+            canvas = model.vfe_scatter(vox)
+            cls, box, dirs = model.backbone_head(canvas)
+            out = model.post_process(cls, box, dirs)
+        barrier()
+        dt = time.perf_counter() - t0
+    if dist is not None:
+        t = torch.tensor([dt], dtype=torch.float64, device=device)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
+
+    vox_ms = float(np.mean([a.elapsed_time(b) for a, b in ev]))
+    total_rows = int(vox["voxel_offsets"][-1].item())
+    npts = int(offs[-1].item())
+    P, C = 32, 4
+    alg_bytes = 16 * npts + total_rows * (P * C * 4 + 16 + 4)          # 16N + V(4PC + 16 + 4)
+    achieved = alg_bytes / (vox_ms * 1e-3) / 1e9
+    frames_total = args.batch * args.steps * world
+    res = {
+        "metric": "frames/sec (fwd+NMS) PointPillar-KITTI", "value": frames_total / dt, "unit": "frames/s",
+        "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": dt / args.steps * 1e3,
+        "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+        "config": {"workload": "PointPillar-KITTI bs=16 per GPU: HIP voxelize + PFN + scatter + rotated NMS, "
+                               "stock-torch fp32 2D backbone/head; cloud_uniform 20k pts/frame, 16k pillars/frame "
+                               "(max_voxels cap), NMS pre 4096 / post 500 / thr 0.01",
+                   "frames_per_step": args.batch, "replicas": world},
+        "roofline": {"bound": "hbm", "kernel": "lidar_voxelize (vx_hash, vx_tile_sums, vx_assign, vx_insert, vx_rows)",
+                     "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
+                     "traffic": None, "alg_bytes_per_launch": alg_bytes, "ms_per_launch": vox_ms},
+    }
+    if args.stages and rank == 0:
+        def gpu_time(fn, n=20):
+            torch.cuda.synchronize()
+            a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            a.record()
+            for _ in range(n):
+                r = fn()
+            b.record()
+            torch.cuda.synchronize()
+            return a.elapsed_time(b) / n, r
+        with torch.no_grad():
+            tv, vox = gpu_time(lambda: model.voxelize(pts, offs))
+            ts, canvas = gpu_time(lambda: model.vfe_scatter(vox))
+            tb, hb = gpu_time(lambda: model.backbone_head(canvas))
+            tp, outp = gpu_time(lambda: model.post_process(*hb))
+        print(f"[stages ms/batch] voxelize {tv:.3f} vfe+scatter {ts:.3f} backbone+head {tb:.3f} post+nms {tp:.3f} "
+              f"kept/frame {outp[3].float().mean().item():.1f}", file=sys.stderr)
+    if rank == 0:
+        if not args.no_cpu_baseline and world == 1:
+            try:
+                res["cpu_baseline"] = cpu_baseline(frames, model, args.cpu_frames)
+            except Exception as e:  # the checker must never sink the measurement
+                res["cpu_baseline"] = {"value": None, "unit": "frames/s", "cores": 0, "kind": "port", "sample": f"failed: {e}"}
+        print(json.dumps(res))
+    if dist is not None:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()
