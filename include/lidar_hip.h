@@ -37,6 +37,9 @@ extern "C" {
  *   range6/voxel_size3/grid3  HOST arrays: [x0,y0,z0,x1,y1,z1], [vx,vy,vz], [nx,ny,nz]
  *   compact       1: frame f's rows start at sum_{g<f} V_g (the collate_batch layout)
  *                 0: frame f's rows start at f*max_voxels
+ *   algo          0: auto; 1: LDS-binned hashing (n_max <= 32768; no global atomics on the critical
+ *                 path; a hash-bin overflow — only reachable with adversarial inputs — sets the sticky
+ *                 flag read by lidar_voxelize_error_flag); 2: global hash table (any n_max)
  *   voxels        (batch*max_voxels, max_points, C) f32; rows [0, total) fully written (zero padded)
  *   coords        (batch*max_voxels, 4) i32 [b, z, y, x]
  *   num_points    (batch*max_voxels) i32
@@ -46,8 +49,10 @@ size_t lidar_voxelize_workspace_bytes(int batch, int n_max, int max_voxels);
 int lidar_voxelize_workspace_init(void *ws, size_t ws_bytes, int batch, int n_max, int max_voxels, void *stream);
 int lidar_voxelize(const float *points, const int *point_offsets, int batch, int n_max, int num_features,
                    const float *range6, const float *voxel_size3, const int *grid3, int max_points,
-                   int max_voxels, int compact, float *voxels, int *coords, int *num_points,
+                   int max_voxels, int compact, int algo, float *voxels, int *coords, int *num_points,
                    int *voxel_offsets, void *ws, size_t ws_bytes, void *stream);
+/* host-synchronous read of the sticky overflow flag of algo 1 (0 = fine); not for use inside captures */
+int lidar_voxelize_error_flag(void *ws, size_t ws_bytes, int batch, int n_max, int max_voxels);
 
 /* ------------------------------------------------------------------ PillarVFE (one PFN layer, eval)
  * Replaces PillarVFE.forward + PFNLayer.forward (pcdet/models/backbones_3d/vfe/pillar_vfe.py:94-123,

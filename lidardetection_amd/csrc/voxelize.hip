@@ -24,15 +24,32 @@
 #define VX_TILE 1024
 #define VX_ROWS_PER_BLOCK 64
 
+typedef float vx_f4 __attribute__((ext_vector_type(4)));
+// streaming (non-temporal) 16-B store: the padded voxel rows are written once and not re-read here
+__device__ __forceinline__ void vx_store_nt(float4 *dst, float4 v) {
+    vx_f4 t = {v.x, v.y, v.z, v.w};
+    __builtin_nontemporal_store(t, reinterpret_cast<vx_f4 *>(dst));
+}
+
 struct VxParams {
     float lo[3];
     float vs[3];
+    float rvs[3];  // fl(1 / vs): only used to skip the IEEE division when the quotient is far from an integer
     int grid[3];  // nx, ny, nz
     int C, P, max_voxels, batch, n_max, compact;
     int H, hshift, ntiles;
+    int dbg;
 };
 
 struct VxWs {
+    // ---- LDS-binned path (algo 1)
+    int *pfirst;     // [B][n_max] index of the first point of the point's voxel (-1 = outside)
+    int *flagw;      // [B][n_max] first points: min(count,P) | VX_SINGLE ; others 0
+    int2 *vinfo;     // [B][n_max] at first points: (voxel rank or -1, list offset)
+    int *err;        // [1] sticky error flag (LDS table / entry list overflow)
+    int2 *queue;     // [B][tile][G][1024] (point, key): each 1024-point tile partitioned by bin
+    int *qcnt;       // [B][tile][G] entries per (tile, bin) segment
+    // ---- global-hash path (algo 2)
     uint32_t *keys;  // [B][H]
     int *first;      // [B][H]
     int *cnt;        // [B][H]
@@ -45,6 +62,11 @@ struct VxWs {
     int *tile_sums;  // [B][ntiles][2]
     int *nvox;       // [B]
 };
+
+static int g_vx_dbg = 0;
+LIDAR_EXPORT void lidar_debug_set(int v) { g_vx_dbg = v; }
+static size_t vx_carve(void *base, int B, int n_max, int max_voxels, struct VxWs *w);
+
 
 static int vx_hash_capacity(int n_max) {
     int h = 1024;
@@ -62,6 +84,12 @@ static size_t vx_carve(void *base, int B, int n_max, int max_voxels, VxWs *w) {
         return (char *)base + o;
     };
     char *p;
+    p = take((size_t)B * (divup(n_max, 2560) * 6144) * 4); if (w) w->pfirst = (int *)p;  // also the LDS path's staging lists
+    p = take((size_t)B * n_max * 4); if (w) w->flagw = (int *)p;
+    p = take((size_t)B * n_max * 8); if (w) w->vinfo = (int2 *)p;
+    p = take(65536); if (w) w->err = (int *)p;  // [0] error flag; rest: debug stamps
+    p = take((size_t)B * divup(n_max, 1024) * divup(n_max, 2560) * 1024 * 8 + 65536); if (w) w->queue = (int2 *)p;  // [B][tile][G][1024]
+    p = take((size_t)B * divup(n_max, 1024) * divup(n_max, 2560) * 4 + 256); if (w) w->qcnt = (int *)p;             // [B][tile][G]
     p = take(B * H * 4); if (w) w->keys = (uint32_t *)p;
     p = take(B * H * 4); if (w) w->first = (int *)p;
     p = take(B * H * 4); if (w) w->cnt = (int *)p;
@@ -77,7 +105,7 @@ static size_t vx_carve(void *base, int B, int n_max, int max_voxels, VxWs *w) {
 }
 
 // ------------------------------------------------------------------ workspace init
-__global__ void vx_ws_init_kernel(VxWs w, long long nh, long long nl) {
+__global__ void vx_ws_init_kernel(VxWs w, long long nh, long long nl, long long nq) {
     long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
     long long stride = (long long)gridDim.x * blockDim.x;
     for (long long k = i; k < nh; k += stride) {
@@ -90,6 +118,7 @@ __global__ void vx_ws_init_kernel(VxWs w, long long nh, long long nl) {
         w.list[k] = VX_INF;
         w.pslot[k] = -1;
     }
+    if (i == 0) *w.err = 0;
 }
 
 // ------------------------------------------------------------------ K1: hash insert
@@ -365,6 +394,432 @@ __global__ __launch_bounds__(256) void vx_rows_kernel(const float *__restrict__ 
     }
 }
 
+
+// ================================================================== LDS-binned path (algo 1)
+// No global atomics at all.  A frame's points are hash-partitioned by voxel key into G bins;
+// workgroup (g, f) streams the whole frame (coalesced float4, L2-resident), keeps the points of its
+// bin, and resolves everything that is local to a voxel inside LDS with LDS atomics:
+//   first point, point count, and the ascending list of its first P point indices (the same
+//   order-independent atomicMin insertion chain as the global path, but on LDS).
+// It leaves one 32-bit word per point (0, or for a voxel's first point: count | list position) and
+// the bin's packed index lists.  A one-block-per-frame ballot scan then ranks the first points
+// (= voxel ids in first-appearance order), and the row writer streams the padded rows.
+#define VXL_S 8192          // LDS table slots per bin
+#define VXL_CAP 6144        // LDS entry / list capacity (points per bin)
+#define VXL_PTS_PER_BIN 2560
+#define VXL_MBITS 14        // pinfo word: m = min(count, P) in the low 14 bits, list position above
+#define VXL_MMASK ((1 << VXL_MBITS) - 1)
+#define VXL_MAX_ITEMS 32    // rank kernel: n_max <= 32 * 1024
+#define VXL_U 8             // points per thread per prefetch step
+
+// floor(fl(d / vs)) — the reference's expression — without paying for the IEEE division when it
+// cannot matter: q' = fl(d * fl(1/vs)) is within 2^-22 (relative) of the true quotient, and so is
+// fl(d / vs); if no integer lies that close to q', both floors are the floor of the true quotient.
+// Otherwise (≈0.1 % of coordinates, NaN/huge values included) the exact division is evaluated.
+__device__ __forceinline__ float vx_floor_div(float d, float vs, float rvs) {
+    float q = d * rvs;
+    if (!(fabsf(q - rintf(q)) > fabsf(q) * 4.8e-7f)) {
+        asm volatile("" ::: "memory");  // keep this a real (rarely taken) branch: no if-conversion of the division
+        q = d / vs;
+    }
+    return floorf(q);
+}
+
+__device__ __forceinline__ bool vx_cell(const VxParams &p, float x, float y, float z, uint32_t &key) {
+    const float fx = vx_floor_div(x - p.lo[0], p.vs[0], p.rvs[0]);
+    const float fy = vx_floor_div(y - p.lo[1], p.vs[1], p.rvs[1]);
+    const float fz = vx_floor_div(z - p.lo[2], p.vs[2], p.rvs[2]);
+    const bool inside = (fx >= 0.f) & (fx < (float)p.grid[0]) & (fy >= 0.f) & (fy < (float)p.grid[1]) &
+                        (fz >= 0.f) & (fz < (float)p.grid[2]);
+    key = inside ? ((uint32_t)fz * (uint32_t)p.grid[1] + (uint32_t)fy) * (uint32_t)p.grid[0] + (uint32_t)fx : 0u;
+    return inside;
+}
+
+// K0: one workgroup per 1024-point tile: voxel key per point, bin = hash(key) % G, and an in-block
+// partition of the tile's (point, key) pairs by bin (wave ballots + a 16 x G LDS count table; no
+// atomics).  Outside-the-grid points get their per-point word (0) here and enter no bin.
+#define VXL_GMAX 16
+#define ITEMS_TILES(p) (((p).n_max + 1023) >> 10)
+template <bool C4>
+__global__ __launch_bounds__(1024) void vxl_key_kernel(const float *__restrict__ points,
+                                                       const int *__restrict__ offsets, VxParams p, VxWs w, int G) {
+    __shared__ int s_wc[16][VXL_GMAX];   // per wave, per bin counts -> exclusive offsets
+    const int tile = blockIdx.x, f = blockIdx.y, t = threadIdx.x, l = t & 63, wv = t >> 6;
+    const int start = offsets[f];
+    const int n = min(offsets[f + 1] - start, p.n_max);
+    const int j = tile * 1024 + t;
+    const int jc = min(j, max(n - 1, 0));
+    float x = 0.f, y = 0.f, z = 0.f;
+    if (n > 0) {  // block-uniform: an empty frame has no row to read
+        if (C4) {
+            const float4 v = reinterpret_cast<const float4 *>(points)[(size_t)start + jc];
+            x = v.x; y = v.y; z = v.z;
+        } else {
+            const float *q = points + ((size_t)start + jc) * p.C;
+            x = q[0]; y = q[1]; z = q[2];
+        }
+    }
+    uint32_t key;
+    const bool inside = vx_cell(p, x, y, z, key) && (j < n);
+    if (j < n && !inside) w.flagw[(size_t)f * p.n_max + j] = 0;
+    const uint32_t h2 = (key * 0x85EBCA6Bu) >> 16;
+    const int bin = inside ? (int)((h2 * (uint32_t)G) >> 16) : -1;
+    int myrank = 0;
+    for (int b = 0; b < G; ++b) {
+        const unsigned long long mm = __ballot(bin == b);
+        if (bin == b) myrank = __popcll(mm & lanemask_lt());
+        if (l == 0) s_wc[wv][b] = __popcll(mm);
+    }
+    __syncthreads();
+    if (t < G) {  // exclusive scan over the 16 waves for bin t; total -> segment count
+        int acc = 0;
+        for (int k = 0; k < 16; ++k) {
+            const int c = s_wc[k][t];
+            s_wc[k][t] = acc;
+            acc += c;
+        }
+        w.qcnt[((size_t)f * gridDim.x + tile) * G + t] = acc;
+    }
+    __syncthreads();
+    if (bin >= 0)
+        w.queue[(((size_t)f * gridDim.x + tile) * G + bin) * 1024 + s_wc[wv][bin] + myrank] = make_int2(j, (int)key);
+}
+
+// K1: workgroup (g, f) = bin g of frame f.
+template <int ITEMS>
+__global__ __launch_bounds__(1024) void vxl_bin_kernel(const int *__restrict__ offsets, VxParams p, VxWs w, int G) {
+    __shared__ uint32_t s_key[VXL_S];   // phase B: keys; phase C..E: list offset of the slot
+    __shared__ int s_first[VXL_S];
+    __shared__ int s_cnt[VXL_S];
+    __shared__ int2 s_q[VXL_CAP];       // phase B: (point, key); afterwards x = point | slot << 15, y = list cell
+    __shared__ int s_wtot[16];
+    __shared__ int s_nent, s_total;
+    const int g = blockIdx.x, f = blockIdx.y, t = threadIdx.x, l = t & 63, wv = t >> 6;
+    long long *stamp = reinterpret_cast<long long *>(w.err + 16) + (size_t)(f * G + g) * 16;
+#define VXL_STAMP(i) if (p.dbg == 9 && t == 0) stamp[i] = (long long)__builtin_amdgcn_s_memtime();
+    VXL_STAMP(0)
+    const int n = min(offsets[f + 1] - offsets[f], p.n_max);
+    // ---- phase B1 (loads): my bin's (point, key) pairs from the ITEMS tile segments written by K0.
+    // Counts and the first 256 entries of every segment are requested together (one memory round trip,
+    // overlapped with the LDS initialisation below); longer segments are topped up afterwards.
+    const int nt = (n + 1023) >> 10;
+    const int *qc = w.qcnt + (size_t)f * ITEMS_TILES(p) * G;
+    int cnt_u[ITEMS];
+    int2 ent[ITEMS];
+#pragma unroll
+    for (int u = 0; u < ITEMS; ++u) cnt_u[u] = qc[min(u, max(nt - 1, 0)) * G + g];
+#pragma unroll
+    for (int u = 0; u < ITEMS; ++u) {
+        const int2 *seg = w.queue + (((size_t)f * ITEMS_TILES(p) + min(u, max(nt - 1, 0))) * G + g) * 1024;
+        ent[u] = seg[min(t, 255)];
+    }
+    for (int k = t; k < VXL_S; k += 1024) {
+        s_key[k] = VX_EMPTY;
+        s_first[k] = VX_INF;
+        s_cnt[k] = 0;
+    }
+    __syncthreads();
+    VXL_STAMP(1)
+    if (p.dbg == 1) return;
+    {
+        int base = 0;
+#pragma unroll
+        for (int u = 0; u < ITEMS; ++u) {
+            const int c = (u < nt) ? cnt_u[u] : 0;
+            if (t < min(c, 256)) {
+                if (base + t < VXL_CAP) s_q[base + t] = ent[u];
+                else atomicOr(w.err, 2);
+            }
+            if (c > 256) {  // block-uniform, rare: a tile that sends more than a quarter of its points to one bin
+                const int2 *seg = w.queue + (((size_t)f * ITEMS_TILES(p) + u) * G + g) * 1024;
+                if (t >= 256 && t < c) {
+                    if (base + t < VXL_CAP) s_q[base + t] = seg[t];
+                    else atomicOr(w.err, 2);
+                }
+            }
+            base += c;
+        }
+        if (t == 0) s_nent = base;
+    }
+    __syncthreads();
+    VXL_STAMP(2)
+    const int ne = min(s_nent, VXL_CAP);
+    // ---- phase B2: dense insertion into the LDS hash table (first point, count per voxel)
+    for (int e = t; e < ne; e += 1024) {
+        const int2 q = s_q[e];
+        const int j = q.x;
+        const uint32_t key = (uint32_t)q.y;
+        uint32_t h = (key * 2654435761u) >> (32 - 13);  // log2(VXL_S) == 13
+        int slot = -1;
+        for (int probe = 0; probe < VXL_S; ++probe) {
+            const uint32_t old = atomicCAS(&s_key[h], VX_EMPTY, key);
+            if (old == VX_EMPTY || old == key) {
+                slot = (int)h;
+                break;
+            }
+            h = (h + 1u) & (VXL_S - 1);
+        }
+        if (slot >= 0) {
+            atomicMin(&s_first[slot], j);
+            atomicAdd(&s_cnt[slot], 1);
+            s_q[e].x = j | (slot << 15);
+        } else {
+            atomicOr(w.err, 1);
+            s_q[e].x = j | (int)0x80000000;
+        }
+    }
+    __syncthreads();
+    VXL_STAMP(3)
+    if (p.dbg == 2) return;
+    // ---- phase C: list offsets = exclusive scan of m = min(count, P) over the slots (8 per thread)
+    int mloc[8];
+    int run = 0;
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {
+        mloc[k] = min(s_cnt[t * 8 + k], p.P);
+        run += mloc[k];
+    }
+    const int inc = wave_incl_scan(run);
+    if (l == 63) s_wtot[wv] = inc;
+    __syncthreads();
+    if (t == 0) {
+        int acc = 0;
+        for (int k = 0; k < 16; ++k) {
+            const int v = s_wtot[k];
+            s_wtot[k] = acc;
+            acc += v;
+        }
+        s_total = acc;
+    }
+    __syncthreads();
+    int off = s_wtot[wv] + inc - run;
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {
+        s_key[t * 8 + k] = (uint32_t)off;
+        off += mloc[k];
+    }
+    const int L = min(s_total, VXL_CAP);
+    for (int k = t; k < L; k += 1024) s_q[k].y = VX_INF;
+    __syncthreads();
+    VXL_STAMP(4)
+    if (p.dbg == 3) return;
+    // ---- phase D: ordered lists (P smallest point indices per voxel, ascending) in LDS
+    for (int e = t; e < ne; e += 1024) {
+        const int en = s_q[e].x;
+        if (en < 0) continue;
+        const int j = en & 0x7FFF, slot = (en >> 15) & 0x1FFF;
+        const int c = s_cnt[slot];
+        int2 *Lp = s_q + s_key[slot];
+        if (c == 1) {
+            Lp[0].y = j;
+        } else {
+            const int m = min(c, p.P);
+            int x = j;
+            for (int s = 0; s < m; ++s) {
+                const int old = atomicMin(&Lp[s].y, x);
+                if (old == VX_INF) break;
+                x = max(old, x);
+            }
+        }
+    }
+    __syncthreads();
+    VXL_STAMP(5)
+    if (p.dbg == 4) return;
+    // ---- phase E: per-point word + this bin's packed lists
+    int *pinfo = w.flagw + (size_t)f * p.n_max;
+    for (int e = t; e < ne; e += 1024) {
+        const int en = s_q[e].x;
+        const int j = en & 0x7FFF;
+        int word = 0;
+        if (en >= 0) {
+            const int slot = (en >> 15) & 0x1FFF;
+            if (s_first[slot] == j) word = min(s_cnt[slot], p.P) | ((g * VXL_CAP + (int)s_key[slot]) << VXL_MBITS);
+        }
+        pinfo[j] = word;
+    }
+    int *stg = w.pfirst + ((size_t)f * G + g) * VXL_CAP;   // staging lists live in the pfirst/vinfo region
+    for (int k = t; k < L; k += 1024) stg[k] = s_q[k].y;
+    VXL_STAMP(6)
+#undef VXL_STAMP
+}
+
+// voxel ids = rank of the first points in point order: ballot scan, one block per frame
+template <int ITEMS>
+__global__ __launch_bounds__(1024) void vxl_rank_kernel(const int *__restrict__ offsets, VxParams p, VxWs w) {
+    __shared__ int s_f[ITEMS * 16 + 1];
+    const int f = blockIdx.x, t = threadIdx.x, wv = t >> 6, l = t & 63;
+    const int n = min(offsets[f + 1] - offsets[f], p.n_max);
+    const int *pinfo = w.flagw + (size_t)f * p.n_max;
+    int word[ITEMS], exf[ITEMS];
+#pragma unroll
+    for (int j = 0; j < ITEMS; ++j) {
+        const int i = j * 1024 + t;
+        const int wv_ = pinfo[min(i, max(n - 1, 0))];  // unconditional load (see vxl_bin_kernel)
+        word[j] = (i < n) ? wv_ : 0;
+    }
+#pragma unroll
+    for (int j = 0; j < ITEMS; ++j) {
+        const unsigned long long bal = __ballot(word[j] != 0);
+        exf[j] = __popcll(bal & lanemask_lt());
+        if (l == 0) s_f[j * 16 + wv] = __popcll(bal);
+    }
+    __syncthreads();
+    if (wv == 0) {  // exclusive scan of the ITEMS*16 (row, wave) counts in row-major order
+        constexpr int NE = ITEMS * 16, PER = (NE + 63) / 64;
+        int a[PER];
+        int sa = 0;
+#pragma unroll
+        for (int k = 0; k < PER; ++k) {
+            const int e = l * PER + k;
+            a[k] = e < NE ? s_f[e] : 0;
+            sa += a[k];
+        }
+        int ea = wave_incl_scan(sa) - sa;
+#pragma unroll
+        for (int k = 0; k < PER; ++k) {
+            const int e = l * PER + k;
+            if (e < NE) s_f[e] = ea;
+            ea += a[k];
+        }
+        if (l == 63) s_f[NE] = ea;
+    }
+    __syncthreads();
+    int *vrow = w.voff + (size_t)f * p.max_voxels;
+#pragma unroll
+    for (int j = 0; j < ITEMS; ++j) {
+        if (word[j] != 0) {
+            const int r = s_f[j * 16 + wv] + exf[j];
+            if (r < p.max_voxels) vrow[r] = word[j];
+        }
+    }
+    if (t == 0) w.nvox[f] = min(s_f[ITEMS * 16], p.max_voxels);
+}
+
+template <bool C4>
+__global__ __launch_bounds__(256) void vxl_rows_kernel(const float *__restrict__ points,
+                                                       const int *__restrict__ offsets, VxParams p, VxWs w, int G,
+                                                       float *__restrict__ voxels, int *__restrict__ coords,
+                                                       int *__restrict__ num_points, int *__restrict__ voxel_offsets) {
+    const int f = blockIdx.y;
+    const int start = offsets[f];
+    // first row of this frame: sum of the earlier frames' voxel counts (lane k holds frame k; batch <= 64
+    // per pass), computed redundantly by every wave: one load latency, no LDS, no barrier
+    int base = f * p.max_voxels;
+    if (p.compact) {
+        int part = 0;
+        for (int k0 = 0; k0 < f; k0 += 64) {
+            const int k = k0 + lane_id();
+            part += (k < f) ? w.nvox[k] : 0;
+        }
+        base = wave_sum(part);
+    }
+    if (blockIdx.x == 0 && f == 0 && threadIdx.x == 0) {  // the batch's offsets table (off the critical path)
+        int b = 0;
+        for (int k = 0; k < p.batch; ++k) {
+            voxel_offsets[k] = p.compact ? b : k * p.max_voxels;
+            b += w.nvox[k];
+        }
+        voxel_offsets[p.batch] = p.compact ? b : p.batch * p.max_voxels;
+    }
+    const int nv = w.nvox[f];
+    const int row0 = blockIdx.x * VX_ROWS_PER_BLOCK;
+    if (row0 >= nv) return;
+    const int rows = min(VX_ROWS_PER_BLOCK, nv - row0);
+    const int *vrow = w.voff + (size_t)f * p.max_voxels;
+    const int *stg = w.pfirst + (size_t)f * G * VXL_CAP;
+    const uint32_t nx = p.grid[0], ny = p.grid[1];
+    if (C4) {
+        const int items = rows * p.P;
+        float4 *out4 = reinterpret_cast<float4 *>(voxels) + (size_t)(base + row0) * p.P;
+        const float4 *pts4 = reinterpret_cast<const float4 *>(points) + start;
+        constexpr int UN = 8;  // 8 x 256 float4 = 32 KiB per pass: all loads of a pass are issued before its stores
+        for (int it0 = threadIdx.x; it0 < items; it0 += 256 * UN) {
+            int word[UN], slot[UN], rix[UN], pidx[UN];
+            float4 v[UN];
+#pragma unroll
+            for (int k = 0; k < UN; ++k) {
+                const int it = it0 + 256 * k;
+                const int rr = it / p.P;
+                slot[k] = it - rr * p.P;
+                rix[k] = row0 + rr;
+                word[k] = (it < items) ? vrow[rix[k]] : 0;
+            }
+#pragma unroll
+            for (int k = 0; k < UN; ++k)
+                pidx[k] = (slot[k] < (word[k] & VXL_MMASK)) ? stg[(word[k] >> VXL_MBITS) + slot[k]] : -1;
+#pragma unroll
+            for (int k = 0; k < UN; ++k) v[k] = pidx[k] >= 0 ? pts4[pidx[k]] : make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+            for (int k = 0; k < UN; ++k) {
+                const int it = it0 + 256 * k;
+                if (it < items) {
+                    if (slot[k] == 0) {  // slot 0 holds the voxel's first point: its cell gives the coords
+                        uint32_t key;
+                        vx_cell(p, v[k].x, v[k].y, v[k].z, key);
+                        reinterpret_cast<int4 *>(coords)[base + rix[k]] =
+                            make_int4(f, (int)(key / (nx * ny)), (int)((key / nx) % ny), (int)(key % nx));
+                        num_points[base + rix[k]] = word[k] & VXL_MMASK;
+                    }
+                    vx_store_nt(out4 + it, v[k]);
+                }
+            }
+        }
+    } else {
+        const int rowlen = p.P * p.C;
+        const int items = rows * rowlen;
+        float *out = voxels + (size_t)(base + row0) * rowlen;
+        const float *pts = points + (size_t)start * p.C;
+        for (int it = threadIdx.x; it < items; it += 256) {
+            const int rr = it / rowlen, e = it - rr * rowlen;
+            const int slot = e / p.C, ch = e - slot * p.C;
+            const int word = vrow[row0 + rr];
+            float v = 0.f;
+            if (slot < (word & VXL_MMASK)) v = pts[(size_t)stg[(word >> VXL_MBITS) + slot] * p.C + ch];
+            out[it] = v;
+        }
+        for (int rr = threadIdx.x; rr < rows; rr += 256) {
+            const int r = row0 + rr;
+            const int word = vrow[r];
+            const float *q = pts + (size_t)stg[word >> VXL_MBITS] * p.C;
+            uint32_t key;
+            vx_cell(p, q[0], q[1], q[2], key);
+            reinterpret_cast<int4 *>(coords)[base + r] =
+                make_int4(f, (int)(key / (nx * ny)), (int)((key / nx) % ny), (int)(key % nx));
+            num_points[base + r] = word & VXL_MMASK;
+        }
+    }
+}
+
+template <int ITEMS>
+static void vxl_rank_launch(int batch, hipStream_t s, const int *offsets, const VxParams &p, const VxWs &w) {
+    hipLaunchKernelGGL(vxl_rank_kernel<ITEMS>, dim3(batch), dim3(1024), 0, s, offsets, p, w);
+}
+
+static int vxl_bins(int n_max) { return divup(n_max, VXL_PTS_PER_BIN); }
+
+static void vxl_run(const float *points, const int *point_offsets, const VxParams &p, const VxWs &w, bool c4,
+                    float *voxels, int *coords, int *num_points, int *voxel_offsets, hipStream_t s) {
+    const int G = vxl_bins(p.n_max);
+    const dim3 gk(divup(p.n_max, 1024), p.batch);
+    if (c4) hipLaunchKernelGGL(vxl_key_kernel<true>, gk, dim3(1024), 0, s, points, point_offsets, p, w, G);
+    else hipLaunchKernelGGL(vxl_key_kernel<false>, gk, dim3(1024), 0, s, points, point_offsets, p, w, G);
+    const int items = divup(p.n_max, 1024);
+    const dim3 gb(G, p.batch);
+    if (items <= 4) hipLaunchKernelGGL(vxl_bin_kernel<4>, gb, dim3(1024), 0, s, point_offsets, p, w, G);
+    else if (items <= 8) hipLaunchKernelGGL(vxl_bin_kernel<8>, gb, dim3(1024), 0, s, point_offsets, p, w, G);
+    else if (items <= 16) hipLaunchKernelGGL(vxl_bin_kernel<16>, gb, dim3(1024), 0, s, point_offsets, p, w, G);
+    else if (items <= 24) hipLaunchKernelGGL(vxl_bin_kernel<24>, gb, dim3(1024), 0, s, point_offsets, p, w, G);
+    else hipLaunchKernelGGL(vxl_bin_kernel<32>, gb, dim3(1024), 0, s, point_offsets, p, w, G);
+    if (items <= 4) vxl_rank_launch<4>(p.batch, s, point_offsets, p, w);
+    else if (items <= 8) vxl_rank_launch<8>(p.batch, s, point_offsets, p, w);
+    else if (items <= 16) vxl_rank_launch<16>(p.batch, s, point_offsets, p, w);
+    else if (items <= 24) vxl_rank_launch<24>(p.batch, s, point_offsets, p, w);
+    else vxl_rank_launch<32>(p.batch, s, point_offsets, p, w);
+    const dim3 grow(divup(p.max_voxels, VX_ROWS_PER_BLOCK), p.batch);
+    if (c4) hipLaunchKernelGGL(vxl_rows_kernel<true>, grow, dim3(256), 0, s, points, point_offsets, p, w, G, voxels, coords, num_points, voxel_offsets);
+    else hipLaunchKernelGGL(vxl_rows_kernel<false>, grow, dim3(256), 0, s, points, point_offsets, p, w, G, voxels, coords, num_points, voxel_offsets);
+}
+
 // ------------------------------------------------------------------ C ABI
 LIDAR_EXPORT size_t lidar_voxelize_workspace_bytes(int batch, int n_max, int max_voxels) {
     if (batch <= 0 || n_max < 0 || max_voxels <= 0) return 0;
@@ -378,13 +833,29 @@ LIDAR_EXPORT int lidar_voxelize_workspace_init(void *ws, size_t ws_bytes, int ba
     VxWs w;
     if (vx_carve(ws, batch, n_max, max_voxels, &w) > ws_bytes) return LIDAR_ERR_WORKSPACE;
     const long long nh = (long long)batch * vx_hash_capacity(n_max), nl = (long long)batch * n_max;
-    hipLaunchKernelGGL(vx_ws_init_kernel, dim3(1024), dim3(256), 0, (hipStream_t)stream, w, nh, nl);
+    hipLaunchKernelGGL(vx_ws_init_kernel, dim3(1024), dim3(256), 0, (hipStream_t)stream, w, nh, nl, 0LL);
     return lidar_check_launch("vx_ws_init");
+}
+
+LIDAR_EXPORT void *lidar_debug_stamp_ptr(void *ws, int batch, int n_max, int max_voxels) {
+    VxWs w;
+    vx_carve(ws, batch, n_max, max_voxels, &w);
+    return w.err + 16;
+}
+
+// sticky overflow flag of the LDS-binned path (0 = fine).  Host-synchronous: call outside captures.
+LIDAR_EXPORT int lidar_voxelize_error_flag(void *ws, size_t ws_bytes, int batch, int n_max, int max_voxels) {
+    VxWs w;
+    if (n_max <= 0) n_max = 1;
+    if (!ws || vx_carve(ws, batch, n_max, max_voxels, &w) > ws_bytes) return LIDAR_ERR_WORKSPACE;
+    int v = 0;
+    if (hipMemcpy(&v, w.err, sizeof(int), hipMemcpyDeviceToHost) != hipSuccess) return LIDAR_ERR_LAUNCH;
+    return v;
 }
 
 LIDAR_EXPORT int lidar_voxelize(const float *points, const int *point_offsets, int batch, int n_max,
                                 int num_features, const float *range6, const float *voxel_size3,
-                                const int *grid3, int max_points, int max_voxels, int compact, float *voxels,
+                                const int *grid3, int max_points, int max_voxels, int compact, int algo, float *voxels,
                                 int *coords, int *num_points, int *voxel_offsets, void *ws, size_t ws_bytes,
                                 void *stream) {
     if (!points || !point_offsets || !voxels || !coords || !num_points || !voxel_offsets || !ws) return LIDAR_ERR_ARG;
@@ -395,6 +866,7 @@ LIDAR_EXPORT int lidar_voxelize(const float *points, const int *point_offsets, i
     for (int j = 0; j < 3; ++j) {
         p.lo[j] = range6[j];
         p.vs[j] = voxel_size3[j];
+        p.rvs[j] = 1.0f / voxel_size3[j];
         p.grid[j] = grid3[j];
     }
     p.C = num_features;
@@ -408,11 +880,19 @@ LIDAR_EXPORT int lidar_voxelize(const float *points, const int *point_offsets, i
     while ((1 << hb) < p.H) ++hb;
     p.hshift = 32 - hb;
     p.ntiles = divup(n_max, VX_TILE);
+    p.dbg = g_vx_dbg;
     VxWs w;
     if (vx_carve(ws, batch, n_max, max_voxels, &w) > ws_bytes) return LIDAR_ERR_WORKSPACE;
     hipStream_t s = (hipStream_t)stream;
     const bool c4 = (num_features == 4) && ((reinterpret_cast<uintptr_t>(points) & 15) == 0) &&
                     ((reinterpret_cast<uintptr_t>(voxels) & 15) == 0);
+    // algo 0 = auto, 1 = LDS-binned (n_max <= 32768, max_points < 65536), 2 = global hash table
+    const bool lds_ok = (n_max <= VXL_MAX_ITEMS * 1024) && (max_points <= VXL_MMASK);
+    if (algo == 1 && !lds_ok) return LIDAR_ERR_ARG;
+    if (algo == 1 || (algo == 0 && lds_ok)) {
+        vxl_run(points, point_offsets, p, w, c4, voxels, coords, num_points, voxel_offsets, s);
+        return lidar_check_launch("lidar_voxelize(lds)");
+    }
     const dim3 gpt(divup(n_max, 256), batch), gtile(p.ntiles, batch);
     if (c4)
         hipLaunchKernelGGL(vx_hash_kernel<true>, gpt, dim3(256), 0, s, points, point_offsets, p, w);

@@ -19,13 +19,14 @@ def grid_size_of(voxel_size, point_cloud_range):
 
 
 class BatchVoxelizer:
-    def __init__(self, voxel_size, point_cloud_range, max_num_points, max_voxels, num_point_features=4):
+    def __init__(self, voxel_size, point_cloud_range, max_num_points, max_voxels, num_point_features=4, algo=0):
         self.voxel_size = [float(np.float32(v)) for v in voxel_size]
         self.point_cloud_range = [float(np.float32(v)) for v in point_cloud_range]
         self.grid_size = grid_size_of(voxel_size, point_cloud_range)  # nx, ny, nz
         self.max_num_points = int(max_num_points)
         self.max_voxels = int(max_voxels)
         self.C = int(num_point_features)
+        self.algo = int(algo)  # 0 auto, 1 LDS-binned, 2 global hash (include/lidar_hip.h)
         self._range_h = _lib.host_f32(self.point_cloud_range)
         self._vs_h = _lib.host_f32(self.voxel_size)
         self._grid_h = _lib.host_i32(self.grid_size)
@@ -69,11 +70,18 @@ class BatchVoxelizer:
             out = self.alloc_outputs(batch, points.device)
         L = _lib.lib()
         _lib.check(L.lidar_voxelize(_lib.ptr(points), _lib.ptr(point_offsets), batch, n_max, self.C, self._range_h,
-                                    self._vs_h, self._grid_h, self.max_num_points, self.max_voxels, int(bool(compact)),
+                                    self._vs_h, self._grid_h, self.max_num_points, self.max_voxels, int(bool(compact)), self.algo,
                                     _lib.ptr(out["voxels"]), _lib.ptr(out["voxel_coords"]),
                                     _lib.ptr(out["voxel_num_points"]), _lib.ptr(out["voxel_offsets"]), _lib.ptr(ws),
                                     nbytes, _lib.stream()), "lidar_voxelize")
         return out
+
+    def check_error_flag(self, batch, n_max, device):
+        """Host-synchronous: raises if the LDS-binned path reported a hash-bin overflow."""
+        ws, nbytes = self._workspace(batch, max(int(n_max), 1), device)
+        flag = _lib.lib().lidar_voxelize_error_flag(_lib.ptr(ws), nbytes, batch, max(int(n_max), 1), self.max_voxels)
+        if flag != 0:
+            raise _lib.LidarHipError(f"lidar_voxelize: LDS hash-bin overflow (flag {flag}); use algo=2")
 
     def voxelize_frames(self, frames, device="cuda"):
         """Convenience: list of (N_f, C) numpy/torch frames -> compact collated tensors, sliced to
@@ -84,5 +92,6 @@ class BatchVoxelizer:
         pts = torch.cat(ts, 0).to(device).contiguous() if sum(sizes) > 0 else torch.zeros((1, self.C), device=device)
         out = self(pts, offs.to(device), max(sizes) if sizes else 1, compact=True)
         total = int(out["voxel_offsets"][-1].item())
+        self.check_error_flag(len(sizes), max(sizes) if sizes else 1, pts.device)
         return {"voxels": out["voxels"][:total], "voxel_coords": out["voxel_coords"][:total],
                 "voxel_num_points": out["voxel_num_points"][:total], "voxel_offsets": out["voxel_offsets"]}

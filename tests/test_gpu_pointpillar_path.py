@@ -18,9 +18,15 @@ pytestmark = pytest.mark.gpu
 
 
 def _check_voxel_parity(frames, vs, rng, P, maxv, C, dev, repeat=2):
-    vz = BatchVoxelizer(vs, rng, P, maxv, num_point_features=C)
     exp = [c_oracle.voxelize(f, vs, rng, P, maxv) for f in frames]
     ev, ec, en = pp_oracle.collate(exp)
+    # both kernel paths: 1 = LDS-binned hashing (default for n_max <= 32768), 2 = global hash table
+    for algo in (1, 2):
+        _check_one_algo(frames, vs, rng, P, maxv, C, dev, repeat, algo, exp, ev, ec, en)
+
+
+def _check_one_algo(frames, vs, rng, P, maxv, C, dev, repeat, algo, exp, ev, ec, en):
+    vz = BatchVoxelizer(vs, rng, P, maxv, num_point_features=C, algo=algo)
     for _ in range(repeat):  # second pass proves the workspace restores itself
         out = vz.voxelize_frames(frames, device=dev)
         offs = out["voxel_offsets"].cpu().numpy()
