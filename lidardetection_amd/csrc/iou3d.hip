@@ -94,12 +94,66 @@ __device__ __forceinline__ bool circles_apart(const BoxPre &A, const BoxPre &B) 
     return dx * dx + dy * dy > rr * rr;
 }
 
-// Per-thread vertex scratch lives in LDS, laid out [slot][thread] (conflict-free): 16 slots of
-// (x, y, angle).  TPB = threads per block of the calling kernel.
+// Separating-axis test on the two rectangles, each inflated by the reference's in-box margin (and a
+// little more for rounding): if an axis of either box separates them, the reference finds no edge
+// crossing and no contained corner, i.e. it returns exactly 0 for the pair.
+__device__ __forceinline__ bool sat_separated_one(const BoxPre &A, const BoxPre &B) {
+    const float m = 0.011f;
+    float umin = 3.0e38f, umax = -3.0e38f, vmin = 3.0e38f, vmax = -3.0e38f;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        const float dx = B.px[k] - A.cx, dy = B.py[k] - A.cy;
+        const float u = dx * A.c + dy * A.s, v = dy * A.c - dx * A.s;
+        umin = fminf(umin, u); umax = fmaxf(umax, u);
+        vmin = fminf(vmin, v); vmax = fmaxf(vmax, v);
+    }
+    const float ex = A.hx * 1.0001f + m, ey = A.hy * 1.0001f + m;
+    return (umin > ex) || (umax < -ex) || (vmin > ey) || (vmax < -ey);
+}
+__device__ __forceinline__ bool sat_separated(const BoxPre &A, const BoxPre &B) {
+    return sat_separated_one(A, B) || sat_separated_one(B, A);
+}
+
+// Per-thread vertex scratch lives in LDS, laid out [slot][thread] (conflict-free): the polygon vertices
+// are APPENDED there (data-dependent count, write-only, no waiting); sorting and the area sum then run
+// on registers with statically indexed, predicated steps.  TPB = threads per block of the caller.
 template <int TPB>
 struct VertScratch {
-    float x[16][TPB], y[16][TPB], a[16][TPB];
+    float x[16][TPB], y[16][TPB];
 };
+
+// the reference's bubble sort by atan2 around the centre (strict >, kernel.cu:199-209) and shoelace
+// fan (:218-224), as the same sequence of compare/swap decisions on M register slots
+template <int M, int TPB>
+__device__ __forceinline__ float polygon_area_sorted(const VertScratch<TPB> &S, int t, int cnt, float ctrx, float ctry) {
+    float vx[M], vy[M], va[M];
+#pragma unroll
+    for (int k = 0; k < M; ++k) {
+        vx[k] = S.x[k][t];
+        vy[k] = S.y[k][t];
+    }
+#pragma unroll
+    for (int k = 0; k < M; ++k) va[k] = atan2f(vy[k] - ctry, vx[k] - ctrx);
+#pragma unroll
+    for (int j = 0; j < M - 1; ++j) {
+#pragma unroll
+        for (int i = 0; i < M - 1 - j; ++i) {
+            const bool sw = (i < cnt - j - 1) && (va[i] > va[i + 1]);
+            const float ax = vx[i], ay = vy[i], aa = va[i];
+            vx[i] = sw ? vx[i + 1] : ax; vy[i] = sw ? vy[i + 1] : ay; va[i] = sw ? va[i + 1] : aa;
+            vx[i + 1] = sw ? ax : vx[i + 1]; vy[i + 1] = sw ? ay : vy[i + 1]; va[i + 1] = sw ? aa : va[i + 1];
+        }
+    }
+    float area = 0.f;
+#pragma unroll
+    for (int k = 0; k < M - 1; ++k) {
+        const float ax = vx[k] - vx[0], ay = vy[k] - vy[0];
+        const float bx = vx[k + 1] - vx[0], by = vy[k + 1] - vy[0];
+        const float term = ax * by - ay * bx;
+        if (k < cnt - 1) area += term;
+    }
+    return fabsf(area) * 0.5f;
+}
 
 // box_overlap (kernel.cu:104-225) on pre-computed boxes.  Polygon of at most 16 vertices.
 template <int TPB>
@@ -137,25 +191,8 @@ __device__ float box_overlap_pre(const BoxPre &A, const BoxPre &B, VertScratch<T
     if (cnt == 0) return 0.f;
     if (cnt > 16) cnt = 16;  // the reference's buffer is Point[16]; unreachable for convex quads
     const float ctrx = sumx / cnt, ctry = sumy / cnt;
-    for (int k = 0; k < cnt; ++k) S.a[k][t] = atan2f(S.y[k][t] - ctry, S.x[k][t] - ctrx);
-    // bubble sort, strict > (kernel.cu:199-209)
-    for (int j = 0; j < cnt - 1; ++j)
-        for (int i = 0; i < cnt - j - 1; ++i) {
-            const float a0 = S.a[i][t], a1 = S.a[i + 1][t];
-            if (a0 > a1) {
-                const float x0 = S.x[i][t], y0 = S.y[i][t];
-                S.x[i][t] = S.x[i + 1][t]; S.y[i][t] = S.y[i + 1][t]; S.a[i][t] = a1;
-                S.x[i + 1][t] = x0; S.y[i + 1][t] = y0; S.a[i + 1][t] = a0;
-            }
-        }
-    float area = 0.f;
-    const float x0 = S.x[0][t], y0 = S.y[0][t];
-    for (int k = 0; k < cnt - 1; ++k) {
-        const float ax = S.x[k][t] - x0, ay = S.y[k][t] - y0;
-        const float bx = S.x[k + 1][t] - x0, by = S.y[k + 1][t] - y0;
-        area += ax * by - ay * bx;
-    }
-    return fabsf(area) * 0.5f;
+    if (cnt <= 8) return polygon_area_sorted<8, TPB>(S, t, cnt, ctrx, ctry);
+    return polygon_area_sorted<16, TPB>(S, t, cnt, ctrx, ctry);
 }
 
 __device__ __forceinline__ float iou_from_overlap(float sa, float sb, float s) {
@@ -200,63 +237,134 @@ __global__ __launch_bounds__(256) void iou_pairwise_kernel(const BoxPre *__restr
 }
 
 // ------------------------------------------------------------------ NMS suppression mask
-// grid = (col_block, row_block, frame); one wave per 64x64 tile; only tiles with col_block >=
-// row_block are computed (the greedy never reads the others).  mask is (n, cb) u64 per frame.
+// grid = (col_block, ceil(row_blocks/4), frame), 256 threads: the 4 waves of a block own 4 row blocks
+// against one 64-box column block (shared in LDS); wave = one 64x64 tile, lane = row.  Only tiles with
+// col_block >= row_block are computed (the greedy never reads the others).  mask is (n, cb) u64.
+// Rotated IoU per tile:
+//   1. bounding-circle test for all 64x64 pairs -> per-lane candidate bits -> compacted pair list (LDS)
+//   2. separating-axis test on the dense pair list; survivors compacted in place
+//   3. polygon intersection, one surviving pair per lane (32 lanes at a time, vertex scratch in LDS)
+#define NMS_PAIR_CAP 1024
+struct NmsWaveLds {
+    unsigned short pairs[NMS_PAIR_CAP];
+    unsigned long long word[64];
+    VertScratch<32> S;
+};
+
 template <bool NORMAL>
-__global__ __launch_bounds__(64) void nms_mask_kernel(const float *__restrict__ boxes_all, const BoxPre *__restrict__ pre_all,
-                                                      const int *__restrict__ counts, int n_max, float thresh,
-                                                      unsigned long long *__restrict__ mask_all) {
-    const int rb = blockIdx.y, cbk = blockIdx.x, f = blockIdx.z;
-    if (cbk < rb) return;
+__global__ __launch_bounds__(256) void nms_mask_kernel(const float *__restrict__ boxes_all, const BoxPre *__restrict__ pre_all,
+                                                       const int *__restrict__ counts, int n_max, float thresh,
+                                                       unsigned long long *__restrict__ mask_all) {
+    __shared__ BoxPre s_pre[64];       // column boxes (rotated)   | NORMAL: raw boxes in the same bytes
+    __shared__ NmsWaveLds s_w[4];
+    const int wv = threadIdx.x >> 6, l = threadIdx.x & 63;
+    const int rb = blockIdx.y * 4 + wv, cbk = blockIdx.x, f = blockIdx.z;
     const int n = counts ? min(counts[f], n_max) : n_max;
-    if (rb * 64 >= n || cbk * 64 >= n) return;
     const int cb_total = (n_max + 63) / 64;
     const float *boxes = boxes_all + (size_t)f * n_max * 7;
     const BoxPre *pre = pre_all + (size_t)f * n_max;
     unsigned long long *mask = mask_all + (size_t)f * n_max * cb_total;
-    const int l = threadIdx.x;
-    const int row = rb * 64 + l, colbase = cbk * 64;
+    const int colbase = cbk * 64;
     const int col_size = min(n - colbase, 64);
+    const bool block_live = (cbk >= (int)blockIdx.y * 4) && (colbase < n) && ((int)blockIdx.y * 256 < n);
+    if (!block_live) return;                                   // block-uniform
+    float *s_raw = reinterpret_cast<float *>(s_pre);
+    if (NORMAL) {
+        for (int k = threadIdx.x; k < col_size * 7; k += 256) s_raw[k] = boxes[(size_t)colbase * 7 + k];
+    } else {
+        if (threadIdx.x < col_size) s_pre[threadIdx.x] = pre[colbase + threadIdx.x];
+    }
+    __syncthreads();
+    if (cbk < rb || rb * 64 >= n) return;                      // wave-uniform; no block barrier below
+    const int row = rb * 64 + l;
     const bool rvalid = row < n;
+    const int start = (rb == cbk) ? l + 1 : 0;
     unsigned long long word = 0ull;
     if (NORMAL) {
-        __shared__ float s_b[64 * 7];
-        for (int k = l; k < col_size * 7; k += 64) s_b[k] = boxes[(size_t)colbase * 7 + k];
-        __syncthreads();
         if (rvalid) {
             float a[7];
 #pragma unroll
             for (int k = 0; k < 7; ++k) a[k] = boxes[(size_t)row * 7 + k];
-            const int start = (rb == cbk) ? l + 1 : 0;
             for (int j = start; j < col_size; ++j)
-                if (iou_normal_dev(a, s_b + j * 7) > thresh) word |= 1ull << j;
+                if (iou_normal_dev(a, s_raw + j * 7) > thresh) word |= 1ull << j;
         }
+    } else if (thresh < 0.f) {
+        // every pair is a hit, disjoint ones included (IoU == 0 > thresh)
+        const unsigned long long all = col_size >= 64 ? ~0ull : ((1ull << col_size) - 1ull);
+        word = (start >= 64) ? 0ull : (all & ~((1ull << start) - 1ull));
     } else {
-        __shared__ BoxPre s_pre[64];
-        __shared__ VertScratch<64> S;
-        if (l < col_size) s_pre[l] = pre[colbase + l];
-        __syncthreads();
-        BoxPre A;
-        if (rvalid) A = pre[row];
-        else A = s_pre[0];
-        // phase 1: cheap circle test -> per-lane candidate set
+        NmsWaveLds &W = s_w[wv];
+        const BoxPre A = pre[rvalid ? row : rb * 64];
+        // 1. circle test, lane = row
         unsigned long long cand = 0ull;
-        const int start = (rb == cbk) ? l + 1 : 0;
-        if (rvalid)
-            for (int j = start; j < col_size; ++j)
-                if (!circles_apart(A, s_pre[j])) cand |= 1ull << j;
-        // a negative threshold makes every pair (even disjoint ones, IoU == 0) a hit
-        if (rvalid && thresh < 0.f) {
-            for (int j = start; j < col_size; ++j)
-                if (!(cand >> j & 1ull)) word |= 1ull << j;
+        if (rvalid) {
+#pragma unroll 16
+            for (int j = 0; j < 64; ++j) {   // fixed trip count: the LDS broadcasts pipeline
+                const bool hit = !circles_apart(A, s_pre[j < col_size ? j : 0]);
+                if (hit && j >= start && j < col_size) cand |= 1ull << j;
+            }
         }
-        // phase 2: polygon code only for candidates
-        while (cand) {
-            const int j = __ffsll((long long)cand) - 1;
-            cand &= cand - 1ull;
-            const BoxPre B = s_pre[j];
-            const float s = box_overlap_pre<64>(A, B, S, l);
-            if (iou_from_overlap(A.area, B.area, s) > thresh) word |= 1ull << j;
+        const int myc = __popcll(cand);
+        const int incl = wave_incl_scan(myc);
+        const int total = __shfl(incl, 63, 64);
+        W.word[l] = 0ull;
+        if (total > NMS_PAIR_CAP) {
+            // pathological tile (most of its 4096 pairs nearly coincide): per-lane sequential evaluation
+            while (cand) {
+                const int j = __ffsll((long long)cand) - 1;
+                cand &= cand - 1ull;
+                bool hitp = false;
+                for (int half = 0; half < 2; ++half) {   // the scratch holds 32 lanes at a time
+                    if ((l >> 5) == half) {
+                        const float sov = box_overlap_pre<32>(A, s_pre[j], W.S, l & 31);
+                        hitp = iou_from_overlap(A.area, s_pre[j].area, sov) > thresh;
+                    }
+                }
+                if (hitp) word |= 1ull << j;
+            }
+        } else {
+            int pos = incl - myc;
+            while (cand) {
+                const int j = __ffsll((long long)cand) - 1;
+                cand &= cand - 1ull;
+                W.pairs[pos++] = (unsigned short)((l << 6) | j);
+            }
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+            // 2. separating-axis test on the dense list, survivors compacted in place
+            int total2 = 0;
+            for (int e0 = 0; e0 < total; e0 += 64) {
+                const int e = e0 + l;
+                unsigned short pr = 0;
+                bool keepit = false;
+                if (e < total) {
+                    pr = W.pairs[e];
+                    keepit = !sat_separated(pre[rb * 64 + (pr >> 6)], s_pre[pr & 63]);
+                }
+                const unsigned long long bal = __ballot(keepit);
+                __builtin_amdgcn_wave_barrier();
+                if (keepit) W.pairs[total2 + __popcll(bal & lanemask_lt())] = pr;
+                total2 += __popcll(bal);
+            }
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+            // 3. polygon intersection: 32 surviving pairs per pass, one per lane of the lower half-wave
+            for (int e0 = 0; e0 < total2; e0 += 32) {
+                const int e = e0 + l;
+                if (l < 32 && e < total2) {
+                    const unsigned short pr = W.pairs[e];
+                    const int i = pr >> 6, j = pr & 63;
+                    const BoxPre Ar = pre[rb * 64 + i], Bc = s_pre[j];
+                    const float sov = box_overlap_pre<32>(Ar, Bc, W.S, l);
+                    if (iou_from_overlap(Ar.area, Bc.area, sov) > thresh) atomicOr(&W.word[i], 1ull << j);
+                }
+            }
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+            word = W.word[l];
         }
     }
     if (rvalid) mask[(size_t)row * cb_total + cbk] = word;
@@ -322,6 +430,86 @@ __global__ __launch_bounds__(GREEDY_TPB) void nms_greedy_kernel(const unsigned l
     if (t == 0) num_keep[f] = s_nkeep;
 }
 
+// ------------------------------------------------------------------ greedy keep, N <= 4096 fast path
+// One block per frame.  All 256 threads stream the mask one 64-row block at a time into LDS (double
+// buffered, coalesced, independent of the decisions), wave 0 walks the decision chain on LDS data only:
+//   lane c keeps remv word c in a register; the 64x64 diagonal tile is resolved by jumping from kept
+//   box to kept box (ctz over the not-yet-suppressed bits, v_readlane of the row's diagonal word);
+//   the kept rows are then OR-ed into remv from LDS (one conflict-free 512-B row read each).
+#define GF_TPB 256
+__global__ __launch_bounds__(GF_TPB) void nms_greedy_fast_kernel(const unsigned long long *__restrict__ mask_all,
+                                                                 const int *__restrict__ counts, int n_max,
+                                                                 long long *__restrict__ keep_all,
+                                                                 int *__restrict__ num_keep) {
+    __shared__ unsigned long long s_tile[2][64][64];
+    const int f = blockIdx.x;
+    const int n = counts ? min(counts[f], n_max) : n_max;
+    const int cb_total = (n_max + 63) / 64;   // <= 64
+    const int cb = (n + 63) / 64;
+    const unsigned long long *mask = mask_all + (size_t)f * n_max * cb_total;
+    long long *keep = keep_all + (size_t)f * n_max;
+    const int t = threadIdx.x, l = t & 63;
+    unsigned long long pre[16];
+    auto fetch = [&](int rb) {  // rows rb*64 .. +63, columns 0..cb_total-1 -> registers
+#pragma unroll
+        for (int k = 0; k < 16; ++k) {
+            const int idx = t + GF_TPB * k, row = idx >> 6, col = idx & 63;
+            const int grow = rb * 64 + row;
+            pre[k] = (rb < cb && grow < n && col < cb_total && col >= rb) ? mask[(size_t)grow * cb_total + col] : 0ull;
+        }
+    };
+    auto stash = [&](int buf) {
+#pragma unroll
+        for (int k = 0; k < 16; ++k) {
+            const int idx = t + GF_TPB * k;
+            s_tile[buf][idx >> 6][idx & 63] = pre[k];
+        }
+    };
+    fetch(0);
+    stash(0);
+    __syncthreads();
+    unsigned long long remv = 0ull;  // wave 0: lane c owns column block c
+    int nkeep = 0;
+    for (int rb = 0; rb < cb; ++rb) {
+        const int buf = rb & 1;
+        fetch(rb + 1);  // in flight while wave 0 decides
+        if (t < 64) {
+            const int row0 = rb * 64;
+            const int lim = min(64, n - row0);
+            const unsigned long long valid = lim >= 64 ? ~0ull : ((1ull << lim) - 1ull);
+            const unsigned long long diag = s_tile[buf][l][rb];   // lane i: diagonal word of row i
+            const unsigned int dlo = (unsigned int)diag, dhi = (unsigned int)(diag >> 32);
+            unsigned long long r = __shfl(remv, rb, 64);
+            r = ((unsigned long long)(unsigned int)__builtin_amdgcn_readfirstlane((int)(r >> 32)) << 32) |
+                (unsigned long long)(unsigned int)__builtin_amdgcn_readfirstlane((int)r);
+            unsigned long long km = 0ull;
+            unsigned long long avail = ~r & valid;
+            while (avail) {   // wave-uniform: one iteration per KEPT box of this block
+                const int i = __ffsll((long long)avail) - 1;
+                km |= 1ull << i;
+                const unsigned long long d =
+                    ((unsigned long long)(unsigned int)__builtin_amdgcn_readlane((int)dhi, i) << 32) |
+                    (unsigned long long)(unsigned int)__builtin_amdgcn_readlane((int)dlo, i);
+                r |= d | (1ull << i);
+                avail = ~r & valid & ~((2ull << i) - 1ull);
+            }
+            if ((km >> l) & 1ull) keep[nkeep + __popcll(km & lanemask_lt())] = row0 + l;
+            nkeep += __popcll(km);
+            unsigned long long acc = 0ull, m = km;
+            while (m) {
+                const int i = __ffsll((long long)m) - 1;
+                m &= m - 1ull;
+                acc |= s_tile[buf][i][l];
+            }
+            if (l > rb) remv |= acc;
+        }
+        __syncthreads();          // everyone is done reading buffer buf^1's predecessor
+        stash(buf ^ 1);
+        __syncthreads();
+    }
+    if (t == 0) num_keep[f] = nkeep;
+}
+
 // ------------------------------------------------------------------ C ABI
 LIDAR_EXPORT size_t lidar_iou_workspace_bytes(int n_a, int n_b) {
     return align_up((size_t)(n_a > 0 ? n_a : 1) * sizeof(BoxPre), 256) + align_up((size_t)(n_b > 0 ? n_b : 1) * sizeof(BoxPre), 256);
@@ -367,13 +555,15 @@ LIDAR_EXPORT int lidar_nms_batch(const float *boxes, const int *counts, int batc
     if (!normal)
         hipLaunchKernelGGL(iou_prep_kernel, dim3(divup((long long)batch * n_max, 256)), dim3(256), 0, s, boxes,
                            batch * n_max, pre);
-    const dim3 grid(cb, cb, batch);
+    const dim3 grid(cb, divup(cb, 4), batch);
     if (normal)
-        hipLaunchKernelGGL(nms_mask_kernel<true>, grid, dim3(64), 0, s, boxes, pre, counts, n_max, thresh, mask);
+        hipLaunchKernelGGL(nms_mask_kernel<true>, grid, dim3(256), 0, s, boxes, pre, counts, n_max, thresh, mask);
     else
-        hipLaunchKernelGGL(nms_mask_kernel<false>, grid, dim3(64), 0, s, boxes, pre, counts, n_max, thresh, mask);
-    hipLaunchKernelGGL(nms_greedy_kernel, dim3(batch), dim3(GREEDY_TPB), 0, s, mask, counts, n_max, keep,
-                       num_keep);
+        hipLaunchKernelGGL(nms_mask_kernel<false>, grid, dim3(256), 0, s, boxes, pre, counts, n_max, thresh, mask);
+    if (cb <= 64)
+        hipLaunchKernelGGL(nms_greedy_fast_kernel, dim3(batch), dim3(GF_TPB), 0, s, mask, counts, n_max, keep, num_keep);
+    else
+        hipLaunchKernelGGL(nms_greedy_kernel, dim3(batch), dim3(GREEDY_TPB), 0, s, mask, counts, n_max, keep, num_keep);
     return lidar_check_launch("lidar_nms_batch");
 }
 

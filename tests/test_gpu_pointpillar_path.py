@@ -125,7 +125,7 @@ def test_iou_matrices_vs_reference_golden(dev, golden_dir):
 
 
 @pytest.mark.parametrize("thresh", [0.01, 0.1, 0.7])
-@pytest.mark.parametrize("seed,objects", [(3000, 512), (3001, 100), (3002, 33)])
+@pytest.mark.parametrize("seed,objects", [(3000, 512), (3001, 100), (3002, 33), (3003, 530)])  # 530*8 > 4096: slow-path greedy
 def test_rotated_nms_keep_bit_exact(dev, thresh, seed, objects):
     boxes, scores = synth.boxes_nms(seed=seed, objects=objects, copies=8)
     if objects == 33:
