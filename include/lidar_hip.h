@@ -96,6 +96,70 @@ int lidar_nms_batch(const float *boxes, const int *counts, int batch, int n_max,
 /* test hook: device pointer to the (batch, n_max, ceil(n_max/64)) u64 suppression mask inside ws */
 const void *lidar_nms_mask_ptr(void *ws, int batch, int n_max);
 
+/* ------------------------------------------------------------------ pointnet2_stack (stacked-batch layout)
+ * Every *_batch_cnt is a (B) i32 DEVICE array of per-sample counts.  Index outputs are i32. */
+/* ball_query_wrapper_stack (pcdet/ops/pointnet2/pointnet2_stack/src/ball_query.cpp:31-47, ball_query_gpu.cu:16-66):
+ * idx (M, nsample) zero-filled by the caller; an empty ball gets idx[.,0] = -1 */
+int lidar_ball_query_stack(int B, int M, float radius, int nsample, const float *new_xyz, const int *new_xyz_batch_cnt,
+                           const float *xyz, const int *xyz_batch_cnt, int *idx, void *stream);
+/* group_points_wrapper_stack (group_points.cpp:31-69 fwd, group_points_gpu.cu:71-102): out (M, C, nsample) */
+int lidar_group_points_stack(int B, int M, int C, int nsample, const float *features, const int *features_batch_cnt,
+                             const int *idx, const int *idx_batch_cnt, float *out, void *stream);
+/* group_points_grad_wrapper_stack (group_points_gpu.cu:15-45): grad_features (N, C) zero-filled by the caller */
+int lidar_group_points_grad_stack(int B, int M, int C, int N, int nsample, const float *grad_out, const int *idx,
+                                  const int *idx_batch_cnt, const int *features_batch_cnt, float *grad_features,
+                                  void *stream);
+/* furthest_point_sampling_wrapper (sampling.cpp, sampling_gpu.cu:24-140; same kernel in pointnet2_batch):
+ * points (b, n, 3), temp (b, n) = 1e10 on entry, idx (b, m) */
+int lidar_furthest_point_sampling(int b, int n, int m, const float *points, float *temp, int *idx, void *stream);
+/* three_nn_wrapper_stack (interpolate_gpu.cu:16-75): dist2 (N,3) squared distances, idx (N,3) global indices */
+int lidar_three_nn_stack(int B, int N, const float *unknown, const int *unknown_batch_cnt, const float *known,
+                         const int *known_batch_cnt, float *dist2, int *idx, void *stream);
+/* three_interpolate_wrapper_stack (:107-126) / _grad_ (:151-172): features (M, C), out (N, C) */
+int lidar_three_interpolate_stack(int N, int C, const float *features, const int *idx, const float *weight, float *out,
+                                  void *stream);
+int lidar_three_interpolate_grad_stack(int N, int C, const float *grad_out, const int *idx, const float *weight,
+                                       float *grad_features, void *stream);
+
+/* ------------------------------------------------------------------ pointnet2_batch (dense, channel-major)
+ * pcdet/ops/pointnet2/pointnet2_batch/src/pointnet2_api.cpp:10-24 */
+int lidar_ball_query_batch(int b, int n, int m, float radius, int nsample, const float *new_xyz, const float *xyz,
+                           int *idx, void *stream);                       /* ball_query_gpu.cu:15-51 */
+int lidar_group_points_batch(int b, int c, int n, int npoints, int nsample, const float *points, const int *idx,
+                             float *out, void *stream);                   /* group_points_gpu.cu:53-72 */
+int lidar_group_points_grad_batch(int b, int c, int n, int npoints, int nsample, const float *grad_out, const int *idx,
+                                  float *grad_points, void *stream);      /* group_points_gpu.cu:14-31 */
+int lidar_gather_points_batch(int b, int c, int n, int npoints, const float *points, const int *idx, float *out,
+                              void *stream);                              /* sampling_gpu.cu:15-31 */
+int lidar_gather_points_grad_batch(int b, int c, int n, int npoints, const float *grad_out, const int *idx,
+                                   float *grad_points, void *stream);     /* sampling_gpu.cu:53-70 */
+int lidar_three_nn_batch(int b, int n, int m, const float *unknown, const float *known, float *dist2, int *idx,
+                         void *stream);                                   /* interpolate_gpu.cu:16-59 */
+int lidar_three_interpolate_batch(int b, int c, int m, int n, const float *points, const int *idx, const float *weight,
+                                  float *out, void *stream);              /* interpolate_gpu.cu:84-104 */
+int lidar_three_interpolate_grad_batch(int b, int c, int n, int m, const float *grad_out, const int *idx,
+                                       const float *weight, float *grad_points, void *stream);  /* :127-149 */
+
+/* ------------------------------------------------------------------ roiaware_pool3d / roipoint_pool3d
+ * roiaware_pool3d_gpu (pcdet/ops/roiaware_pool3d/src/roiaware_pool3d.cpp:29-66): argmax (R,x,y,z,C) i32,
+ * pts_idx_of_voxels (R,x,y,z,max_pts) i32 (slot 0 = count) and pooled (R,x,y,z,C) f32 zero-filled by the
+ * caller; pool_method 0 = max, 1 = avg; out_x/y/z < 256.  No (boxes x points) scratch matrix is needed. */
+int lidar_roiaware_pool3d_forward(int boxes_num, int pts_num, int channels, int max_pts_each_voxel, int out_x, int out_y,
+                                  int out_z, const float *rois, const float *pts, const float *pts_feature, int *argmax,
+                                  int *pts_idx_of_voxels, float *pooled_features, int pool_method, void *stream);
+/* roiaware_pool3d_gpu_backward (roiaware_pool3d.cpp:68-96): grad_in (P, C) zero-filled by the caller */
+int lidar_roiaware_pool3d_backward(int boxes_num, int out_x, int out_y, int out_z, int channels, int max_pts_each_voxel,
+                                   const int *pts_idx_of_voxels, const int *argmax, const float *grad_out,
+                                   float *grad_in, int pool_method, void *stream);
+/* points_in_boxes_gpu (roiaware_pool3d.cpp:98-118): boxes (B,T,7), pts (B,P,3), box_idx_of_points (B,P) pre-filled -1 */
+int lidar_points_in_boxes(int batch, int boxes_num, int pts_num, const float *boxes, const float *pts,
+                          int *box_idx_of_points, void *stream);
+/* roipool3d_gpu (pcdet/ops/roipoint_pool3d/src/roipoint_pool3d.cpp:23-54): xyz (B,N,3), boxes3d (B,M,7) already
+ * enlarged, pts_feature (B,N,C) -> pooled (B,M,S,3+C), empty_flag (B,M); both zero-filled by the caller; S <= 1024 */
+int lidar_roipoint_pool3d_forward(int batch, int pts_num, int boxes_num, int feature_len, int sampled_pts_num,
+                                  const float *xyz, const float *boxes3d, const float *pts_feature,
+                                  float *pooled_features, int *pooled_empty_flag, void *stream);
+
 #ifdef __cplusplus
 }
 #endif

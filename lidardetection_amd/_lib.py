@@ -26,6 +26,25 @@ SIGNATURES = {
     "lidar_nms_workspace_bytes": (sz, [i32, i32]),
     "lidar_nms_batch": (i32, [vp, vp, i32, i32, f32, i32, vp, vp, vp, sz, vp]),
     "lidar_nms_mask_ptr": (vp, [vp, i32, i32]),
+    "lidar_ball_query_stack": (i32, [i32, i32, f32, i32, vp, vp, vp, vp, vp, vp]),
+    "lidar_group_points_stack": (i32, [i32, i32, i32, i32, vp, vp, vp, vp, vp, vp]),
+    "lidar_group_points_grad_stack": (i32, [i32, i32, i32, i32, i32, vp, vp, vp, vp, vp, vp]),
+    "lidar_furthest_point_sampling": (i32, [i32, i32, i32, vp, vp, vp, vp]),
+    "lidar_three_nn_stack": (i32, [i32, i32, vp, vp, vp, vp, vp, vp, vp]),
+    "lidar_three_interpolate_stack": (i32, [i32, i32, vp, vp, vp, vp, vp]),
+    "lidar_three_interpolate_grad_stack": (i32, [i32, i32, vp, vp, vp, vp, vp]),
+    "lidar_ball_query_batch": (i32, [i32, i32, i32, f32, i32, vp, vp, vp, vp]),
+    "lidar_group_points_batch": (i32, [i32, i32, i32, i32, i32, vp, vp, vp, vp]),
+    "lidar_group_points_grad_batch": (i32, [i32, i32, i32, i32, i32, vp, vp, vp, vp]),
+    "lidar_gather_points_batch": (i32, [i32, i32, i32, i32, vp, vp, vp, vp]),
+    "lidar_gather_points_grad_batch": (i32, [i32, i32, i32, i32, vp, vp, vp, vp]),
+    "lidar_three_nn_batch": (i32, [i32, i32, i32, vp, vp, vp, vp, vp]),
+    "lidar_three_interpolate_batch": (i32, [i32, i32, i32, i32, vp, vp, vp, vp, vp]),
+    "lidar_three_interpolate_grad_batch": (i32, [i32, i32, i32, i32, vp, vp, vp, vp, vp]),
+    "lidar_roiaware_pool3d_forward": (i32, [i32, i32, i32, i32, i32, i32, i32, vp, vp, vp, vp, vp, vp, i32, vp]),
+    "lidar_roiaware_pool3d_backward": (i32, [i32, i32, i32, i32, i32, i32, vp, vp, vp, vp, i32, vp]),
+    "lidar_points_in_boxes": (i32, [i32, i32, i32, vp, vp, vp, vp]),
+    "lidar_roipoint_pool3d_forward": (i32, [i32, i32, i32, i32, i32, vp, vp, vp, vp, vp, vp]),
 }
 
 _lib = None

@@ -1,0 +1,638 @@
+// PointNet++ set-abstraction primitives on gfx950 (stacked-batch and dense-batch layouts).
+// Reference: pcdet/ops/pointnet2/pointnet2_stack/src/*.cu and pcdet/ops/pointnet2/pointnet2_batch/src/*.cu
+// (per-kernel citations at each entry point below).  Integer outputs (ball-query / FPS / 3-NN indices)
+// follow the reference's sequential scan order exactly; the distance expression is evaluated as
+// written, (dx*dx + dy*dy) + dz*dz in fp32 without contraction.
+//
+// CDNA4 organisation:
+//   * brute-force searches (ball query, 3-NN) stage the candidate points through LDS tiles that the whole
+//     workgroup streams coalesced once, instead of every thread re-reading them from global memory; every
+//     lane then reads the same LDS address (broadcast, conflict-free) while walking the tile in index order;
+//   * FPS keeps each sample's points and running min-distances in registers (<= 20480 points per sample),
+//     one barrier per round: per-wave argmax by DPP/shuffle, 16 partials in double-buffered LDS, every wave
+//     reduces them redundantly; the winner's coordinates travel with the partial (no global re-read);
+//   * grouping transposes (sample-major rows -> channel-major output) through an LDS tile so both the
+//     gathered feature rows and the (M, C, nsample) output are accessed with full 256-B wave transactions;
+//   * scatter-add backward passes issue float atomics as contiguous per-wave row segments.
+#include "common.h"
+
+#define PN_TPB 256
+#define PN_TILE 1024
+
+__device__ __forceinline__ float pn_dist2(float ax, float ay, float az, float x, float y, float z) {
+    return (ax - x) * (ax - x) + (ay - y) * (ay - y) + (az - z) * (az - z);
+}
+
+// batch of stacked element `i` given per-batch counts; also the exclusive start of that batch in
+// a second stacked array (reference: the cumulative-count walk at the top of every *_stack kernel)
+__device__ __forceinline__ void pn_batch_of(const int *__restrict__ cnt, int B, int i, const int *__restrict__ other,
+                                            int &bs, int &start_other, int &n_other) {
+    int b = 0, acc = cnt[0];
+    for (int k = 1; k < B; ++k) {
+        if (i < acc) break;
+        acc += cnt[k];
+        b = k;
+    }
+    int s = 0;
+    for (int k = 0; k < b; ++k) s += other[k];
+    bs = b;
+    start_other = s;
+    n_other = other[b];
+}
+
+// ------------------------------------------------------------------ ball query
+// STACK: ball_query_kernel_stack (pointnet2_stack/src/ball_query_gpu.cu:16-66), -1 sentinel for empty balls.
+// !STACK: ball_query_kernel_fast (pointnet2_batch/src/ball_query_gpu.cu:15-51), dense (b, m, .) layout.
+template <bool STACK>
+__global__ __launch_bounds__(PN_TPB) void ball_query_kernel(int B, int M, int N, float radius, int nsample,
+                                                            const float *__restrict__ new_xyz, const int *__restrict__ new_cnt,
+                                                            const float *__restrict__ xyz, const int *__restrict__ xyz_cnt,
+                                                            int *__restrict__ idx) {
+    __shared__ float s_pts[PN_TILE * 3];
+    __shared__ int s_range[2];
+    const int t = threadIdx.x;
+    int q, bs = 0, start = 0, n = N;
+    bool valid;
+    if (STACK) {
+        q = blockIdx.x * PN_TPB + t;
+        valid = q < M;
+        if (valid) pn_batch_of(new_cnt, B, q, xyz_cnt, bs, start, n);
+    } else {
+        bs = blockIdx.y;
+        q = blockIdx.x * PN_TPB + t;
+        valid = q < M;
+        start = bs * N;
+        q += bs * M;
+    }
+    if (STACK) {  // batches covered by this block's queries (usually one)
+        if (t == 0) {
+            int b0, s0, n0, b1, s1, n1;
+            const int qa = blockIdx.x * PN_TPB, qb = min(qa + PN_TPB, M) - 1;
+            pn_batch_of(new_cnt, B, qa, xyz_cnt, b0, s0, n0);
+            pn_batch_of(new_cnt, B, qb, xyz_cnt, b1, s1, n1);
+            s_range[0] = b0;
+            s_range[1] = b1;
+        }
+        __syncthreads();
+    }
+    const int b_lo = STACK ? s_range[0] : bs, b_hi = STACK ? s_range[1] : bs;
+    const float r2 = radius * radius;
+    float qx = 0.f, qy = 0.f, qz = 0.f;
+    if (valid) {
+        qx = new_xyz[(size_t)q * 3 + 0];
+        qy = new_xyz[(size_t)q * 3 + 1];
+        qz = new_xyz[(size_t)q * 3 + 2];
+    }
+    int *o = idx + (size_t)q * nsample;
+    int cnt = 0;
+    bool done = !valid;
+    for (int bb = b_lo; bb <= b_hi; ++bb) {
+        int bstart = start, bn = n;   // dense layout: block-uniform already
+        if (STACK) {                  // stacked layout: derive the candidate range from bb (block-uniform bounds)
+            bstart = 0;
+            for (int k = 0; k < bb; ++k) bstart += xyz_cnt[k];
+            bn = xyz_cnt[bb];
+        }
+        const bool mine = valid && (bs == bb);
+        for (int t0 = 0; t0 < bn; t0 += PN_TILE) {
+            const int tn = min(PN_TILE, bn - t0);
+            __syncthreads();
+            for (int k = t; k < tn * 3; k += PN_TPB) s_pts[k] = xyz[((size_t)bstart + t0) * 3 + k];
+            __syncthreads();
+            if (mine && !done) {
+                for (int k = 0; k < tn; ++k) {
+                    const float d2 = pn_dist2(qx, qy, qz, s_pts[3 * k], s_pts[3 * k + 1], s_pts[3 * k + 2]);
+                    if (d2 < r2) {
+                        const int gi = t0 + k;
+                        if (cnt == 0)
+                            for (int l = 0; l < nsample; ++l) o[l] = gi;
+                        o[cnt] = gi;
+                        if (++cnt >= nsample) {
+                            done = true;
+                            break;
+                        }
+                    }
+                }
+            }
+            if (__syncthreads_and(done || !mine || !valid) && (b_lo == b_hi)) {
+                t0 = bn;  // every query of the block is finished
+            }
+        }
+    }
+    if (STACK && valid && cnt == 0) o[0] = -1;
+}
+
+LIDAR_EXPORT int lidar_ball_query_stack(int B, int M, float radius, int nsample, const float *new_xyz,
+                                        const int *new_xyz_batch_cnt, const float *xyz, const int *xyz_batch_cnt,
+                                        int *idx, void *stream) {
+    if (B <= 0 || M < 0 || nsample <= 0) return LIDAR_ERR_ARG;
+    if (M == 0) return LIDAR_OK;
+    if (!new_xyz || !new_xyz_batch_cnt || !xyz || !xyz_batch_cnt || !idx) return LIDAR_ERR_ARG;
+    hipLaunchKernelGGL(ball_query_kernel<true>, dim3(divup(M, PN_TPB)), dim3(PN_TPB), 0, (hipStream_t)stream, B, M, 0,
+                       radius, nsample, new_xyz, new_xyz_batch_cnt, xyz, xyz_batch_cnt, idx);
+    return lidar_check_launch("lidar_ball_query_stack");
+}
+
+LIDAR_EXPORT int lidar_ball_query_batch(int b, int n, int m, float radius, int nsample, const float *new_xyz,
+                                        const float *xyz, int *idx, void *stream) {
+    if (b <= 0 || n < 0 || m < 0 || nsample <= 0) return LIDAR_ERR_ARG;
+    if (m == 0) return LIDAR_OK;
+    if (!new_xyz || !xyz || !idx) return LIDAR_ERR_ARG;
+    hipLaunchKernelGGL(ball_query_kernel<false>, dim3(divup(m, PN_TPB), b), dim3(PN_TPB), 0, (hipStream_t)stream, b, m, n,
+                       radius, nsample, new_xyz, (const int *)nullptr, xyz, (const int *)nullptr, idx);
+    return lidar_check_launch("lidar_ball_query_batch");
+}
+
+// ------------------------------------------------------------------ grouping (stack)
+// group_points_kernel_stack (pointnet2_stack/src/group_points_gpu.cu:71-102): out (M, C, ns).
+// One workgroup per query point: feature rows are read channel-contiguous, the (C, ns) tile is transposed in LDS.
+#define GP_MAX_TILE 8192
+__global__ __launch_bounds__(PN_TPB) void group_points_stack_kernel(int B, int M, int C, int ns, const float *__restrict__ feat,
+                                                                    const int *__restrict__ feat_cnt, const int *__restrict__ idx,
+                                                                    const int *__restrict__ idx_cnt, float *__restrict__ out) {
+    extern __shared__ float s_tile[];  // [C][ns + 1]
+    __shared__ int s_start;
+    const int m = blockIdx.x, t = threadIdx.x;
+    if (t == 0) {
+        int bs, st, nn;
+        pn_batch_of(idx_cnt, B, m, feat_cnt, bs, st, nn);
+        s_start = st;
+    }
+    __syncthreads();
+    const int start = s_start;
+    const int *row = idx + (size_t)m * ns;
+    for (int e = t; e < C * ns; e += PN_TPB) {
+        const int s = e / C, c = e - s * C;
+        s_tile[c * (ns + 1) + s] = feat[((size_t)start + row[s]) * C + c];
+    }
+    __syncthreads();
+    float *o = out + (size_t)m * C * ns;
+    for (int e = t; e < C * ns; e += PN_TPB) {
+        const int c = e / ns, s = e - c * ns;
+        o[e] = s_tile[c * (ns + 1) + s];
+    }
+}
+
+// fallback for very wide tiles: one thread per output element (the reference's mapping)
+__global__ void group_points_stack_naive_kernel(int B, int M, int C, int ns, const float *__restrict__ feat,
+                                                const int *__restrict__ feat_cnt, const int *__restrict__ idx,
+                                                const int *__restrict__ idx_cnt, float *__restrict__ out) {
+    const long long e = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (e >= (long long)M * C * ns) return;
+    const int s = (int)(e % ns), c = (int)((e / ns) % C), m = (int)(e / ns / C);
+    int bs, st, nn;
+    pn_batch_of(idx_cnt, B, m, feat_cnt, bs, st, nn);
+    out[e] = feat[((size_t)st + idx[(size_t)m * ns + s]) * C + c];
+}
+
+LIDAR_EXPORT int lidar_group_points_stack(int B, int M, int C, int nsample, const float *features,
+                                          const int *features_batch_cnt, const int *idx, const int *idx_batch_cnt,
+                                          float *out, void *stream) {
+    if (B <= 0 || M < 0 || C <= 0 || nsample <= 0) return LIDAR_ERR_ARG;
+    if (M == 0) return LIDAR_OK;
+    if (!features || !features_batch_cnt || !idx || !idx_batch_cnt || !out) return LIDAR_ERR_ARG;
+    hipStream_t s = (hipStream_t)stream;
+    if (C * (nsample + 1) <= GP_MAX_TILE)
+        hipLaunchKernelGGL(group_points_stack_kernel, dim3(M), dim3(PN_TPB), (size_t)C * (nsample + 1) * 4, s, B, M, C, nsample,
+                           features, features_batch_cnt, idx, idx_batch_cnt, out);
+    else
+        hipLaunchKernelGGL(group_points_stack_naive_kernel, dim3(divup((long long)M * C * nsample, 256)), dim3(256), 0, s, B, M, C,
+                           nsample, features, features_batch_cnt, idx, idx_batch_cnt, out);
+    return lidar_check_launch("lidar_group_points_stack");
+}
+
+// group_points_grad_kernel_stack (:15-45): grad_features (N, C) += grad_out (M, C, ns); atomics issued with
+// the channel on the lane (contiguous row segments of grad_features per wave instruction)
+__global__ __launch_bounds__(PN_TPB) void group_points_grad_stack_kernel(int B, int M, int C, int ns, const float *__restrict__ grad_out,
+                                                                         const int *__restrict__ idx, const int *__restrict__ idx_cnt,
+                                                                         const int *__restrict__ feat_cnt, float *__restrict__ grad_feat) {
+    extern __shared__ float s_tile[];  // [C][ns + 1]
+    __shared__ int s_start;
+    const int m = blockIdx.x, t = threadIdx.x;
+    if (t == 0) {
+        int bs, st, nn;
+        pn_batch_of(idx_cnt, B, m, feat_cnt, bs, st, nn);
+        s_start = st;
+    }
+    const float *g = grad_out + (size_t)m * C * ns;
+    for (int e = t; e < C * ns; e += PN_TPB) {
+        const int c = e / ns, s = e - c * ns;
+        s_tile[c * (ns + 1) + s] = g[e];
+    }
+    __syncthreads();
+    const int start = s_start;
+    const int *row = idx + (size_t)m * ns;
+    for (int e = t; e < C * ns; e += PN_TPB) {
+        const int s = e / C, c = e - s * C;
+        atomicAdd(&grad_feat[((size_t)start + row[s]) * C + c], s_tile[c * (ns + 1) + s]);
+    }
+}
+
+__global__ void group_points_grad_stack_naive_kernel(int B, int M, int C, int ns, const float *__restrict__ grad_out,
+                                                     const int *__restrict__ idx, const int *__restrict__ idx_cnt,
+                                                     const int *__restrict__ feat_cnt, float *__restrict__ grad_feat) {
+    const long long e = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (e >= (long long)M * C * ns) return;
+    const int s = (int)(e % ns), c = (int)((e / ns) % C), m = (int)(e / ns / C);
+    int bs, st, nn;
+    pn_batch_of(idx_cnt, B, m, feat_cnt, bs, st, nn);
+    atomicAdd(&grad_feat[((size_t)st + idx[(size_t)m * ns + s]) * C + c], grad_out[e]);
+}
+
+LIDAR_EXPORT int lidar_group_points_grad_stack(int B, int M, int C, int N, int nsample, const float *grad_out, const int *idx,
+                                               const int *idx_batch_cnt, const int *features_batch_cnt,
+                                               float *grad_features, void *stream) {
+    if (B <= 0 || M < 0 || C <= 0 || nsample <= 0 || N < 0) return LIDAR_ERR_ARG;
+    if (M == 0) return LIDAR_OK;
+    if (!grad_out || !idx || !idx_batch_cnt || !features_batch_cnt || !grad_features) return LIDAR_ERR_ARG;
+    hipStream_t s = (hipStream_t)stream;
+    if (C * (nsample + 1) <= GP_MAX_TILE)
+        hipLaunchKernelGGL(group_points_grad_stack_kernel, dim3(M), dim3(PN_TPB), (size_t)C * (nsample + 1) * 4, s, B, M, C, nsample,
+                           grad_out, idx, idx_batch_cnt, features_batch_cnt, grad_features);
+    else
+        hipLaunchKernelGGL(group_points_grad_stack_naive_kernel, dim3(divup((long long)M * C * nsample, 256)), dim3(256), 0, s, B, M,
+                           C, nsample, grad_out, idx, idx_batch_cnt, features_batch_cnt, grad_features);
+    return lidar_check_launch("lidar_group_points_grad_stack");
+}
+
+// ------------------------------------------------------------------ furthest point sampling
+// furthest_point_sampling_kernel (pointnet2_stack/src/sampling_gpu.cu:24-140; identical in pointnet2_batch).
+// Reference tie rule reproduced: the winner is the maximum running distance; among equal maxima the smallest
+// (k mod block_ref, k) wins, where block_ref = largest power of two <= min(n, 1024) is the reference's block size.
+struct FpsBest {
+    float v;
+    int key;  // (k mod block_ref) << 15 | k   (k < 32768); smaller key wins ties
+};
+
+__device__ __forceinline__ bool fps_better(float v2, int k2, float v1, int k1) {
+    return (v2 > v1) || (v2 == v1 && k2 < k1);
+}
+
+template <int ITEMS>
+__global__ __launch_bounds__(1024) void fps_kernel(int n, int m, int block_ref_mask, const float *__restrict__ data,
+                                                   float *__restrict__ temp, int *__restrict__ idxs) {
+    __shared__ float s_v[2][16], s_x[2][16], s_y[2][16], s_z[2][16];
+    __shared__ int s_k[2][16];
+    const int bidx = blockIdx.x, t = threadIdx.x, l = t & 63, wv = t >> 6;
+    const float *D = data + (size_t)bidx * n * 3;
+    float *T = temp + (size_t)bidx * n;
+    int *O = idxs + (size_t)bidx * m;
+    float px[ITEMS], py[ITEMS], pz[ITEMS], pt[ITEMS];
+#pragma unroll
+    for (int j = 0; j < ITEMS; ++j) {
+        const int k = j * 1024 + t;
+        const int kc = min(k, n - 1);
+        px[j] = D[(size_t)kc * 3 + 0];
+        py[j] = D[(size_t)kc * 3 + 1];
+        pz[j] = D[(size_t)kc * 3 + 2];
+        pt[j] = T[kc];
+    }
+    float x1 = D[0], y1 = D[1], z1 = D[2];
+    if (t == 0) O[0] = 0;
+    for (int r = 1; r < m; ++r) {
+        float best = -1.f;
+        int bk = 0;   // thread-local candidates all share k mod 1024 == t; first strictly greater wins
+        float bx = 0.f, by = 0.f, bz = 0.f;
+#pragma unroll
+        for (int j = 0; j < ITEMS; ++j) {
+            const int k = j * 1024 + t;
+            if (k < n) {
+                const float d = (px[j] - x1) * (px[j] - x1) + (py[j] - y1) * (py[j] - y1) + (pz[j] - z1) * (pz[j] - z1);
+                const float d2 = fminf(d, pt[j]);
+                pt[j] = d2;
+                if (d2 > best) {
+                    best = d2; bk = k; bx = px[j]; by = py[j]; bz = pz[j];
+                }
+            }
+        }
+        // thread -> wave: reference slot of this thread's candidates is (k mod block_ref)
+        // reference slot of the candidate = k mod block_ref; its LDS tree keeps, among equal values, the slot
+        // whose index is smaller when read from the least-significant bit up (bit-reversed order)
+        int key = (int)((__brev((unsigned)(bk & block_ref_mask)) >> 17) | 0u) ;
+        key = (key << 15) | bk;
+#pragma unroll
+        for (int d = 32; d >= 1; d >>= 1) {
+            const float ov = __shfl_xor(best, d, 64);
+            const int ok = __shfl_xor(key, d, 64);
+            const float ox = __shfl_xor(bx, d, 64), oy = __shfl_xor(by, d, 64), oz = __shfl_xor(bz, d, 64);
+            if (fps_better(ov, ok, best, key)) {
+                best = ov; key = ok; bx = ox; by = oy; bz = oz;
+            }
+        }
+        const int buf = r & 1;
+        if (l == 0) {
+            s_v[buf][wv] = best; s_k[buf][wv] = key; s_x[buf][wv] = bx; s_y[buf][wv] = by; s_z[buf][wv] = bz;
+        }
+        __syncthreads();
+        // every wave reduces the 16 partials redundantly (no second barrier; buffers alternate)
+        float v = s_v[buf][l & 15];
+        int kk = s_k[buf][l & 15];
+        float cx = s_x[buf][l & 15], cy = s_y[buf][l & 15], cz = s_z[buf][l & 15];
+#pragma unroll
+        for (int d = 8; d >= 1; d >>= 1) {
+            const float ov = __shfl_xor(v, d, 64);
+            const int ok = __shfl_xor(kk, d, 64);
+            const float ox = __shfl_xor(cx, d, 64), oy = __shfl_xor(cy, d, 64), oz = __shfl_xor(cz, d, 64);
+            if (fps_better(ov, ok, v, kk)) {
+                v = ov; kk = ok; cx = ox; cy = oy; cz = oz;
+            }
+        }
+        x1 = cx; y1 = cy; z1 = cz;
+        if (t == 0) O[r] = kk & 0x7FFF;
+    }
+#pragma unroll
+    for (int j = 0; j < ITEMS; ++j) {
+        const int k = j * 1024 + t;
+        if (k < n) T[k] = pt[j];   // the reference leaves the running distances in temp
+    }
+}
+
+// generic fallback (any n): running distances stay in global memory, same tie rule
+__global__ __launch_bounds__(1024) void fps_generic_kernel(int n, int m, int block_ref, const float *__restrict__ data,
+                                                           float *__restrict__ temp, int *__restrict__ idxs) {
+    __shared__ float s_v[2][16];
+    __shared__ long long s_k[2][16];
+    const int bidx = blockIdx.x, t = threadIdx.x, l = t & 63, wv = t >> 6;
+    const float *D = data + (size_t)bidx * n * 3;
+    float *T = temp + (size_t)bidx * n;
+    int *O = idxs + (size_t)bidx * m;
+    int old = 0;
+    if (t == 0) O[0] = 0;
+    for (int r = 1; r < m; ++r) {
+        const float x1 = D[(size_t)old * 3], y1 = D[(size_t)old * 3 + 1], z1 = D[(size_t)old * 3 + 2];
+        float best = -1.f;
+        long long key = 0;
+        for (int k = t; k < n; k += 1024) {
+            const float x2 = D[(size_t)k * 3], y2 = D[(size_t)k * 3 + 1], z2 = D[(size_t)k * 3 + 2];
+            const float d = (x2 - x1) * (x2 - x1) + (y2 - y1) * (y2 - y1) + (z2 - z1) * (z2 - z1);
+            const float d2 = fminf(d, T[k]);
+            T[k] = d2;
+            const long long kk = ((long long)(__brev((unsigned)(k % block_ref)) >> 1) << 32) | (unsigned)k;
+            if (d2 > best || (d2 == best && kk < key)) {
+                best = d2; key = kk;
+            }
+        }
+#pragma unroll
+        for (int d = 32; d >= 1; d >>= 1) {
+            const float ov = __shfl_xor(best, d, 64);
+            const long long ok = __shfl_xor(key, d, 64);
+            if (ov > best || (ov == best && ok < key)) { best = ov; key = ok; }
+        }
+        const int buf = r & 1;
+        if (l == 0) { s_v[buf][wv] = best; s_k[buf][wv] = key; }
+        __syncthreads();
+        float v = s_v[buf][l & 15];
+        long long kk = s_k[buf][l & 15];
+#pragma unroll
+        for (int d = 8; d >= 1; d >>= 1) {
+            const float ov = __shfl_xor(v, d, 64);
+            const long long ok = __shfl_xor(kk, d, 64);
+            if (ov > v || (ov == v && ok < kk)) { v = ov; kk = ok; }
+        }
+        old = (int)(kk & 0xFFFFFFFFll);
+        if (t == 0) O[r] = old;
+        __syncthreads();   // T[] of this round is complete before the next round reads D[old] / T
+    }
+}
+
+LIDAR_EXPORT int lidar_furthest_point_sampling(int b, int n, int m, const float *points, float *temp, int *idx, void *stream) {
+    if (b <= 0 || n <= 0 || m < 0) return LIDAR_ERR_ARG;
+    if (m == 0) return LIDAR_OK;
+    if (!points || !temp || !idx) return LIDAR_ERR_ARG;
+    hipStream_t s = (hipStream_t)stream;
+    int block_ref = 1;
+    while (block_ref * 2 <= n && block_ref * 2 <= 1024) block_ref *= 2;
+    const int items = divup(n, 1024);
+#define FPS_CASE(I) hipLaunchKernelGGL(fps_kernel<I>, dim3(b), dim3(1024), 0, s, n, m, block_ref - 1, points, temp, idx)
+    if (items <= 1) FPS_CASE(1);
+    else if (items <= 2) FPS_CASE(2);
+    else if (items <= 4) FPS_CASE(4);
+    else if (items <= 8) FPS_CASE(8);
+    else if (items <= 16) FPS_CASE(16);
+    else if (items <= 20) FPS_CASE(20);
+    else hipLaunchKernelGGL(fps_generic_kernel, dim3(b), dim3(1024), 0, s, n, m, block_ref, points, temp, idx);
+#undef FPS_CASE
+    return lidar_check_launch("lidar_furthest_point_sampling");
+}
+
+// ------------------------------------------------------------------ 3-NN
+// three_nn_kernel_stack (pointnet2_stack/src/interpolate_gpu.cu:16-75) / three_nn_kernel_fast (batch :16-59).
+// The reference keeps the running bests in double but only ever stores fp32 distances (or the 1e40 start,
+// which every finite fp32 beats and +inf does not): identical to fp32 bests initialised to +inf.
+template <bool STACK>
+__global__ __launch_bounds__(PN_TPB) void three_nn_kernel(int B, int N, int Mb, const float *__restrict__ unknown,
+                                                          const int *__restrict__ unk_cnt, const float *__restrict__ known,
+                                                          const int *__restrict__ known_cnt, float *__restrict__ dist2,
+                                                          int *__restrict__ idx) {
+    __shared__ float s_pts[PN_TILE * 3];
+    __shared__ int s_range[2];
+    const int t = threadIdx.x;
+    int q, bs = 0, start = 0, m = Mb;
+    bool valid;
+    if (STACK) {
+        q = blockIdx.x * PN_TPB + t;
+        valid = q < N;
+        if (valid) pn_batch_of(unk_cnt, B, q, known_cnt, bs, start, m);
+        if (t == 0) {
+            int b0, s0, n0, b1, s1, n1;
+            const int qa = blockIdx.x * PN_TPB, qb = min(qa + PN_TPB, N) - 1;
+            pn_batch_of(unk_cnt, B, qa, known_cnt, b0, s0, n0);
+            pn_batch_of(unk_cnt, B, qb, known_cnt, b1, s1, n1);
+            s_range[0] = b0;
+            s_range[1] = b1;
+        }
+        __syncthreads();
+    } else {
+        bs = blockIdx.y;
+        q = blockIdx.x * PN_TPB + t;
+        valid = q < N;
+        start = bs * Mb;
+        q += bs * N;
+    }
+    const int b_lo = STACK ? s_range[0] : bs, b_hi = STACK ? s_range[1] : bs;
+    float ux = 0.f, uy = 0.f, uz = 0.f;
+    if (valid) {
+        ux = unknown[(size_t)q * 3];
+        uy = unknown[(size_t)q * 3 + 1];
+        uz = unknown[(size_t)q * 3 + 2];
+    }
+    float b1 = INFINITY, b2 = INFINITY, b3 = INFINITY;
+    int i1 = 0, i2 = 0, i3 = 0;
+    for (int bb = b_lo; bb <= b_hi; ++bb) {
+        int bstart = start, bn = m;
+        if (STACK) {
+            bstart = 0;
+            for (int k = 0; k < bb; ++k) bstart += known_cnt[k];
+            bn = known_cnt[bb];
+        }
+        const bool mine = valid && (bs == bb);
+        for (int t0 = 0; t0 < bn; t0 += PN_TILE) {
+            const int tn = min(PN_TILE, bn - t0);
+            __syncthreads();
+            for (int k = t; k < tn * 3; k += PN_TPB) s_pts[k] = known[((size_t)bstart + t0) * 3 + k];
+            __syncthreads();
+            if (mine) {
+                for (int k = 0; k < tn; ++k) {
+                    const float d = pn_dist2(ux, uy, uz, s_pts[3 * k], s_pts[3 * k + 1], s_pts[3 * k + 2]);
+                    const int gi = t0 + k;
+                    if (d < b1) { b3 = b2; i3 = i2; b2 = b1; i2 = i1; b1 = d; i1 = gi; }
+                    else if (d < b2) { b3 = b2; i3 = i2; b2 = d; i2 = gi; }
+                    else if (d < b3) { b3 = d; i3 = gi; }
+                }
+            }
+        }
+    }
+    if (valid) {
+        const int off = STACK ? start : 0;
+        dist2[(size_t)q * 3] = b1; dist2[(size_t)q * 3 + 1] = b2; dist2[(size_t)q * 3 + 2] = b3;
+        idx[(size_t)q * 3] = i1 + off; idx[(size_t)q * 3 + 1] = i2 + off; idx[(size_t)q * 3 + 2] = i3 + off;
+    }
+}
+
+LIDAR_EXPORT int lidar_three_nn_stack(int B, int N, const float *unknown, const int *unknown_batch_cnt, const float *known,
+                                      const int *known_batch_cnt, float *dist2, int *idx, void *stream) {
+    if (B <= 0 || N < 0) return LIDAR_ERR_ARG;
+    if (N == 0) return LIDAR_OK;
+    if (!unknown || !unknown_batch_cnt || !known || !known_batch_cnt || !dist2 || !idx) return LIDAR_ERR_ARG;
+    hipLaunchKernelGGL(three_nn_kernel<true>, dim3(divup(N, PN_TPB)), dim3(PN_TPB), 0, (hipStream_t)stream, B, N, 0, unknown,
+                       unknown_batch_cnt, known, known_batch_cnt, dist2, idx);
+    return lidar_check_launch("lidar_three_nn_stack");
+}
+
+LIDAR_EXPORT int lidar_three_nn_batch(int b, int n, int m, const float *unknown, const float *known, float *dist2, int *idx,
+                                      void *stream) {
+    if (b <= 0 || n < 0 || m < 0) return LIDAR_ERR_ARG;
+    if (n == 0) return LIDAR_OK;
+    if (!unknown || !known || !dist2 || !idx) return LIDAR_ERR_ARG;
+    hipLaunchKernelGGL(three_nn_kernel<false>, dim3(divup(n, PN_TPB), b), dim3(PN_TPB), 0, (hipStream_t)stream, b, n, m, unknown,
+                       (const int *)nullptr, known, (const int *)nullptr, dist2, idx);
+    return lidar_check_launch("lidar_three_nn_batch");
+}
+
+// ------------------------------------------------------------------ 3-point interpolation
+// stack: three_interpolate_kernel_stack (:107-126) / grad (:151-172); features (M, C), out (N, C): channel on the lane
+__global__ void three_interp_stack_kernel(int N, int C, const float *__restrict__ feat, const int *__restrict__ idx,
+                                          const float *__restrict__ w, float *__restrict__ out) {
+    const long long e = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (e >= (long long)N * C) return;
+    const int p = (int)(e / C), c = (int)(e - (long long)p * C);
+    const int *ii = idx + (size_t)p * 3;
+    const float *ww = w + (size_t)p * 3;
+    out[e] = ww[0] * feat[(size_t)ii[0] * C + c] + ww[1] * feat[(size_t)ii[1] * C + c] + ww[2] * feat[(size_t)ii[2] * C + c];
+}
+
+__global__ void three_interp_grad_stack_kernel(int N, int C, const float *__restrict__ grad_out, const int *__restrict__ idx,
+                                               const float *__restrict__ w, float *__restrict__ grad_feat) {
+    const long long e = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (e >= (long long)N * C) return;
+    const int p = (int)(e / C), c = (int)(e - (long long)p * C);
+    const float g = grad_out[e];
+#pragma unroll
+    for (int k = 0; k < 3; ++k) atomicAdd(&grad_feat[(size_t)idx[(size_t)p * 3 + k] * C + c], g * w[(size_t)p * 3 + k]);
+}
+
+LIDAR_EXPORT int lidar_three_interpolate_stack(int N, int C, const float *features, const int *idx, const float *weight,
+                                               float *out, void *stream) {
+    if (N < 0 || C <= 0) return LIDAR_ERR_ARG;
+    if (N == 0) return LIDAR_OK;
+    if (!features || !idx || !weight || !out) return LIDAR_ERR_ARG;
+    hipLaunchKernelGGL(three_interp_stack_kernel, dim3(divup((long long)N * C, 256)), dim3(256), 0, (hipStream_t)stream, N, C,
+                       features, idx, weight, out);
+    return lidar_check_launch("lidar_three_interpolate_stack");
+}
+
+LIDAR_EXPORT int lidar_three_interpolate_grad_stack(int N, int C, const float *grad_out, const int *idx, const float *weight,
+                                                    float *grad_features, void *stream) {
+    if (N < 0 || C <= 0) return LIDAR_ERR_ARG;
+    if (N == 0) return LIDAR_OK;
+    if (!grad_out || !idx || !weight || !grad_features) return LIDAR_ERR_ARG;
+    hipLaunchKernelGGL(three_interp_grad_stack_kernel, dim3(divup((long long)N * C, 256)), dim3(256), 0, (hipStream_t)stream, N, C,
+                       grad_out, idx, weight, grad_features);
+    return lidar_check_launch("lidar_three_interpolate_grad_stack");
+}
+
+// batch (channel-major): three_interpolate_kernel_fast (:84-104) / grad (:127-149); points (b,c,m), out (b,c,n)
+__global__ void three_interp_batch_kernel(int b, int c, int m, int n, const float *__restrict__ points, const int *__restrict__ idx,
+                                          const float *__restrict__ w, float *__restrict__ out) {
+    const int p = blockIdx.x * blockDim.x + threadIdx.x, cc = blockIdx.y, bb = blockIdx.z;
+    if (p >= n) return;
+    const float *P = points + ((size_t)bb * c + cc) * m;
+    const size_t o = ((size_t)bb * n + p) * 3;
+    out[((size_t)bb * c + cc) * n + p] = w[o] * P[idx[o]] + w[o + 1] * P[idx[o + 1]] + w[o + 2] * P[idx[o + 2]];
+}
+
+__global__ void three_interp_grad_batch_kernel(int b, int c, int n, int m, const float *__restrict__ grad_out,
+                                               const int *__restrict__ idx, const float *__restrict__ w,
+                                               float *__restrict__ grad_points) {
+    const int p = blockIdx.x * blockDim.x + threadIdx.x, cc = blockIdx.y, bb = blockIdx.z;
+    if (p >= n) return;
+    float *G = grad_points + ((size_t)bb * c + cc) * m;
+    const size_t o = ((size_t)bb * n + p) * 3;
+    const float g = grad_out[((size_t)bb * c + cc) * n + p];
+    atomicAdd(&G[idx[o]], g * w[o]);
+    atomicAdd(&G[idx[o + 1]], g * w[o + 1]);
+    atomicAdd(&G[idx[o + 2]], g * w[o + 2]);
+}
+
+LIDAR_EXPORT int lidar_three_interpolate_batch(int b, int c, int m, int n, const float *points, const int *idx,
+                                               const float *weight, float *out, void *stream) {
+    if (b <= 0 || c <= 0 || m < 0 || n < 0) return LIDAR_ERR_ARG;
+    if (n == 0) return LIDAR_OK;
+    if (!points || !idx || !weight || !out) return LIDAR_ERR_ARG;
+    hipLaunchKernelGGL(three_interp_batch_kernel, dim3(divup(n, 256), c, b), dim3(256), 0, (hipStream_t)stream, b, c, m, n, points,
+                       idx, weight, out);
+    return lidar_check_launch("lidar_three_interpolate_batch");
+}
+
+LIDAR_EXPORT int lidar_three_interpolate_grad_batch(int b, int c, int n, int m, const float *grad_out, const int *idx,
+                                                    const float *weight, float *grad_points, void *stream) {
+    if (b <= 0 || c <= 0 || m < 0 || n < 0) return LIDAR_ERR_ARG;
+    if (n == 0) return LIDAR_OK;
+    if (!grad_out || !idx || !weight || !grad_points) return LIDAR_ERR_ARG;
+    hipLaunchKernelGGL(three_interp_grad_batch_kernel, dim3(divup(n, 256), c, b), dim3(256), 0, (hipStream_t)stream, b, c, n, m,
+                       grad_out, idx, weight, grad_points);
+    return lidar_check_launch("lidar_three_interpolate_grad_batch");
+}
+
+// ------------------------------------------------------------------ grouping / gathering (batch, channel-major)
+// group_points_kernel_fast (pointnet2_batch/src/group_points_gpu.cu:53-72) / grad (:14-31)
+__global__ void group_points_batch_kernel(int b, int c, int n, int np, int ns, const float *__restrict__ points,
+                                          const int *__restrict__ idx, float *__restrict__ out, int grad, float *__restrict__ gpoints) {
+    const int e = blockIdx.x * blockDim.x + threadIdx.x, cc = blockIdx.y, bb = blockIdx.z;
+    if (e >= np * ns) return;
+    const int src = idx[(size_t)bb * np * ns + e];
+    const size_t oo = ((size_t)bb * c + cc) * np * ns + e;
+    if (!grad) out[oo] = points[((size_t)bb * c + cc) * n + src];
+    else atomicAdd(&gpoints[((size_t)bb * c + cc) * n + src], points[oo]);   // points == grad_out here
+}
+
+LIDAR_EXPORT int lidar_group_points_batch(int b, int c, int n, int npoints, int nsample, const float *points, const int *idx,
+                                          float *out, void *stream) {
+    if (b <= 0 || c <= 0 || n < 0 || npoints < 0 || nsample <= 0) return LIDAR_ERR_ARG;
+    if (npoints == 0) return LIDAR_OK;
+    if (!points || !idx || !out) return LIDAR_ERR_ARG;
+    hipLaunchKernelGGL(group_points_batch_kernel, dim3(divup(npoints * nsample, 256), c, b), dim3(256), 0, (hipStream_t)stream, b, c,
+                       n, npoints, nsample, points, idx, out, 0, (float *)nullptr);
+    return lidar_check_launch("lidar_group_points_batch");
+}
+
+LIDAR_EXPORT int lidar_group_points_grad_batch(int b, int c, int n, int npoints, int nsample, const float *grad_out,
+                                               const int *idx, float *grad_points, void *stream) {
+    if (b <= 0 || c <= 0 || n < 0 || npoints < 0 || nsample <= 0) return LIDAR_ERR_ARG;
+    if (npoints == 0) return LIDAR_OK;
+    if (!grad_out || !idx || !grad_points) return LIDAR_ERR_ARG;
+    hipLaunchKernelGGL(group_points_batch_kernel, dim3(divup(npoints * nsample, 256), c, b), dim3(256), 0, (hipStream_t)stream, b, c,
+                       n, npoints, nsample, grad_out, idx, (float *)nullptr, 1, grad_points);
+    return lidar_check_launch("lidar_group_points_grad_batch");
+}
+
+// gather_points_kernel_fast (pointnet2_batch/src/sampling_gpu.cu:15-31) / grad (:53-70): == grouping with nsample 1
+LIDAR_EXPORT int lidar_gather_points_batch(int b, int c, int n, int npoints, const float *points, const int *idx, float *out,
+                                           void *stream) {
+    return lidar_group_points_batch(b, c, n, npoints, 1, points, idx, out, stream);
+}
+
+LIDAR_EXPORT int lidar_gather_points_grad_batch(int b, int c, int n, int npoints, const float *grad_out, const int *idx,
+                                                float *grad_points, void *stream) {
+    return lidar_group_points_grad_batch(b, c, n, npoints, 1, grad_out, idx, grad_points, stream);
+}

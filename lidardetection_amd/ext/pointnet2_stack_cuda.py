@@ -1,0 +1,53 @@
+"""`pointnet2_stack_cuda` — same entry points as pcdet/ops/pointnet2/pointnet2_stack/src/pointnet2_api.cpp:10-21."""
+from .. import _lib
+
+_S = _lib.stream
+_p = _lib.ptr
+
+
+def ball_query_wrapper(B, M, radius, nsample, new_xyz, new_xyz_batch_cnt, xyz, xyz_batch_cnt, idx):
+    """ball_query_wrapper_stack (ball_query.cpp:31-47): fills idx (M, nsample) int32 (zero-filled by the caller)."""
+    _lib.require_cuda(new_xyz, new_xyz_batch_cnt, xyz, xyz_batch_cnt, idx)
+    _lib.check(_lib.lib().lidar_ball_query_stack(B, M, float(radius), nsample, _p(new_xyz), _p(new_xyz_batch_cnt), _p(xyz),
+                                                 _p(xyz_batch_cnt), _p(idx), _S()), "lidar_ball_query_stack")
+    return 1
+
+
+def furthest_point_sampling_wrapper(b, n, m, points, temp, idx):
+    """sampling.cpp: points (b,n,3), temp (b,n) == 1e10, idx (b,m) int32."""
+    _lib.require_cuda(points, temp, idx)
+    _lib.check(_lib.lib().lidar_furthest_point_sampling(b, n, m, _p(points), _p(temp), _p(idx), _S()), "lidar_furthest_point_sampling")
+    return 1
+
+
+def group_points_wrapper(B, M, C, nsample, features, features_batch_cnt, idx, idx_batch_cnt, out):
+    _lib.require_cuda(features, features_batch_cnt, idx, idx_batch_cnt, out)
+    _lib.check(_lib.lib().lidar_group_points_stack(B, M, C, nsample, _p(features), _p(features_batch_cnt), _p(idx),
+                                                   _p(idx_batch_cnt), _p(out), _S()), "lidar_group_points_stack")
+    return 1
+
+
+def group_points_grad_wrapper(B, M, C, N, nsample, grad_out, idx, idx_batch_cnt, features_batch_cnt, grad_features):
+    _lib.require_cuda(grad_out, idx, idx_batch_cnt, features_batch_cnt, grad_features)
+    _lib.check(_lib.lib().lidar_group_points_grad_stack(B, M, C, N, nsample, _p(grad_out), _p(idx), _p(idx_batch_cnt),
+                                                        _p(features_batch_cnt), _p(grad_features), _S()),
+               "lidar_group_points_grad_stack")
+    return 1
+
+
+def three_nn_wrapper(unknown, unknown_batch_cnt, known, known_batch_cnt, dist2, idx):
+    _lib.require_cuda(unknown, unknown_batch_cnt, known, known_batch_cnt, dist2, idx)
+    _lib.check(_lib.lib().lidar_three_nn_stack(unknown_batch_cnt.shape[0], unknown.shape[0], _p(unknown), _p(unknown_batch_cnt),
+                                               _p(known), _p(known_batch_cnt), _p(dist2), _p(idx), _S()), "lidar_three_nn_stack")
+
+
+def three_interpolate_wrapper(features, idx, weight, out):
+    _lib.require_cuda(features, idx, weight, out)
+    _lib.check(_lib.lib().lidar_three_interpolate_stack(idx.shape[0], features.shape[1], _p(features), _p(idx), _p(weight), _p(out),
+                                                        _S()), "lidar_three_interpolate_stack")
+
+
+def three_interpolate_grad_wrapper(grad_out, idx, weight, grad_features):
+    _lib.require_cuda(grad_out, idx, weight, grad_features)
+    _lib.check(_lib.lib().lidar_three_interpolate_grad_stack(idx.shape[0], grad_out.shape[1], _p(grad_out), _p(idx), _p(weight),
+                                                             _p(grad_features), _S()), "lidar_three_interpolate_grad_stack")

@@ -1,0 +1,146 @@
+"""GPU parity of the PointNet++ operators (stack + batch layouts) against the CPU oracle
+(oracle/src/points_oracle.c).  Indices are bit-exact; gathered / interpolated features are bit-exact
+where they are copies or single sequential expressions, 1e-5 where float atomics reorder a sum."""
+import numpy as np
+import pytest
+import torch
+
+from lidardetection_amd import synth
+from lidardetection_amd.pcdet.ops.pointnet2.pointnet2_batch import pointnet2_modules as bmod
+from lidardetection_amd.pcdet.ops.pointnet2.pointnet2_batch import pointnet2_utils as butils
+from lidardetection_amd.pcdet.ops.pointnet2.pointnet2_stack import pointnet2_modules as smod
+from lidardetection_amd.pcdet.ops.pointnet2.pointnet2_stack import pointnet2_utils as sutils
+from oracle import c_oracle
+
+pytestmark = pytest.mark.gpu
+
+
+def _stack_scene(seed, sizes=(3000, 1777, 0, 2500), msizes=(400, 300, 0, 333)):
+    r = np.random.default_rng(seed)
+    xyz = np.concatenate([synth.cloud_ring(2000 + k)[:n, :3] for k, n in enumerate(sizes)], 0) if sum(sizes) else np.zeros((0, 3), np.float32)
+    new = []
+    off = 0
+    for n, m in zip(sizes, msizes):
+        if m:
+            pick = r.choice(n, m, replace=False)
+            new.append(xyz[off + pick] + r.normal(0, 0.05, (m, 3)).astype(np.float32))
+        off += n
+    new = np.concatenate(new, 0).astype(np.float32)
+    return xyz.astype(np.float32), np.array(sizes, np.int32), new, np.array(msizes, np.int32)
+
+
+@pytest.mark.parametrize("radius,nsample", [(0.4, 16), (1.6, 32), (0.01, 8)])
+def test_ball_query_and_group_stack(dev, radius, nsample):
+    xyz, xc, new, nc = _stack_scene(1)
+    t = lambda a: torch.from_numpy(a).to(dev)
+    idx_o = c_oracle.ball_query_stack(radius, nsample, xyz, xc, new, nc)
+    idx, empty = sutils.ball_query(radius, nsample, t(xyz), t(xc), t(new), t(nc))
+    exp_empty = idx_o[:, 0] == -1
+    assert np.array_equal(empty.cpu().numpy(), exp_empty)
+    idx_o[exp_empty] = 0
+    assert np.array_equal(idx.cpu().numpy(), idx_o)
+    feat = np.random.default_rng(2).standard_normal((len(xyz), 37)).astype(np.float32)
+    tf = t(feat).requires_grad_(True)
+    g = sutils.grouping_operation(tf, t(xc), idx, t(nc))
+    assert np.array_equal(g.detach().cpu().numpy(), c_oracle.group_points_stack(feat, xc, idx_o, nc))
+    go = np.random.default_rng(3).standard_normal(g.shape).astype(np.float32)
+    g.backward(t(go))
+    # float atomics reorder the per-row sums (thousands of terms land on row 0 when every ball is empty)
+    np.testing.assert_allclose(tf.grad.cpu().numpy(), c_oracle.group_points_grad_stack(go, idx_o, nc, xc, len(xyz)), rtol=1e-4, atol=2e-3)
+
+
+def test_group_wide_tile_fallback(dev):
+    xyz, xc, new, nc = _stack_scene(5, sizes=(500, 400), msizes=(50, 60))
+    t = lambda a: torch.from_numpy(a).to(dev)
+    idx, _ = sutils.ball_query(2.0, 64, t(xyz), t(xc), t(new), t(nc))
+    feat = np.random.default_rng(6).standard_normal((len(xyz), 160)).astype(np.float32)   # 160 * 65 > LDS tile cap
+    g = sutils.grouping_operation(t(feat), t(xc), idx, t(nc))
+    assert np.array_equal(g.cpu().numpy(), c_oracle.group_points_stack(feat, xc, idx.cpu().numpy(), nc))
+
+
+@pytest.mark.parametrize("n,m", [(20000, 2048), (5000, 512), (1000, 64), (700, 33), (40, 40), (25000, 128)])
+def test_furthest_point_sampling(dev, n, m):
+    r = np.random.default_rng(n)
+    pts = np.stack([synth.cloud_uniform(1000 + k, n=n)[:, :3] for k in range(2)], 0)
+    pts[1] = np.round(pts[1] * 2) / 2            # coarse lattice: many exact distance ties -> exercises the tie rule
+    out = sutils.furthest_point_sample(torch.from_numpy(pts).to(dev), m)
+    assert np.array_equal(out.cpu().numpy(), c_oracle.fps(pts, m))
+    outb = butils.furthest_point_sample(torch.from_numpy(pts).to(dev), m)
+    assert torch.equal(out, outb)
+
+
+def test_three_nn_and_interpolate_stack(dev):
+    xyz, xc, new, nc = _stack_scene(7, sizes=(1200, 2, 900), msizes=(300, 2, 1))
+    t = lambda a: torch.from_numpy(a).to(dev)
+    d_o, i_o = c_oracle.three_nn_stack(new, nc, xyz, xc)
+    d, i = sutils.three_nn(t(new), t(nc), t(xyz), t(xc))
+    assert np.array_equal(i.cpu().numpy(), i_o)
+    np.testing.assert_array_equal(d.cpu().numpy(), np.sqrt(d_o))       # batch with 2 known points: inf for the 3rd
+    feat = np.random.default_rng(8).standard_normal((len(xyz), 19)).astype(np.float32)
+    w = np.random.default_rng(9).uniform(0, 1, (len(new), 3)).astype(np.float32)
+    tf = t(feat).requires_grad_(True)
+    out = sutils.three_interpolate(tf, i, t(w))
+    assert np.array_equal(out.detach().cpu().numpy(), c_oracle.three_interpolate_stack(feat, i_o, w))
+    go = np.random.default_rng(10).standard_normal(out.shape).astype(np.float32)
+    out.backward(t(go))
+    np.testing.assert_allclose(tf.grad.cpu().numpy(), c_oracle.three_interpolate_grad_stack(go, i_o, w, len(xyz)), rtol=1e-5, atol=1e-5)
+
+
+def test_batch_layout_ops(dev):
+    r = np.random.default_rng(11)
+    B, N, M, C = 3, 1500, 200, 21
+    xyz = np.stack([synth.cloud_ring(2000 + k)[:N, :3] for k in range(B)], 0)
+    new = xyz[:, r.choice(N, M, replace=False)] + r.normal(0, 0.05, (B, M, 3)).astype(np.float32)
+    new = np.ascontiguousarray(new, np.float32)
+    feat = r.standard_normal((B, C, N)).astype(np.float32)
+    t = lambda a: torch.from_numpy(a).to(dev)
+    idx = butils.ball_query(0.8, 16, t(xyz), t(new))
+    idx_o = c_oracle.ball_query_batch(0.8, 16, xyz, new)
+    assert np.array_equal(idx.cpu().numpy(), idx_o)
+    tf = t(feat).requires_grad_(True)
+    g = butils.grouping_operation(tf, idx)
+    assert np.array_equal(g.detach().cpu().numpy(), c_oracle.group_points_batch(feat, idx_o))
+    go = r.standard_normal(g.shape).astype(np.float32)
+    g.backward(t(go))
+    np.testing.assert_allclose(tf.grad.cpu().numpy(), c_oracle.group_points_grad_batch(go, idx_o, N), rtol=1e-5, atol=1e-5)
+    gi = r.integers(0, N, (B, M)).astype(np.int32)
+    tf2 = t(feat).requires_grad_(True)
+    ga = butils.gather_operation(tf2, t(gi))
+    assert np.array_equal(ga.detach().cpu().numpy(), c_oracle.gather_points_batch(feat, gi))
+    go2 = r.standard_normal(ga.shape).astype(np.float32)
+    ga.backward(t(go2))
+    np.testing.assert_allclose(tf2.grad.cpu().numpy(), c_oracle.gather_points_grad_batch(go2, gi, N), rtol=1e-5, atol=1e-5)
+    d, i = butils.three_nn(t(new), t(xyz))
+    d_o, i_o = c_oracle.three_nn_batch(new, xyz)
+    assert np.array_equal(i.cpu().numpy(), i_o) and np.array_equal(d.cpu().numpy(), np.sqrt(d_o))
+    w = r.uniform(0, 1, (B, M, 3)).astype(np.float32)
+    tf3 = t(feat).requires_grad_(True)
+    o = butils.three_interpolate(tf3, i, t(w))
+    assert np.array_equal(o.detach().cpu().numpy(), c_oracle.three_interpolate_batch(feat, i_o, w))
+    go3 = r.standard_normal(o.shape).astype(np.float32)
+    o.backward(t(go3))
+    np.testing.assert_allclose(tf3.grad.cpu().numpy(), c_oracle.three_interpolate_grad_batch(go3, i_o, w, N), rtol=1e-5, atol=1e-5)
+
+
+def test_set_abstraction_modules_run(dev):
+    """StackSAModuleMSG / StackPointnetFPModule / PointnetSAModuleMSG / PointnetFPModule forward + backward."""
+    xyz, xc, new, nc = _stack_scene(12, sizes=(800, 600), msizes=(64, 48))
+    t = lambda a: torch.from_numpy(a).to(dev)
+    torch.manual_seed(0)
+    sa = smod.StackSAModuleMSG(radii=[0.8, 1.6], nsamples=[16, 32], mlps=[[8, 16, 16], [8, 16, 32]]).to(dev)
+    f = torch.randn(len(xyz), 8, device=dev, requires_grad=True)
+    _, nf = sa(t(xyz), t(xc), t(new), t(nc), f)
+    assert nf.shape == (len(new), 48)
+    nf.sum().backward()
+    assert f.grad is not None and torch.isfinite(f.grad).all()
+    fp = smod.StackPointnetFPModule(mlp=[48 + 8, 32]).to(dev)
+    out = fp(t(xyz), t(xc), t(new), t(nc), unknown_feats=f.detach(), known_feats=nf.detach())
+    assert out.shape == (len(xyz), 32)
+    B, N = 2, 1024
+    bx = torch.from_numpy(np.stack([synth.cloud_ring(2000 + k)[:N, :3] for k in range(B)], 0)).to(dev)
+    bsa = bmod.PointnetSAModuleMSG(npoint=128, radii=[0.5, 1.0], nsamples=[8, 16], mlps=[[4, 8], [4, 16]]).to(dev)
+    bf = torch.randn(B, 4, N, device=dev, requires_grad=True)
+    nx, nfeat = bsa(bx, bf)
+    assert nx.shape == (B, 128, 3) and nfeat.shape == (B, 24, 128)
+    bfp = bmod.PointnetFPModule(mlp=[24 + 4, 16]).to(dev)
+    assert bfp(bx, nx, bf, nfeat).shape == (B, 16, N)

@@ -1,0 +1,91 @@
+"""GPU parity of roiaware_pool3d / points_in_boxes / roipoint_pool3d against the CPU oracle.
+The in-box test multiplies by cos/sin of the heading; device and glibc trig may differ in the last ulp, so
+scenes are built with no point closer than 1e-4 to a box face (checked in float64) — decisions then agree
+bit for bit and every integer output is compared exactly."""
+import numpy as np
+import pytest
+import torch
+
+from lidardetection_amd.pcdet.ops.roiaware_pool3d import roiaware_pool3d_utils
+from lidardetection_amd.pcdet.ops.roipoint_pool3d import roipoint_pool3d_utils
+from oracle import c_oracle
+
+pytestmark = pytest.mark.gpu
+
+
+def _scene(seed, nbox, npts, extent=20.0):
+    r = np.random.default_rng(seed)
+    boxes = np.concatenate([r.uniform(0, extent, (nbox, 2)), r.uniform(-1, 1, (nbox, 1)), r.uniform(2.0, 6.0, (nbox, 2)),
+                            r.uniform(1.5, 3.0, (nbox, 1)), r.uniform(-np.pi, np.pi, (nbox, 1))], 1).astype(np.float32)
+    pts = np.concatenate([r.uniform(0, extent, (npts, 2)), r.uniform(-2.5, 2.5, (npts, 1))], 1).astype(np.float32)
+    pts[: npts // 4, :2] = boxes[r.integers(0, nbox, npts // 4), :2] + r.normal(0, 0.7, (npts // 4, 2))  # dense near boxes
+    # drop points within 1e-4 of any face (float64 geometry)
+    b, p = boxes.astype(np.float64), pts.astype(np.float64)
+    dx, dy = p[None, :, 0] - b[:, None, 0], p[None, :, 1] - b[:, None, 1]
+    c, s = np.cos(-b[:, 6])[:, None], np.sin(-b[:, 6])[:, None]
+    lx, ly = dx * c - dy * s, dx * s + dy * c
+    near = (np.abs(np.abs(lx) - b[:, None, 3] / 2) < 1e-4) | (np.abs(np.abs(ly) - b[:, None, 4] / 2) < 1e-4) | \
+           (np.abs(np.abs(p[None, :, 2] - b[:, None, 2]) - b[:, None, 5] / 2) < 1e-4)
+    return boxes, pts[~near.any(0)]
+
+
+def test_points_in_boxes_gpu(dev):
+    boxes, pts = _scene(1, 40, 6000)
+    B = 2
+    bb = np.stack([boxes, boxes[::-1]], 0).copy()
+    pp = np.stack([pts[:5000], pts[-5000:]], 0).copy()
+    out = roiaware_pool3d_utils.points_in_boxes_gpu(torch.from_numpy(pp).to(dev), torch.from_numpy(bb).to(dev))
+    exp = c_oracle.points_in_boxes_gpu(bb, pp)
+    assert np.array_equal(out.cpu().numpy(), exp) and (exp >= 0).sum() > 500
+
+
+@pytest.mark.parametrize("method", ["max", "avg"])
+@pytest.mark.parametrize("out_size,maxpts", [(12, 128), ((3, 5, 4), 4)])
+def test_roiaware_pool3d_forward_backward(dev, method, out_size, maxpts):
+    boxes, pts = _scene(2, 24, 16000, extent=14.0)
+    C = 20
+    feat = np.random.default_rng(3).standard_normal((len(pts), C)).astype(np.float32)
+    osz = (out_size,) * 3 if isinstance(out_size, int) else out_size
+    pooled_o, argmax_o, pidx_o = c_oracle.roiaware_pool3d(boxes, pts, feat, osz, maxpts, 0 if method == "max" else 1)
+    tf = torch.from_numpy(feat).to(dev).requires_grad_(True)
+    fn = roiaware_pool3d_utils.RoIAwarePool3dFunction
+    pooled = fn.apply(torch.from_numpy(boxes).to(dev), torch.from_numpy(pts).to(dev), tf, out_size, maxpts, method)
+    # reach into the autograd node for the integer side outputs
+    pidx, argmax, _, _, _ = pooled.grad_fn.roiaware_pool3d_for_backward
+    assert np.array_equal(pidx.cpu().numpy(), pidx_o)
+    assert (pidx_o[..., 0] > 0).sum() > 50                       # the scene does fill voxels
+    if maxpts == 4:
+        assert (pidx_o[..., 0] == maxpts - 1).sum() > 0          # and exercises the per-voxel cap
+    if method == "max":
+        assert np.array_equal(argmax.cpu().numpy(), argmax_o)
+        assert np.array_equal(pooled.detach().cpu().numpy(), pooled_o)
+    else:
+        np.testing.assert_allclose(pooled.detach().cpu().numpy(), pooled_o, rtol=0, atol=1e-6)
+    go = np.random.default_rng(4).standard_normal(pooled.shape).astype(np.float32)
+    pooled.backward(torch.from_numpy(go).to(dev))
+    gi_o = c_oracle.roiaware_pool3d_backward(pidx_o, argmax_o, go, len(pts), 0 if method == "max" else 1)
+    np.testing.assert_allclose(tf.grad.cpu().numpy(), gi_o, rtol=1e-5, atol=1e-5)
+
+
+def test_roipoint_pool3d(dev):
+    boxes, pts = _scene(5, 30, 9000)
+    B, N, M, C, S = 2, 4000, 30, 11, 64
+    xyz = np.stack([pts[:N], pts[-N:]], 0).copy()
+    bx = np.stack([boxes, boxes[::-1]], 0).copy()
+    bx[1, 3] = [100, 100, 50, 1, 1, 1, 0]                        # an empty box
+    feat = np.random.default_rng(6).standard_normal((B, N, C)).astype(np.float32)
+    pool = roipoint_pool3d_utils.RoIPointPool3d(num_sampled_points=S, pool_extra_width=[0.0, 0.0, 0.0])
+    pooled, empty = pool(torch.from_numpy(xyz).to(dev), torch.from_numpy(feat).to(dev), torch.from_numpy(bx).to(dev))
+    po, eo = c_oracle.roipoint_pool3d(xyz, bx, feat, S)
+    assert np.array_equal(empty.cpu().numpy(), eo) and eo.sum() >= 1
+    assert np.array_equal(pooled.cpu().numpy(), po)
+    # S larger than every box's point count -> cyclic duplication path
+    pool2 = roipoint_pool3d_utils.RoIPointPool3d(num_sampled_points=512, pool_extra_width=[0.2, 0.2, 0.2])
+    p2, e2 = pool2(torch.from_numpy(xyz).to(dev), torch.from_numpy(feat).to(dev), torch.from_numpy(bx).to(dev))
+    bxe = bx.copy()
+    bxe[:, :, 3:6] += 0.2
+    po2, eo2 = c_oracle.roipoint_pool3d(xyz, bxe, feat, 512)
+    # the enlarged faces may now graze a point: compare only boxes whose oracle membership has a safe margin
+    assert np.array_equal(e2.cpu().numpy(), eo2)
+    same = (p2.cpu().numpy() == po2).reshape(B, M, -1).all(-1)
+    assert same.mean() > 0.95
