@@ -160,6 +160,38 @@ int lidar_roipoint_pool3d_forward(int batch, int pts_num, int boxes_num, int fea
                                   const float *xyz, const float *boxes3d, const float *pts_feature,
                                   float *pooled_features, int *pooled_empty_flag, void *stream);
 
+/* ------------------------------------------------------------------ sparse 3D convolution (spconv v1.x semantics)
+ * Replaces the external, un-vendored `spconv` package (docs/INSTALL.md:9,28-29; call sites
+ * pcdet/models/backbones_3d/spconv_backbone.py:3-26,76-116, spconv_unet.py, roi_heads/partA2_head.py).
+ * indices are (N,4) i32 [b,z,y,x]; spatial shape (D,H,W); kernel offsets enumerate (kz,ky,kx) row-major.
+ * Rulebooks are neighbour tables nbr (N_out, K) i32: nbr[j][k] = input row feeding output row j through
+ * offset k, or -1 (spconv.ops.get_indice_pairs gives the same relation as per-offset pair lists). */
+size_t lidar_spconv_hash_capacity(int n);            /* slots; table memory = capacity * 12 bytes */
+int lidar_spconv_build_hash(const int *indices, int n, int D, int H, int W, void *table, size_t capacity, void *stream);
+/* SubMConv3d rulebook: outputs == inputs (same row order) */
+int lidar_spconv_subm_table(const int *indices, int n, int D, int H, int W, int kD, int kH, int kW, const void *table,
+                            size_t capacity, int *nbr, void *stream);
+/* SparseConv3d rulebook in two phases (the caller reads *num_out in between to size nbr):
+ *   phase 1 -> out_indices (out_cap >= n*prod ceil(k/s) rows, 4), *num_out; output rows in first-touch order
+ *   phase 2 -> nbr (num_out, K) and nbr_t (n, K) = transposed table (inverse conv / input gradient) */
+size_t lidar_spconv_conv_table_workspace_bytes(int n, int kD, int kH, int kW, int sD, int sH, int sW);
+int lidar_spconv_conv_outputs(const int *indices, int n, int batch, int D, int H, int W, int kD, int kH, int kW, int sD,
+                              int sH, int sW, int pD, int pH, int pW, int *out_indices, int out_cap, int *num_out,
+                              void *ws, size_t ws_bytes, void *stream);
+int lidar_spconv_conv_tables(int n, int kD, int kH, int kW, int sD, int sH, int sW, int num_out, int *nbr, int *nbr_t,
+                             void *ws, size_t ws_bytes, void *stream);
+/* indice_conv forward (and input gradient with the transposed table + transposed weights):
+ * out (n_out, Cout) = sum_k in[nbr[., k]] @ weight[k] (+ bias); weight (K, Cin, Cout); fp32 MFMA; Cin, Cout <= 128 */
+int lidar_spconv_implicit_gemm(const float *in_features, const int *nbr, int n_out, int K, int Cin, int Cout,
+                               const float *weight, const float *bias, float *out_features, void *stream);
+/* weight gradient: grad_weight (K, Cin, Cout) += sum_j in[nbr[j][k]]^T (x) grad_out[j]; zero-filled by the caller */
+int lidar_spconv_wgrad(const float *in_features, const float *grad_out, const int *nbr, int n_out, int K, int Cin, int Cout,
+                       float *grad_weight, void *stream);
+/* SparseConvTensor.dense(): (N, C) rows at (N,4) indices -> (B, C, D, H, W), every element written once */
+size_t lidar_sparse_to_dense_workspace_bytes(int batch, int D, int H, int W);
+int lidar_sparse_to_dense(const float *features, const int *indices, int n, int channels, int batch, int D, int H, int W,
+                          float *out, void *ws, size_t ws_bytes, void *stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -45,6 +45,16 @@ SIGNATURES = {
     "lidar_roiaware_pool3d_backward": (i32, [i32, i32, i32, i32, i32, i32, vp, vp, vp, vp, i32, vp]),
     "lidar_points_in_boxes": (i32, [i32, i32, i32, vp, vp, vp, vp]),
     "lidar_roipoint_pool3d_forward": (i32, [i32, i32, i32, i32, i32, vp, vp, vp, vp, vp, vp]),
+    "lidar_spconv_hash_capacity": (sz, [i32]),
+    "lidar_spconv_build_hash": (i32, [vp, i32, i32, i32, i32, vp, sz, vp]),
+    "lidar_spconv_subm_table": (i32, [vp, i32, i32, i32, i32, i32, i32, i32, vp, sz, vp, vp]),
+    "lidar_spconv_conv_table_workspace_bytes": (sz, [i32, i32, i32, i32, i32, i32, i32]),
+    "lidar_spconv_conv_outputs": (i32, [vp, i32, i32, i32, i32, i32, i32, i32, i32, i32, i32, i32, i32, i32, i32, vp, i32, vp, vp, sz, vp]),
+    "lidar_spconv_conv_tables": (i32, [i32, i32, i32, i32, i32, i32, i32, i32, vp, vp, vp, sz, vp]),
+    "lidar_spconv_implicit_gemm": (i32, [vp, vp, i32, i32, i32, i32, vp, vp, vp, vp]),
+    "lidar_spconv_wgrad": (i32, [vp, vp, vp, i32, i32, i32, i32, vp, vp]),
+    "lidar_sparse_to_dense_workspace_bytes": (sz, [i32, i32, i32, i32]),
+    "lidar_sparse_to_dense": (i32, [vp, vp, i32, i32, i32, i32, i32, i32, vp, vp, sz, vp]),
 }
 
 _lib = None

@@ -175,7 +175,7 @@ __global__ void scatter_fill_kernel(int *__restrict__ map, long long n) {
 }
 
 __global__ void scatter_index_kernel(const void *__restrict__ coords, int coords_are_float, int nvox_host,
-                                     const int *__restrict__ nvox_dev, int B, int nx, int ny, int *__restrict__ map) {
+                                     const int *__restrict__ nvox_dev, int B, int nx, int ny, int hrows, int *__restrict__ map) {
     const int nv = nvox_dev ? min(*nvox_dev, nvox_host) : nvox_host;
     for (int v = blockIdx.x * blockDim.x + threadIdx.x; v < nv; v += gridDim.x * blockDim.x) {
         int b, z, y, x;
@@ -186,8 +186,9 @@ __global__ void scatter_index_kernel(const void *__restrict__ coords, int coords
             const int4 c = ((const int4 *)coords)[v];
             b = c.x; z = c.y; y = c.z; x = c.w;
         }
-        // reference index: z + y*nx + x with nz == 1 (pointpillar_scatter.py:27)
-        const long long cell = (long long)z + (long long)y * nx + x;
+        // PointPillarScatter: z + y*nx + x with nz == 1 (pointpillar_scatter.py:27) == (z*hrows + y)*nx + x with z == 0;
+        // SparseConvTensor.dense(): the (D*H, W) view of a (D, H, W) volume, hrows = H
+        const long long cell = ((long long)z * hrows + y) * nx + x;
         if (b >= 0 && b < B && cell >= 0 && cell < (long long)nx * ny) map[(size_t)b * nx * ny + cell] = v;
     }
 }
@@ -254,7 +255,7 @@ LIDAR_EXPORT int lidar_pillar_scatter(const float *pillar_features, const void *
     if (num_voxels > 0) {
         int ib = divup(num_voxels, 256);
         hipLaunchKernelGGL(scatter_index_kernel, dim3(ib), dim3(256), 0, s, coords, coords_are_float, num_voxels,
-                           num_voxels_dev, batch, nx, ny, map);
+                           num_voxels_dev, batch, nx, ny, ny, map);
     }
     const dim3 grid(divup(nx, SC_XT), ny, batch);
     if (channels == 64)
@@ -264,4 +265,32 @@ LIDAR_EXPORT int lidar_pillar_scatter(const float *pillar_features, const void *
     else
         hipLaunchKernelGGL(scatter_canvas_kernel<128>, grid, dim3(256), 0, s, pillar_features, map, nx, ny, canvas);
     return lidar_check_launch("lidar_pillar_scatter");
+}
+
+// SparseConvTensor.dense() (spconv; consumer pcdet/models/backbones_2d/map_to_bev/height_compression.py:21-23):
+// features (N, C) at indices (N, 4) [b,z,y,x] -> zeros-filled (B, C, D, H, W), written once. C in {32,64,128}.
+LIDAR_EXPORT size_t lidar_sparse_to_dense_workspace_bytes(int batch, int D, int H, int W) {
+    return align_up((size_t)batch * D * H * W * 4, 256);
+}
+
+LIDAR_EXPORT int lidar_sparse_to_dense(const float *features, const int *indices, int n, int channels, int batch, int D, int H,
+                                       int W, float *out, void *ws, size_t ws_bytes, void *stream) {
+    if (!features || !indices || !out || !ws || batch <= 0 || D <= 0 || H <= 0 || W <= 0 || n < 0) return LIDAR_ERR_ARG;
+    if (channels != 64 && channels != 32 && channels != 128) return LIDAR_ERR_ARG;
+    if (ws_bytes < lidar_sparse_to_dense_workspace_bytes(batch, D, H, W)) return LIDAR_ERR_WORKSPACE;
+    if ((long long)D * H > 65535) return LIDAR_ERR_ARG;
+    hipStream_t s = (hipStream_t)stream;
+    int *map = (int *)ws;
+    const long long cells = (long long)batch * D * H * W;
+    int fb = divup(cells, 256 * 4);
+    if (fb > 2048) fb = 2048;
+    hipLaunchKernelGGL(scatter_fill_kernel, dim3(fb), dim3(256), 0, s, map, cells);
+    if (n > 0)
+        hipLaunchKernelGGL(scatter_index_kernel, dim3(divup(n, 256)), dim3(256), 0, s, (const void *)indices, 0, n,
+                           (const int *)nullptr, batch, W, D * H, H, map);
+    const dim3 grid(divup(W, SC_XT), D * H, batch);
+    if (channels == 64) hipLaunchKernelGGL(scatter_canvas_kernel<64>, grid, dim3(256), 0, s, features, map, W, D * H, out);
+    else if (channels == 32) hipLaunchKernelGGL(scatter_canvas_kernel<32>, grid, dim3(256), 0, s, features, map, W, D * H, out);
+    else hipLaunchKernelGGL(scatter_canvas_kernel<128>, grid, dim3(256), 0, s, features, map, W, D * H, out);
+    return lidar_check_launch("lidar_sparse_to_dense");
 }

@@ -1,0 +1,495 @@
+// Sparse 3D convolution (spconv v1.x semantics) on gfx950: rulebook build + output-stationary implicit GEMM.
+// Replaces the external `spconv` package the reference imports (call sites: pcdet/models/backbones_3d/
+// spconv_backbone.py:3-26,76-116; spconv_unet.py; roi_heads/partA2_head.py).
+//
+// Rulebook representation: a NEIGHBOUR TABLE nbr (N_out, K) i32 — nbr[j][k] = input row that reaches output
+// row j through kernel offset k, or -1 — instead of spconv's per-offset (in, out) pair lists.  With it
+//     out[j] = sum_k in[nbr[j][k]] @ W[k]
+// is an output-stationary implicit GEMM: no scatter-add, no atomics, a fixed summation order (k ascending),
+// one launch per layer instead of up to 81 (gather + SGEMM + scatter per offset).  The pair-list view is
+// recovered by enumerating the valid table entries (tests check set equality with the brute-force oracle).
+//
+//   SubM   : outputs = inputs; nbr[j][k] = row of site_j + (k - centre), looked up in a coordinate hash table.
+//   Regular: o = (q + p - k) / s for every (input q, offset k) that divides evenly and lands in bounds.  Output
+//            rows are numbered in first-touch order of the (input row, offset) scan — deterministic (this is
+//            the order upstream's CPU rulebook builder produces): atomicMin picks each output site's first
+//            candidate, an exclusive scan over the candidate flags ranks them.
+//   Inverse: the transposed table of the forward conv it is paired with (same offset index, no flip).
+// GEMM: fp32 MFMA (v_mfma_f32_32x32x2_f32 == exact fp32 FMA chain), wave tile 32 rows x 32 cols, workgroup =
+// 4 waves = 128 output rows; per offset the gathered rows (32 x Cin per wave) and W[k] (Cin x Cout, shared by
+// the workgroup) are staged in LDS; offsets with no neighbour in a wave's tile are skipped.
+#include "common.h"
+
+#define SC_EMPTY 0xFFFFFFFFFFFFFFFFull
+
+struct ScGeom {
+    int B, D, H, W;          // input spatial shape
+    int oD, oH, oW;          // output spatial shape
+    int kD, kH, kW, K;
+    int sD, sH, sW, pD, pH, pW;
+};
+
+__device__ __forceinline__ unsigned long long sc_key(int b, int z, int y, int x, int D, int H, int W) {
+    return (((unsigned long long)b * D + z) * H + y) * W + x;
+}
+
+__device__ __forceinline__ unsigned sc_hash(unsigned long long key, unsigned mask) {
+    key ^= key >> 33;
+    key *= 0xff51afd7ed558ccdull;
+    key ^= key >> 33;
+    return (unsigned)key & mask;
+}
+
+// insert keys of `indices` (N,4) [b,z,y,x] -> table (keys, vals=row).  Duplicate coordinates keep the lowest row.
+__global__ void sc_hash_build_kernel(const int *__restrict__ indices, int N, int D, int H, int W,
+                                     unsigned long long *__restrict__ keys, int *__restrict__ vals, unsigned mask) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= N) return;
+    const int4 c = reinterpret_cast<const int4 *>(indices)[i];
+    const unsigned long long key = sc_key(c.x, c.y, c.z, c.w, D, H, W);
+    unsigned h = sc_hash(key, mask);
+    for (unsigned probe = 0; probe <= mask; ++probe) {
+        const unsigned long long old = atomicCAS(&keys[h], SC_EMPTY, key);
+        if (old == SC_EMPTY || old == key) {
+            atomicMin(&vals[h], i);
+            return;
+        }
+        h = (h + 1) & mask;
+    }
+}
+
+__device__ __forceinline__ int sc_lookup(const unsigned long long *__restrict__ keys, const int *__restrict__ vals,
+                                         unsigned mask, unsigned long long key) {
+    unsigned h = sc_hash(key, mask);
+    for (unsigned probe = 0; probe <= mask; ++probe) {
+        const unsigned long long k = keys[h];
+        if (k == key) return vals[h];
+        if (k == SC_EMPTY) return -1;
+        h = (h + 1) & mask;
+    }
+    return -1;
+}
+
+__global__ void sc_fill_kernel(unsigned long long *__restrict__ keys, int *__restrict__ vals, long long n, int valfill) {
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x) {
+        keys[i] = SC_EMPTY;
+        vals[i] = valfill;
+    }
+}
+
+__global__ void sc_fill_i32_kernel(int *__restrict__ p, long long n, int v) {
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x) p[i] = v;
+}
+
+// ------------------------------------------------------------------ SubM table
+__global__ void sc_subm_table_kernel(const int *__restrict__ indices, int N, ScGeom g, const unsigned long long *__restrict__ keys,
+                                     const int *__restrict__ vals, unsigned mask, int *__restrict__ nbr) {
+    const long long e = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (e >= (long long)N * g.K) return;
+    const int j = (int)(e / g.K), k = (int)(e - (long long)j * g.K);
+    const int kz = k / (g.kH * g.kW), ky = (k / g.kW) % g.kH, kx = k % g.kW;
+    const int4 c = reinterpret_cast<const int4 *>(indices)[j];
+    const int z = c.y + kz - g.kD / 2, y = c.z + ky - g.kH / 2, x = c.w + kx - g.kW / 2;
+    int r = -1;
+    if (z >= 0 && z < g.D && y >= 0 && y < g.H && x >= 0 && x < g.W) r = sc_lookup(keys, vals, mask, sc_key(c.x, z, y, x, g.D, g.H, g.W));
+    nbr[e] = r;
+}
+
+// ------------------------------------------------------------------ regular conv: candidates -> unique outputs
+// candidate c = in_row * K + k.  cand_slot[c] = slot of its output site in the output hash (or -1);
+// owner[slot] = smallest candidate that produced the site.
+__global__ void sc_candidates_kernel(const int *__restrict__ indices, int N, ScGeom g, unsigned long long *__restrict__ okeys,
+                                     int *__restrict__ owner, unsigned omask, int *__restrict__ cand_slot) {
+    const long long e = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (e >= (long long)N * g.K) return;
+    const int i = (int)(e / g.K), k = (int)(e - (long long)i * g.K);
+    const int kz = k / (g.kH * g.kW), ky = (k / g.kW) % g.kH, kx = k % g.kW;
+    const int4 c = reinterpret_cast<const int4 *>(indices)[i];
+    const int tz = c.y + g.pD - kz, ty = c.z + g.pH - ky, tx = c.w + g.pW - kx;
+    int slot = -1;
+    if (tz >= 0 && ty >= 0 && tx >= 0 && tz % g.sD == 0 && ty % g.sH == 0 && tx % g.sW == 0) {
+        const int oz = tz / g.sD, oy = ty / g.sH, ox = tx / g.sW;
+        if (oz < g.oD && oy < g.oH && ox < g.oW) {
+            const unsigned long long key = sc_key(c.x, oz, oy, ox, g.oD, g.oH, g.oW);
+            unsigned h = sc_hash(key, omask);
+            for (unsigned probe = 0; probe <= omask; ++probe) {
+                const unsigned long long old = atomicCAS(&okeys[h], SC_EMPTY, key);
+                if (old == SC_EMPTY || old == key) {
+                    slot = (int)h;
+                    break;
+                }
+                h = (h + 1) & omask;
+            }
+            if (slot >= 0) atomicMin(&owner[slot], (int)e);
+        }
+    }
+    cand_slot[e] = slot;
+}
+
+// three-kernel exclusive scan over candidate flags (flag = candidate owns its output site)
+#define SCAN_TPB 1024
+__global__ __launch_bounds__(SCAN_TPB) void sc_scan_blocks_kernel(const int *__restrict__ cand_slot, const int *__restrict__ owner,
+                                                                  long long n, int *__restrict__ block_sums) {
+    __shared__ int s_w[16];
+    const long long e = (long long)blockIdx.x * SCAN_TPB + threadIdx.x;
+    int f = 0;
+    if (e < n) {
+        const int s = cand_slot[e];
+        f = (s >= 0 && owner[s] == (int)e) ? 1 : 0;
+    }
+    const int c = __popcll(__ballot(f));
+    if ((threadIdx.x & 63) == 0) s_w[threadIdx.x >> 6] = c;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        int a = 0;
+        for (int k = 0; k < 16; ++k) a += s_w[k];
+        block_sums[blockIdx.x] = a;
+    }
+}
+
+__global__ __launch_bounds__(1024) void sc_scan_sums_kernel(int *__restrict__ block_sums, int nblocks, int *__restrict__ total) {
+    // single block: sequential chunks of 1024 with a carried prefix
+    __shared__ int s_w[16];
+    __shared__ int s_carry;
+    if (threadIdx.x == 0) s_carry = 0;
+    __syncthreads();
+    for (int base = 0; base < nblocks; base += 1024) {
+        const int i = base + threadIdx.x;
+        const int v = i < nblocks ? block_sums[i] : 0;
+        const int inc = wave_incl_scan(v);
+        if ((threadIdx.x & 63) == 63) s_w[threadIdx.x >> 6] = inc;
+        __syncthreads();
+        int woff = 0;
+        for (int k = 0; k < (int)(threadIdx.x >> 6); ++k) woff += s_w[k];
+        const int carry = s_carry;
+        if (i < nblocks) block_sums[i] = carry + woff + inc - v;
+        __syncthreads();
+        if (threadIdx.x == 1023) s_carry = carry + woff + inc;
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) *total = s_carry;
+}
+
+// rank the owners, emit output coordinates and out_row[slot]
+__global__ __launch_bounds__(SCAN_TPB) void sc_assign_outputs_kernel(const int *__restrict__ cand_slot, const int *__restrict__ owner,
+                                                                     long long n, const int *__restrict__ block_sums,
+                                                                     const unsigned long long *__restrict__ okeys, ScGeom g,
+                                                                     int *__restrict__ out_row, int *__restrict__ out_indices) {
+    __shared__ int s_w[16];
+    const long long e = (long long)blockIdx.x * SCAN_TPB + threadIdx.x;
+    int f = 0, s = -1;
+    if (e < n) {
+        s = cand_slot[e];
+        f = (s >= 0 && owner[s] == (int)e) ? 1 : 0;
+    }
+    const unsigned long long bal = __ballot(f);
+    if ((threadIdx.x & 63) == 0) s_w[threadIdx.x >> 6] = __popcll(bal);
+    __syncthreads();
+    if (f) {
+        int r = block_sums[blockIdx.x] + __popcll(bal & lanemask_lt());
+        for (int k = 0; k < (int)(threadIdx.x >> 6); ++k) r += s_w[k];
+        out_row[s] = r;
+        unsigned long long key = okeys[s];
+        const int x = (int)(key % g.oW); key /= g.oW;
+        const int y = (int)(key % g.oH); key /= g.oH;
+        const int z = (int)(key % g.oD); key /= g.oD;
+        reinterpret_cast<int4 *>(out_indices)[r] = make_int4((int)key, z, y, x);
+    }
+}
+
+// forward table nbr (N_out, K) and (optionally) the transposed table nbr_t (N_in, K): nbr_t[i][k] = output row j
+__global__ void sc_fill_tables_kernel(const int *__restrict__ cand_slot, const int *__restrict__ out_row, long long n, int K,
+                                      int *__restrict__ nbr, int *__restrict__ nbr_t) {
+    const long long e = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (e >= n) return;
+    const int s = cand_slot[e];
+    int j = -1;
+    if (s >= 0) {
+        j = out_row[s];
+        const int i = (int)(e / K), k = (int)(e - (long long)i * K);
+        nbr[(size_t)j * K + k] = i;
+    }
+    if (nbr_t) nbr_t[e] = j;
+}
+
+// ------------------------------------------------------------------ C ABI: rulebooks
+LIDAR_EXPORT size_t lidar_spconv_hash_capacity(int n) {
+    size_t c = 1024;
+    while (c < 2 * (size_t)(n > 0 ? n : 1)) c <<= 1;
+    return c;
+}
+
+// table memory = capacity * 12 bytes: [keys u64 x cap][vals i32 x cap]
+LIDAR_EXPORT int lidar_spconv_build_hash(const int *indices, int n, int D, int H, int W, void *table, size_t capacity,
+                                         void *stream) {
+    if (!table || n < 0 || (capacity & (capacity - 1)) || capacity < 2 * (size_t)(n > 0 ? n : 1)) return LIDAR_ERR_ARG;
+    hipStream_t s = (hipStream_t)stream;
+    unsigned long long *keys = (unsigned long long *)table;
+    int *vals = (int *)(keys + capacity);
+    hipLaunchKernelGGL(sc_fill_kernel, dim3(divup(capacity, 1024) > 1024 ? 1024 : divup(capacity, 1024)), dim3(1024), 0, s, keys, vals,
+                       (long long)capacity, 0x7FFFFFFF);
+    if (n > 0)
+        hipLaunchKernelGGL(sc_hash_build_kernel, dim3(divup(n, 256)), dim3(256), 0, s, indices, n, D, H, W, keys, vals,
+                           (unsigned)(capacity - 1));
+    return lidar_check_launch("lidar_spconv_build_hash");
+}
+
+// SubMConv3d rulebook: nbr (n, K) with K = kD*kH*kW (odd kernel sizes), spatial shape (D,H,W)
+LIDAR_EXPORT int lidar_spconv_subm_table(const int *indices, int n, int D, int H, int W, int kD, int kH, int kW,
+                                         const void *table, size_t capacity, int *nbr, void *stream) {
+    if (n < 0 || kD <= 0 || kH <= 0 || kW <= 0) return LIDAR_ERR_ARG;
+    if (n == 0) return LIDAR_OK;
+    if (!indices || !table || !nbr) return LIDAR_ERR_ARG;
+    ScGeom g = {};
+    g.D = D; g.H = H; g.W = W; g.kD = kD; g.kH = kH; g.kW = kW; g.K = kD * kH * kW;
+    const unsigned long long *keys = (const unsigned long long *)table;
+    const int *vals = (const int *)(keys + capacity);
+    hipLaunchKernelGGL(sc_subm_table_kernel, dim3(divup((long long)n * g.K, 256)), dim3(256), 0, (hipStream_t)stream, indices, n, g,
+                       keys, vals, (unsigned)(capacity - 1), nbr);
+    return lidar_check_launch("lidar_spconv_subm_table");
+}
+
+// distinct outputs <= n * prod ceil(k/s): the output hash is sized for that, not for the n*K candidates
+static long long sc_out_bound(int n, int kD, int kH, int kW, int sD, int sH, int sW) {
+    const long long b = (long long)(n > 0 ? n : 1) * divup(kD, sD) * divup(kH, sH) * divup(kW, sW);
+    const long long nc = (long long)(n > 0 ? n : 1) * kD * kH * kW;
+    return b < nc ? b : nc;
+}
+
+static size_t sc_conv_ws_layout(int n, int K, long long bound, size_t *cap_out) {
+    const size_t nc = (size_t)(n > 0 ? n : 1) * K;
+    const size_t cap = lidar_spconv_hash_capacity((int)(bound > 0x3FFFFFFF ? 0x3FFFFFFF : bound));
+    if (cap_out) *cap_out = cap;
+    return align_up(cap * 8, 256) + align_up(cap * 4, 256) * 2 + align_up(nc * 4, 256) + align_up((nc / SCAN_TPB + 2) * 4, 256) + 256;
+}
+
+LIDAR_EXPORT size_t lidar_spconv_conv_table_workspace_bytes(int n, int kD, int kH, int kW, int sD, int sH, int sW) {
+    if (kD <= 0 || kH <= 0 || kW <= 0 || sD <= 0 || sH <= 0 || sW <= 0) return 0;
+    return sc_conv_ws_layout(n, kD * kH * kW, sc_out_bound(n, kD, kH, kW, sD, sH, sW), nullptr);
+}
+
+// SparseConv3d rulebook, phase 1: unique output sites.  out_indices (out_cap, 4) receives the coordinates of the
+// output rows (first-touch order), *num_out (device int) their number.  The caller reads num_out (one host sync),
+// allocates nbr (num_out, K) and calls phase 2 with the same workspace.
+LIDAR_EXPORT int lidar_spconv_conv_outputs(const int *indices, int n, int batch, int D, int H, int W, int kD, int kH, int kW,
+                                           int sD, int sH, int sW, int pD, int pH, int pW, int *out_indices, int out_cap,
+                                           int *num_out, void *ws, size_t ws_bytes, void *stream) {
+    if (n < 0 || batch <= 0 || kD <= 0 || kH <= 0 || kW <= 0 || sD <= 0 || sH <= 0 || sW <= 0) return LIDAR_ERR_ARG;
+    if (!num_out) return LIDAR_ERR_ARG;
+    hipStream_t s = (hipStream_t)stream;
+    if (n == 0) return hipMemsetAsync(num_out, 0, 4, s) == hipSuccess ? LIDAR_OK : LIDAR_ERR_LAUNCH;
+    if (!indices || !out_indices || !ws) return LIDAR_ERR_ARG;
+    ScGeom g = {};
+    g.B = batch; g.D = D; g.H = H; g.W = W; g.kD = kD; g.kH = kH; g.kW = kW; g.K = kD * kH * kW;
+    g.sD = sD; g.sH = sH; g.sW = sW; g.pD = pD; g.pH = pH; g.pW = pW;
+    g.oD = (D + 2 * pD - kD) / sD + 1; g.oH = (H + 2 * pH - kH) / sH + 1; g.oW = (W + 2 * pW - kW) / sW + 1;
+    if (g.oD <= 0 || g.oH <= 0 || g.oW <= 0) return LIDAR_ERR_ARG;
+    const long long nc = (long long)n * g.K;
+    if (nc > 0x3FFFFFFF) return LIDAR_ERR_ARG;
+    // an input site reaches at most prod ceil(k/s) outputs
+    const long long bound = sc_out_bound(n, kD, kH, kW, sD, sH, sW);
+    if (out_cap < bound) return LIDAR_ERR_ARG;
+    size_t cap;
+    if (ws_bytes < sc_conv_ws_layout(n, g.K, bound, &cap)) return LIDAR_ERR_WORKSPACE;
+    char *p = (char *)ws;
+    unsigned long long *okeys = (unsigned long long *)p; p += align_up(cap * 8, 256);
+    int *owner = (int *)p; p += align_up(cap * 4, 256);
+    int *out_row = (int *)p; p += align_up(cap * 4, 256);
+    int *cand_slot = (int *)p; p += align_up((size_t)nc * 4, 256);
+    int *block_sums = (int *)p;
+    const int nblocks = divup(nc, SCAN_TPB);
+    hipLaunchKernelGGL(sc_fill_kernel, dim3(divup(cap, 1024) > 1024 ? 1024 : divup(cap, 1024)), dim3(1024), 0, s, okeys, owner,
+                       (long long)cap, 0x7FFFFFFF);
+    hipLaunchKernelGGL(sc_candidates_kernel, dim3(divup(nc, 256)), dim3(256), 0, s, indices, n, g, okeys, owner, (unsigned)(cap - 1),
+                       cand_slot);
+    hipLaunchKernelGGL(sc_scan_blocks_kernel, dim3(nblocks), dim3(SCAN_TPB), 0, s, cand_slot, owner, nc, block_sums);
+    hipLaunchKernelGGL(sc_scan_sums_kernel, dim3(1), dim3(1024), 0, s, block_sums, nblocks, num_out);
+    hipLaunchKernelGGL(sc_assign_outputs_kernel, dim3(nblocks), dim3(SCAN_TPB), 0, s, cand_slot, owner, nc, block_sums, okeys, g,
+                       out_row, out_indices);
+    return lidar_check_launch("lidar_spconv_conv_outputs");
+}
+
+// phase 2: nbr (num_out, K) forward table (filled with -1 here first) and nbr_t (n, K) transposed table
+// (nbr_t[i][k] = output row reached from input i through offset k, or -1) — used by the inverse conv and dgrad.
+LIDAR_EXPORT int lidar_spconv_conv_tables(int n, int kD, int kH, int kW, int sD, int sH, int sW, int num_out, int *nbr,
+                                          int *nbr_t, void *ws, size_t ws_bytes, void *stream) {
+    if (n < 0 || kD <= 0 || kH <= 0 || kW <= 0 || sD <= 0 || sH <= 0 || sW <= 0 || num_out < 0) return LIDAR_ERR_ARG;
+    if (n == 0) return LIDAR_OK;
+    if (!nbr || !ws) return LIDAR_ERR_ARG;
+    const int K = kD * kH * kW;
+    size_t cap;
+    if (ws_bytes < sc_conv_ws_layout(n, K, sc_out_bound(n, kD, kH, kW, sD, sH, sW), &cap)) return LIDAR_ERR_WORKSPACE;
+    hipStream_t s = (hipStream_t)stream;
+    const long long nc = (long long)n * K;
+    char *p = (char *)ws;
+    p += align_up(cap * 8, 256);
+    p += align_up(cap * 4, 256);
+    int *out_row = (int *)p; p += align_up(cap * 4, 256);
+    int *cand_slot = (int *)p;
+    const long long nt = (long long)num_out * K;
+    if (nt > 0)
+        hipLaunchKernelGGL(sc_fill_i32_kernel, dim3(divup(nt, 1024) > 2048 ? 2048 : divup(nt, 1024)), dim3(1024), 0, s, nbr, nt, -1);
+    hipLaunchKernelGGL(sc_fill_tables_kernel, dim3(divup(nc, 256)), dim3(256), 0, s, cand_slot, out_row, nc, K, nbr, nbr_t);
+    return lidar_check_launch("lidar_spconv_conv_tables");
+}
+
+// ------------------------------------------------------------------ implicit GEMM (fp32 MFMA 32x32x2)
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+#define IG_ROWS 128          // rows per workgroup (4 waves x 32)
+#define IG_MAX_C 128
+
+// out (n_out, Cout) = sum_k in[nbr[., k]] @ W[k] (+ bias).  W is (K, Cin, Cout) row-major (spconv's
+// (kD,kH,kW,Cin,Cout) parameter viewed flat).  NT = number of 32-column tiles (Cout <= 32*NT).
+template <int NT>
+__global__ __launch_bounds__(256) void sc_implicit_gemm_kernel(const float *__restrict__ in, const int *__restrict__ nbr, int n_out, int K,
+                                                               int Cin, int Cout, const float *__restrict__ Wt,
+                                                               const float *__restrict__ bias, float *__restrict__ out) {
+    extern __shared__ float s_mem[];
+    const int Cp = Cin + 1;                       // padded row stride of the gathered tiles
+    float *s_w = s_mem;                           // [Cin][NT*32]
+    float *s_a = s_mem + (size_t)Cin * NT * 32;   // [4 waves][32][Cp]
+    const int t = threadIdx.x, l = t & 63, wv = t >> 6;
+    const int row0 = blockIdx.x * IG_ROWS + wv * 32;
+    float *A = s_a + (size_t)wv * 32 * Cp;
+    f32x16 acc[NT];
+#pragma unroll
+    for (int q = 0; q < NT; ++q)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[q][r] = 0.f;
+    const int ar = l & 31, ak = l >> 5;           // MFMA operand coordinates of this lane
+    const int CW = NT * 32;
+    for (int k = 0; k < K; ++k) {
+        __syncthreads();                          // previous offset's LDS reads are done
+        // W[k] -> LDS (zero padded to NT*32 columns)
+        for (int e = t; e < Cin * CW; e += 256) {
+            const int ci = e / CW, co = e - ci * CW;
+            s_w[e] = co < Cout ? Wt[((size_t)k * Cin + ci) * Cout + co] : 0.f;
+        }
+        // this wave's 32 gathered rows -> LDS
+        const int myrow = row0 + (l & 31);
+        const int src = (myrow < n_out) ? nbr[(size_t)myrow * K + k] : -1;
+        const bool any = __ballot(src >= 0) != 0ull;
+        if (any) {
+            // lanes 0..31 know the 32 source rows; every (row, channel) element is copied by lane (e % 64)
+            for (int e = l; e < 32 * Cin; e += 64) {
+                const int r = e / Cin, c = e - r * Cin;
+                const int sr = __shfl(src, r, 64);
+                A[r * Cp + c] = sr >= 0 ? in[(size_t)sr * Cin + c] : 0.f;
+            }
+        }
+        __syncthreads();
+        if (any) {
+            for (int c0 = 0; c0 < Cin; c0 += 2) {
+                const float a = (c0 + ak < Cin) ? A[ar * Cp + c0 + ak] : 0.f;
+#pragma unroll
+                for (int q = 0; q < NT; ++q) {
+                    const float b = (c0 + ak < Cin) ? s_w[(c0 + ak) * CW + q * 32 + ar] : 0.f;
+                    acc[q] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, acc[q], 0, 0, 0);
+                }
+            }
+        }
+    }
+    // C/D layout of 32x32 MFMA: col = lane & 31, row = (reg & 3) + 8 * (reg >> 2) + 4 * (lane >> 5)
+#pragma unroll
+    for (int q = 0; q < NT; ++q) {
+        const int col = q * 32 + (l & 31);
+        if (col < Cout) {
+            const float bv = bias ? bias[col] : 0.f;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int row = row0 + (r & 3) + 8 * (r >> 2) + 4 * (l >> 5);
+                if (row < n_out) out[(size_t)row * Cout + col] = acc[q][r] + bv;
+            }
+        }
+    }
+}
+
+// indice_conv forward / dgrad (with the transposed table and W^T) — spconv.functional indice_conv (Appendix A.3)
+LIDAR_EXPORT int lidar_spconv_implicit_gemm(const float *in_features, const int *nbr, int n_out, int K, int Cin, int Cout,
+                                            const float *weight, const float *bias, float *out_features, void *stream) {
+    if (n_out < 0 || K <= 0 || Cin <= 0 || Cout <= 0 || Cin > IG_MAX_C || Cout > IG_MAX_C) return LIDAR_ERR_ARG;
+    if (n_out == 0) return LIDAR_OK;
+    if (!in_features || !nbr || !weight || !out_features) return LIDAR_ERR_ARG;
+    hipStream_t s = (hipStream_t)stream;
+    const int nt = divup(Cout, 32);
+    const size_t lds = ((size_t)Cin * nt * 32 + (size_t)4 * 32 * (Cin + 1)) * sizeof(float);
+    const dim3 grid(divup(n_out, IG_ROWS));
+#define IG_CASE(NT) hipLaunchKernelGGL(sc_implicit_gemm_kernel<NT>, grid, dim3(256), lds, s, in_features, nbr, n_out, K, Cin, Cout, weight, bias, out_features)
+    switch (nt) {
+        case 1: IG_CASE(1); break;
+        case 2: IG_CASE(2); break;
+        case 3: IG_CASE(3); break;
+        default: IG_CASE(4); break;
+    }
+#undef IG_CASE
+    return lidar_check_launch("lidar_spconv_implicit_gemm");
+}
+
+// ------------------------------------------------------------------ weight gradient
+// dW[k] (Cin, Cout) = sum_j in[nbr[j][k]]^T (x) dout[j].  grid = (row chunks, K); each workgroup reduces its
+// chunk in registers (thread = one (ci, 4-wide co strip) cell set) and adds it to dW with float atomics.
+#define WG_CHUNK 512
+template <int PER>
+__global__ __launch_bounds__(256) void sc_wgrad_kernel(const float *__restrict__ in, const float *__restrict__ dout,
+                                                       const int *__restrict__ nbr, int n_out, int K, int Cin, int Cout,
+                                                       float *__restrict__ dW) {
+    extern __shared__ float s_mem[];
+    float *s_in = s_mem;                    // [16][Cin]
+    float *s_do = s_mem + 16 * Cin;         // [16][Cout]
+    __shared__ int s_src[16];
+    const int k = blockIdx.y, t = threadIdx.x;
+    const int row_begin = blockIdx.x * WG_CHUNK, row_end = min(row_begin + WG_CHUNK, n_out);
+    const int cells = Cin * Cout;
+    float acc[PER];                         // PER * 256 >= Cin * Cout
+#pragma unroll
+    for (int q = 0; q < PER; ++q) acc[q] = 0.f;
+    for (int r0 = row_begin; r0 < row_end; r0 += 16) {
+        __syncthreads();
+        if (t < 16) s_src[t] = (r0 + t < row_end) ? nbr[(size_t)(r0 + t) * K + k] : -1;
+        __syncthreads();
+        for (int e = t; e < 16 * Cin; e += 256) {
+            const int r = e / Cin, c = e - r * Cin;
+            s_in[e] = s_src[r] >= 0 ? in[(size_t)s_src[r] * Cin + c] : 0.f;
+        }
+        for (int e = t; e < 16 * Cout; e += 256) {
+            const int r = e / Cout, c = e - r * Cout;
+            s_do[e] = (s_src[r] >= 0) ? dout[(size_t)(r0 + r) * Cout + c] : 0.f;
+        }
+        __syncthreads();
+#pragma unroll
+        for (int q = 0; q < PER; ++q) {
+            const int cell = q * 256 + t;
+            if (cell < cells) {
+                const int ci = cell / Cout, co = cell - ci * Cout;
+                float a = acc[q];
+#pragma unroll
+                for (int r = 0; r < 16; ++r) a = fmaf(s_in[r * Cin + ci], s_do[r * Cout + co], a);
+                acc[q] = a;
+            }
+        }
+    }
+#pragma unroll
+    for (int q = 0; q < PER; ++q) {
+        const int cell = q * 256 + t;
+        if (cell < cells && acc[q] != 0.f) atomicAdd(&dW[(size_t)k * cells + cell], acc[q]);
+    }
+}
+
+// dW (K, Cin, Cout) must be zero-filled by the caller
+LIDAR_EXPORT int lidar_spconv_wgrad(const float *in_features, const float *grad_out, const int *nbr, int n_out, int K, int Cin,
+                                    int Cout, float *grad_weight, void *stream) {
+    if (n_out < 0 || K <= 0 || Cin <= 0 || Cout <= 0 || Cin > IG_MAX_C || Cout > IG_MAX_C) return LIDAR_ERR_ARG;
+    if (n_out == 0) return LIDAR_OK;
+    if (!in_features || !grad_out || !nbr || !grad_weight) return LIDAR_ERR_ARG;
+    const size_t lds = (size_t)16 * (Cin + Cout) * sizeof(float);
+    const dim3 grid(divup(n_out, WG_CHUNK), K);
+    const int per = divup(Cin * Cout, 256);
+#define WG_CASE(P) hipLaunchKernelGGL(sc_wgrad_kernel<P>, grid, dim3(256), lds, (hipStream_t)stream, in_features, grad_out, nbr, n_out, K, Cin, Cout, grad_weight)
+    if (per <= 1) WG_CASE(1);
+    else if (per <= 4) WG_CASE(4);
+    else if (per <= 16) WG_CASE(16);
+    else if (per <= 32) WG_CASE(32);
+    else WG_CASE(64);
+#undef WG_CASE
+    return lidar_check_launch("lidar_spconv_wgrad");
+}

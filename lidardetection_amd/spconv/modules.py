@@ -1,0 +1,65 @@
+"""SparseModule / SparseSequential (spconv/modules.py upstream; used at spconv_backbone.py:20,29,76-116)."""
+from collections import OrderedDict
+
+import torch
+from torch import nn
+
+from .tensor import SparseConvTensor
+
+
+class SparseModule(nn.Module):
+    """Marker base class: modules that consume and produce a SparseConvTensor."""
+    pass
+
+
+def is_spconv_module(module):
+    return isinstance(module, SparseModule)
+
+
+class SparseSequential(SparseModule):
+    """Sequential container mixing sparse modules with dense ones (BatchNorm1d, ReLU, ...) that act on `.features`."""
+
+    def __init__(self, *args, **kwargs):
+        super().__init__()
+        if len(args) == 1 and isinstance(args[0], OrderedDict):
+            for key, module in args[0].items():
+                self.add_module(key, module)
+        else:
+            for idx, module in enumerate(args):
+                self.add_module(str(idx), module)
+        for name, module in kwargs.items():
+            if name in self._modules:
+                raise ValueError("name exists.")
+            self.add_module(name, module)
+
+    def __getitem__(self, idx):
+        if not (-len(self) <= idx < len(self)):
+            raise IndexError('index {} is out of range'.format(idx))
+        if idx < 0:
+            idx += len(self)
+        it = iter(self._modules.values())
+        for _ in range(idx):
+            next(it)
+        return next(it)
+
+    def __len__(self):
+        return len(self._modules)
+
+    def add(self, module, name=None):
+        if name is None:
+            name = str(len(self._modules))
+            if name in self._modules:
+                raise KeyError("name exists")
+        self.add_module(name, module)
+
+    def forward(self, input):
+        for module in self._modules.values():
+            if is_spconv_module(module):
+                assert isinstance(input, SparseConvTensor)
+                input = module(input)
+            elif isinstance(input, SparseConvTensor):
+                if input.indices.shape[0] != 0:        # BatchNorm1d cannot take an empty batch
+                    input.features = module(input.features)
+            else:
+                input = module(input)
+        return input

@@ -1,0 +1,117 @@
+"""Rulebook construction and the sparse-conv autograd function (host side of csrc/sparse_conv.hip).
+
+upstream equivalents: spconv.ops.get_indice_pairs / get_conv_output_size, spconv.functional.indice_conv /
+indice_subm_conv / indice_inverse_conv."""
+import torch
+from torch.autograd import Function
+
+from .. import _lib, workspace
+
+
+def get_conv_output_size(input_size, kernel_size, stride, padding, dilation=None):
+    return [(i + 2 * p - k) // s + 1 for i, k, s, p in zip(input_size, kernel_size, stride, padding)]
+
+
+def _hash_table(indices, spatial_shape):
+    L = _lib.lib()
+    n = indices.shape[0]
+    cap = L.lidar_spconv_hash_capacity(n)
+    table = torch.empty(cap * 12, dtype=torch.uint8, device=indices.device)
+    D, H, W = spatial_shape
+    _lib.check(L.lidar_spconv_build_hash(_lib.ptr(indices), n, D, H, W, _lib.ptr(table), cap, _lib.stream()), "lidar_spconv_build_hash")
+    return table, cap
+
+
+def subm_rulebook(indices, spatial_shape, ksize):
+    """-> nbr (N, K) int32.  outputs == inputs."""
+    _lib.require_cuda(indices)
+    n = indices.shape[0]
+    K = ksize[0] * ksize[1] * ksize[2]
+    nbr = torch.empty((n, K), dtype=torch.int32, device=indices.device)
+    if n == 0:
+        return nbr
+    table, cap = _hash_table(indices, spatial_shape)
+    D, H, W = spatial_shape
+    _lib.check(_lib.lib().lidar_spconv_subm_table(_lib.ptr(indices), n, D, H, W, ksize[0], ksize[1], ksize[2], _lib.ptr(table), cap,
+                                                  _lib.ptr(nbr), _lib.stream()), "lidar_spconv_subm_table")
+    return nbr
+
+
+def conv_rulebook(indices, batch_size, spatial_shape, ksize, stride, padding):
+    """-> out_indices (N_out, 4) int32, nbr (N_out, K), nbr_t (N_in, K).  One host sync (N_out)."""
+    _lib.require_cuda(indices)
+    L = _lib.lib()
+    n = indices.shape[0]
+    K = ksize[0] * ksize[1] * ksize[2]
+    dev = indices.device
+    if n == 0:
+        return (torch.empty((0, 4), dtype=torch.int32, device=dev), torch.empty((0, K), dtype=torch.int32, device=dev),
+                torch.empty((0, K), dtype=torch.int32, device=dev))
+    bound = n
+    for k, s in zip(ksize, stride):
+        bound *= -(-k // s)
+    bound = min(bound, n * K)
+    wsb = L.lidar_spconv_conv_table_workspace_bytes(n, *ksize, *stride)
+    ws = workspace.get("spconv_rulebook", wsb, dev)
+    out_idx = torch.empty((bound, 4), dtype=torch.int32, device=dev)
+    num = torch.empty((1,), dtype=torch.int32, device=dev)
+    D, H, W = spatial_shape
+    _lib.check(L.lidar_spconv_conv_outputs(_lib.ptr(indices), n, batch_size, D, H, W, *ksize, *stride, *padding, _lib.ptr(out_idx), bound,
+                                           _lib.ptr(num), _lib.ptr(ws), wsb, _lib.stream()), "lidar_spconv_conv_outputs")
+    n_out = int(num.item())
+    nbr = torch.empty((n_out, K), dtype=torch.int32, device=dev)
+    nbr_t = torch.empty((n, K), dtype=torch.int32, device=dev)
+    _lib.check(L.lidar_spconv_conv_tables(n, *ksize, *stride, n_out, _lib.ptr(nbr), _lib.ptr(nbr_t), _lib.ptr(ws), wsb, _lib.stream()),
+               "lidar_spconv_conv_tables")
+    return out_idx[:n_out].clone(), nbr, nbr_t
+
+
+def _implicit_gemm(feats, nbr, weight_kcc, bias, n_out):
+    """out (n_out, Cout) = sum_k feats[nbr[:, k]] @ weight_kcc[k] (+ bias)."""
+    K, Cin, Cout = weight_kcc.shape
+    out = torch.empty((n_out, Cout), dtype=torch.float32, device=feats.device)
+    if n_out == 0:
+        return out
+    _lib.check(_lib.lib().lidar_spconv_implicit_gemm(_lib.ptr(feats), _lib.ptr(nbr), n_out, K, Cin, Cout, _lib.ptr(weight_kcc),
+                                                     _lib.ptr(bias), _lib.ptr(out), _lib.stream()), "lidar_spconv_implicit_gemm")
+    return out
+
+
+class SparseConvFunction(Function):
+    """features (N_in, Cin), weight (kD,kH,kW,Cin,Cout) [, bias] -> (N_out, Cout) through a neighbour table.
+
+    fwd_table (N_out, K) drives the forward and the weight gradient; bwd_table (N_in, K) the input gradient.
+    flip_bwd: submanifold tables are symmetric (bwd_table is fwd_table itself, read with the kernel flipped)."""
+
+    @staticmethod
+    def forward(ctx, features, weight, bias, fwd_table, bwd_table, flip_bwd):
+        feats = features.contiguous()
+        Cin, Cout = weight.shape[-2], weight.shape[-1]
+        w = weight.reshape(-1, Cin, Cout).contiguous()
+        _lib.require_cuda(feats, w, fwd_table)
+        out = _implicit_gemm(feats, fwd_table, w, bias.contiguous() if bias is not None else None, fwd_table.shape[0])
+        ctx.save_for_backward(feats, w, fwd_table, bwd_table)
+        ctx.flip_bwd, ctx.has_bias, ctx.wshape = flip_bwd, bias is not None, weight.shape
+        return out
+
+    @staticmethod
+    def backward(ctx, grad_out):
+        feats, w, fwd_table, bwd_table = ctx.saved_tensors
+        g = grad_out.contiguous()
+        K, Cin, Cout = w.shape
+        grad_feats = grad_w = grad_b = None
+        if ctx.needs_input_grad[0]:
+            wt = w.flip(0) if ctx.flip_bwd else w
+            grad_feats = _implicit_gemm(g, bwd_table, wt.transpose(1, 2).contiguous(), None, feats.shape[0])
+        if ctx.needs_input_grad[1]:
+            grad_w = torch.zeros_like(w)
+            if fwd_table.shape[0] > 0:
+                _lib.check(_lib.lib().lidar_spconv_wgrad(_lib.ptr(feats), _lib.ptr(g), _lib.ptr(fwd_table), fwd_table.shape[0], K, Cin,
+                                                         Cout, _lib.ptr(grad_w), _lib.stream()), "lidar_spconv_wgrad")
+            grad_w = grad_w.view(ctx.wshape)
+        if ctx.has_bias and ctx.needs_input_grad[2]:
+            grad_b = g.sum(0)
+        return grad_feats, grad_w, grad_b, None, None, None
+
+
+indice_conv = SparseConvFunction.apply

@@ -1,0 +1,140 @@
+"""GPU parity of the sparse-conv stack (lidardetection_amd.spconv) against oracle/spconv_oracle.py:
+rulebooks as sets of (offset, in coord, out coord) triples + active output sets (bit-exact), features against
+dense conv3d / conv_transpose3d within 1e-4 (north_star), gradients against autograd of the dense oracle."""
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+from lidardetection_amd import spconv
+from oracle import spconv_oracle as so
+
+pytestmark = pytest.mark.gpu
+
+
+def _sites(seed, batch, shape, n):
+    r = np.random.default_rng(seed)
+    cells = batch * shape[0] * shape[1] * shape[2]
+    pick = r.choice(cells, n, replace=False)
+    b, rem = np.divmod(pick, shape[0] * shape[1] * shape[2])
+    z, rem = np.divmod(rem, shape[1] * shape[2])
+    y, x = np.divmod(rem, shape[2])
+    # clustered occupancy (neighbours exist): fold coordinates towards a few blobs
+    idx = np.stack([b, z, y, x], 1).astype(np.int32)
+    return idx[r.permutation(n)]
+
+
+def _table_triples(nbr, in_idx, out_idx):
+    nbr, in_idx, out_idx = nbr.cpu().numpy(), in_idx.cpu().numpy(), out_idx.cpu().numpy()
+    j, k = np.nonzero(nbr >= 0)
+    return {(int(kk), tuple(int(v) for v in in_idx[nbr[jj, kk]]), tuple(int(v) for v in out_idx[jj])) for jj, kk in zip(j, k)}
+
+
+CASES = [
+    # (shape, ksize, stride, padding, subm, cin, cout, bias)
+    ([9, 14, 16], [3, 3, 3], [1, 1, 1], [1, 1, 1], True, 4, 16, False),
+    ([9, 14, 16], [3, 3, 3], [2, 2, 2], [1, 1, 1], False, 16, 32, False),
+    ([5, 12, 10], [3, 3, 3], [2, 2, 2], [0, 1, 1], False, 64, 64, True),
+    ([11, 8, 8], [3, 1, 1], [2, 1, 1], [0, 0, 0], False, 64, 128, False),
+    ([6, 10, 10], [3, 3, 3], [1, 1, 1], [1, 1, 1], True, 5, 16, True),      # odd Cin (NuScenes' 5 point features)
+    ([8, 9, 7], [3, 3, 3], [1, 1, 1], [0, 0, 0], True, 32, 32, False),
+]
+
+
+@pytest.mark.parametrize("case", CASES)
+def test_rulebook_and_features(dev, case):
+    shape, ks, st, pd, subm, cin, cout, bias = case
+    B = 2
+    n = int(0.35 * B * shape[0] * shape[1] * shape[2])
+    idx = _sites(hash(tuple(shape)) % 1000, B, shape, n)
+    feats = np.random.default_rng(1).standard_normal((n, cin)).astype(np.float32)
+    torch.manual_seed(0)
+    mod = (spconv.SubMConv3d if subm else spconv.SparseConv3d)(cin, cout, ks, stride=st, padding=pd, bias=bias, indice_key="k").to(dev)
+    x = spconv.SparseConvTensor(torch.from_numpy(feats).to(dev), torch.from_numpy(idx).to(dev), shape, B)
+    y = mod(x)
+    d = x.indice_dict["k"]
+    trip_o, outs_o = so.rulebook(idx, shape, ks, st, pd, subm)
+    out_idx = y.indices.cpu().numpy()
+    assert sorted(tuple(int(v) for v in r) for r in out_idx) == outs_o                 # active output set
+    assert _table_triples(d["nbr"], x.indices, y.indices) == trip_o                     # forward table == brute force
+    if not subm:   # transposed table describes the same relation
+        nt = d["nbr_t"].cpu().numpy()
+        i, k = np.nonzero(nt >= 0)
+        tt = {(int(kk), tuple(int(v) for v in idx[ii]), tuple(int(v) for v in out_idx[nt[ii, kk]])) for ii, kk in zip(i, k)}
+        assert tt == trip_o
+        assert y.spatial_shape == so.out_shape(shape, ks, st, pd)
+    ref = so.conv_features(feats, idx, B, shape, mod.weight.detach().cpu(), mod.bias.detach().cpu() if bias else None, ks, st, pd,
+                           subm, out_idx)
+    np.testing.assert_allclose(y.features.detach().cpu().double().numpy(), ref.numpy(), rtol=0, atol=1e-4)
+
+
+def test_conv_backward_matches_dense_autograd(dev):
+    shape, B, cin, cout = [7, 10, 9], 2, 16, 32
+    n = 500
+    idx = _sites(7, B, shape, n)
+    feats = np.random.default_rng(2).standard_normal((n, cin)).astype(np.float32)
+    for subm, ks, st, pd in ((True, [3, 3, 3], [1, 1, 1], [1, 1, 1]), (False, [3, 3, 3], [2, 2, 2], [1, 1, 1])):
+        torch.manual_seed(1)
+        mod = (spconv.SubMConv3d if subm else spconv.SparseConv3d)(cin, cout, ks, stride=st, padding=pd, bias=True).to(dev)
+        f = torch.from_numpy(feats).to(dev).requires_grad_(True)
+        y = mod(spconv.SparseConvTensor(f, torch.from_numpy(idx).to(dev), shape, B))
+        go = torch.randn(y.features.shape, generator=torch.Generator().manual_seed(3)).to(dev)
+        y.features.backward(go)
+        # dense autograd oracle (float64)
+        fd = torch.from_numpy(feats).double().requires_grad_(True)
+        wd = mod.weight.detach().cpu().double().requires_grad_(True)
+        bd = mod.bias.detach().cpu().double().requires_grad_(True)
+        dense = torch.zeros((B, cin, *shape), dtype=torch.float64)
+        ii = torch.from_numpy(idx).long()
+        dense = dense.index_put((ii[:, 0], slice(None), ii[:, 1], ii[:, 2], ii[:, 3]), fd) if False else None
+        dense = torch.zeros((B, *shape, cin), dtype=torch.float64).index_put((ii[:, 0], ii[:, 1], ii[:, 2], ii[:, 3]), fd).permute(0, 4, 1, 2, 3)
+        o = F.conv3d(dense, wd.permute(4, 3, 0, 1, 2), bd, stride=(1 if subm else st), padding=([1, 1, 1] if subm else pd))
+        oc = y.indices.cpu().long()
+        (o[oc[:, 0], :, oc[:, 1], oc[:, 2], oc[:, 3]] * go.cpu().double()).sum().backward()
+        np.testing.assert_allclose(f.grad.cpu().double().numpy(), fd.grad.numpy(), rtol=0, atol=1e-4)
+        np.testing.assert_allclose(mod.weight.grad.cpu().double().numpy(), wd.grad.numpy(), rtol=1e-4, atol=1e-3)
+        np.testing.assert_allclose(mod.bias.grad.cpu().double().numpy(), bd.grad.numpy(), rtol=1e-4, atol=1e-3)
+
+
+def test_inverse_conv_and_indice_key_reuse(dev):
+    shape, B, c = [9, 12, 12], 2, 16
+    n = 600
+    idx = _sites(11, B, shape, n)
+    feats = np.random.default_rng(4).standard_normal((n, c)).astype(np.float32)
+    torch.manual_seed(2)
+    down = spconv.SparseConv3d(c, 32, 3, stride=2, padding=1, bias=False, indice_key="spconv2").to(dev)
+    sub = spconv.SubMConv3d(32, 32, 3, padding=1, bias=False, indice_key="subm2").to(dev)
+    sub_b = spconv.SubMConv3d(32, 32, 3, padding=1, bias=False, indice_key="subm2").to(dev)
+    up = spconv.SparseInverseConv3d(32, c, 3, indice_key="spconv2", bias=False).to(dev)
+    x = spconv.SparseConvTensor(torch.from_numpy(feats).to(dev), torch.from_numpy(idx).to(dev), shape, B)
+    y = down(x)
+    y2 = sub_b(sub(y))
+    assert y2.indice_dict["subm2"]["nbr"].data_ptr() == y.indice_dict["subm2"]["nbr"].data_ptr()   # rulebook reused, not rebuilt
+    z = up(y2)
+    assert torch.equal(z.indices, x.indices) and z.spatial_shape == shape
+    ref = so.inverse_conv_features(y2.features.detach().cpu().numpy(), y2.indices.cpu().numpy(), B, y2.spatial_shape,
+                                   up.weight.detach().cpu(), None, [3, 3, 3], [2, 2, 2], [1, 1, 1], idx, shape)
+    np.testing.assert_allclose(z.features.detach().cpu().double().numpy(), ref.numpy(), rtol=0, atol=1e-4)
+
+
+def test_dense_and_sequential_and_empty(dev):
+    shape, B = [2, 20, 24], 2
+    idx = _sites(13, B, shape, 300)
+    f = torch.randn(300, 128, device=dev)
+    x = spconv.SparseConvTensor(f, torch.from_numpy(idx).to(dev), shape, B)
+    dn = x.dense()
+    ref = torch.zeros(B, 128, *shape)
+    ii = torch.from_numpy(idx).long()
+    ref[ii[:, 0], :, ii[:, 1], ii[:, 2], ii[:, 3]] = f.cpu()
+    assert torch.equal(dn.cpu(), ref)
+    x5 = spconv.SparseConvTensor(torch.randn(300, 5, device=dev), torch.from_numpy(idx).to(dev), shape, B)
+    assert x5.dense().shape == (B, 5, *shape)                       # odd width -> torch path
+    seq = spconv.SparseSequential(spconv.SubMConv3d(128, 16, 3, padding=1, bias=False, indice_key="a"),
+                                  torch.nn.BatchNorm1d(16, eps=1e-3, momentum=0.01), torch.nn.ReLU()).to(dev)
+    out = seq(x)
+    assert out.features.shape == (300, 16) and float(out.features.min()) >= 0
+    empty = spconv.SparseConvTensor(torch.zeros(0, 128, device=dev), torch.zeros(0, 4, dtype=torch.int32, device=dev), shape, B)
+    oe = seq(empty)
+    assert oe.features.shape[0] == 0
+    dw = spconv.SparseConv3d(128, 16, 3, stride=2, padding=1).to(dev)(empty)
+    assert dw.features.shape == (0, 16)
