@@ -1,0 +1,151 @@
+"""GPU parity of the mirrored model modules that sit on the hot path (PillarVFE, MeanVFE, PointPillarScatter,
+HeightCompression, VoxelBackBone8x / VoxelResBackBone8x, class_agnostic_nms / multi_classes_nms) — module-level API as in
+the reference (batch_dict in, batch_dict out), checked against the reference-generated golden fixtures and the oracles."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from lidardetection_amd import synth
+from lidardetection_amd.pcdet.models.backbones_2d import map_to_bev
+from lidardetection_amd.pcdet.models.backbones_3d import spconv_backbone, vfe
+from lidardetection_amd.pcdet.models.model_utils import model_nms_utils
+from lidardetection_amd.pcdet.utils.cfg import AttrDict
+from lidardetection_amd.voxelizer import BatchVoxelizer
+from oracle import c_oracle, spconv_oracle as so
+
+pytestmark = pytest.mark.gpu
+
+
+def test_pillar_modules_vs_reference_golden(dev, golden_dir):
+    g = np.load(os.path.join(golden_dir, "pp_modules.npz"))
+    cfg = AttrDict(USE_NORM=True, WITH_DISTANCE=False, USE_ABSLOTE_XYZ=True, NUM_FILTERS=[64])
+    m = vfe.PillarVFE(cfg, 4, [float(v) for v in g["voxel_size"]], [float(v) for v in g["pc_range"]]).to(dev)
+    with torch.no_grad():
+        m.pfn_layers[0].linear.weight.copy_(torch.from_numpy(g["pfn_weight"]))
+        n = m.pfn_layers[0].norm
+        n.weight.copy_(torch.from_numpy(g["bn_gamma"])); n.bias.copy_(torch.from_numpy(g["bn_beta"]))
+        n.running_mean.copy_(torch.from_numpy(g["bn_mean"])); n.running_var.copy_(torch.from_numpy(g["bn_var"]))
+    bd = {"voxels": torch.from_numpy(g["voxels"]).to(dev), "voxel_num_points": torch.from_numpy(g["num_points"]).float().to(dev),
+          "voxel_coords": torch.from_numpy(g["coords"]).float().to(dev), "batch_size": 2}
+    for mode in ("eval", "train_path"):     # fused HIP kernel, then the stock-torch path (BN kept in eval to compare)
+        m.eval()
+        if mode == "train_path":
+            bd["voxels"] = bd["voxels"].clone().requires_grad_(True)     # forces the torch path
+        out = m(dict(bd))["pillar_features"]
+        np.testing.assert_allclose(out.detach().cpu().numpy(), g["pillar_features"], rtol=0, atol=1e-4)
+    bd["voxels"] = bd["voxels"].detach()
+    bd = m(bd)
+    sc = map_to_bev.PointPillarScatter(AttrDict(NUM_BEV_FEATURES=64), grid_size=(48, 40, 1))
+    canvas = sc(bd)["spatial_features"]
+    ref = np.zeros(tuple(g["canvas_shape"]), np.float32)
+    ref[tuple(g["canvas_nz_idx"])] = g["canvas_nz_val"]
+    np.testing.assert_allclose(canvas.cpu().numpy(), ref, rtol=0, atol=1e-4)
+    mv = vfe.MeanVFE(AttrDict(), 4)({"voxels": bd["voxels"], "voxel_num_points": bd["voxel_num_points"]})["voxel_features"]
+    np.testing.assert_allclose(mv.cpu().numpy(), g["mean_features"], rtol=0, atol=1e-6)
+
+
+def _oracle_sequential(seq, feats, idx, shape, B, dicts):
+    """Replays a SparseSequential / SparseBasicBlock chain with the dense-conv oracle in float64."""
+    from lidardetection_amd import spconv
+    for mod in (seq._modules.values() if isinstance(seq, spconv.SparseSequential) else [seq]):
+        if isinstance(mod, spconv.SparseSequential):
+            feats, idx, shape = _oracle_sequential(mod, feats, idx, shape, B, dicts)
+        elif isinstance(mod, spconv_backbone.SparseBasicBlock):
+            ident = feats
+            f1, idx, shape = _oracle_sequential(mod.conv1, feats, idx, shape, B, dicts)
+            f1 = torch.relu(_bn(mod.bn1, f1))
+            f2, idx, shape = _oracle_sequential(mod.conv2, f1, idx, shape, B, dicts)
+            feats = torch.relu(_bn(mod.bn2, f2) + ident)
+        elif isinstance(mod, spconv.SparseConvolution):
+            w = mod.weight.detach().cpu()
+            b = mod.bias.detach().cpu() if mod.bias is not None else None
+            if mod.subm:
+                feats = so.conv_features(feats, idx, B, shape, w, b, mod.kernel_size, [1, 1, 1], [0, 0, 0], True, idx)
+            else:
+                _, outs = so.rulebook(idx, shape, mod.kernel_size, mod.stride, mod.padding, False)
+                outs = np.array(outs, np.int64)
+                feats = so.conv_features(feats, idx, B, shape, w, b, mod.kernel_size, mod.stride, mod.padding, False, outs)
+                idx, shape = outs, so.out_shape(shape, mod.kernel_size, mod.stride, mod.padding)
+        elif isinstance(mod, torch.nn.BatchNorm1d):
+            feats = _bn(mod, feats)
+        elif isinstance(mod, torch.nn.ReLU):
+            feats = torch.relu(feats)
+        else:
+            raise NotImplementedError(type(mod))
+    return feats, idx, shape
+
+
+def _bn(bn, x):
+    d = lambda t: t.detach().cpu().double()
+    return (x - d(bn.running_mean)) / torch.sqrt(d(bn.running_var) + bn.eps) * d(bn.weight) + d(bn.bias)
+
+
+@pytest.mark.parametrize("res", [False, True])
+def test_voxel_backbone8x_small_grid(dev, res):
+    grid = [48, 40, 24]                                   # nx, ny, nz -> sparse_shape [25, 40, 48]
+    B = 2
+    r = np.random.default_rng(5)
+    cells = 25 * 40 * 48
+    pick = np.concatenate([r.choice(cells, 2500, replace=False) + b * cells for b in range(B)])
+    b_, rem = np.divmod(pick, cells)
+    z, rem = np.divmod(rem, 40 * 48)
+    y, x = np.divmod(rem, 48)
+    idx = np.stack([b_, z, y, x], 1).astype(np.int32)
+    feats = r.standard_normal((len(idx), 4)).astype(np.float32)
+    torch.manual_seed(3)
+    cls = spconv_backbone.VoxelResBackBone8x if res else spconv_backbone.VoxelBackBone8x
+    m = cls(AttrDict(), 4, grid).to(dev).eval()
+    with torch.no_grad():
+        for mod in m.modules():
+            if isinstance(mod, torch.nn.BatchNorm1d):
+                mod.running_mean.uniform_(-0.2, 0.2); mod.running_var.uniform_(0.5, 1.5)
+                mod.weight.uniform_(0.8, 1.2); mod.bias.uniform_(-0.1, 0.1)
+        bd = m({"voxel_features": torch.from_numpy(feats).to(dev), "voxel_coords": torch.from_numpy(idx).float().to(dev), "batch_size": B})
+    out = bd["encoded_spconv_tensor"]
+    f, i, s = torch.from_numpy(feats).double(), idx.astype(np.int64), m.sparse_shape
+    for name in ("conv_input", "conv1", "conv2", "conv3", "conv4", "conv_out"):
+        f, i, s = _oracle_sequential(getattr(m, name), f, i, s, B, None)
+    assert out.spatial_shape == list(s)
+    got = {tuple(int(v) for v in c): row for c, row in zip(out.indices.cpu().numpy(), out.features.cpu().double().numpy())}
+    assert set(got) == {tuple(int(v) for v in c) for c in i}
+    ref = np.stack([got[tuple(int(v) for v in c)] for c in i])
+    scale = max(1.0, float(f.abs().max()))
+    np.testing.assert_allclose(ref, f.numpy(), rtol=0, atol=2e-4 * scale)
+    hc = map_to_bev.HeightCompression(AttrDict(NUM_BEV_FEATURES=256))(bd)["spatial_features"]
+    assert hc.shape == (B, 128 * s[0], s[1], s[2])
+    assert set(bd["multi_scale_3d_features"]) == {"x_conv1", "x_conv2", "x_conv3", "x_conv4"}
+
+
+def test_second_front_end_on_kitti_shapes(dev):
+    """SECOND-KITTI shapes end to end: HIP voxelise (P=5) -> MeanVFE -> VoxelBackBone8x -> HeightCompression."""
+    frames = [synth.cloud_ring(2000), synth.cloud_ring(2001)]
+    vz = BatchVoxelizer(synth.SEC_VOXEL, synth.SEC_RANGE, 5, 16000)
+    o = vz.voxelize_frames(frames, device=dev)
+    bd = {"voxels": o["voxels"], "voxel_num_points": o["voxel_num_points"], "voxel_coords": o["voxel_coords"], "batch_size": 2}
+    bd = vfe.MeanVFE(AttrDict(), 4)(bd)
+    m = spconv_backbone.VoxelBackBone8x(AttrDict(), 4, [1408, 1600, 40]).to(dev).eval()
+    with torch.no_grad():
+        bd = m(bd)
+        bd = map_to_bev.HeightCompression(AttrDict(NUM_BEV_FEATURES=256))(bd)
+    assert bd["spatial_features"].shape == (2, 256, 200, 176)
+    assert bd["encoded_spconv_tensor"].spatial_shape == [2, 200, 176]
+    assert torch.isfinite(bd["spatial_features"]).all()
+
+
+def test_model_nms_utils(dev):
+    boxes, scores = synth.boxes_nms(seed=3020, objects=200, copies=8)
+    cfg = AttrDict(NMS_TYPE="nms_gpu", NMS_THRESH=0.1, NMS_PRE_MAXSIZE=1024, NMS_POST_MAXSIZE=100, MULTI_CLASSES_NMS=False)
+    tb, ts = torch.from_numpy(boxes).to(dev), torch.from_numpy(scores).to(dev)
+    sel, sc = model_nms_utils.class_agnostic_nms(ts, tb, cfg, score_thresh=0.3)
+    # oracle replay of class_agnostic_nms
+    mask = scores >= 0.3
+    bs, ss = boxes[mask], scores[mask]
+    top = np.argsort(-ss, kind="stable")[:1024]
+    keep = c_oracle.nms(bs[top], ss[top], 0.1)[:100]
+    exp = np.nonzero(mask)[0][top[keep]]
+    assert sel.cpu().tolist() == exp.tolist() and np.allclose(sc.cpu().numpy(), scores[exp])
+    cls_scores = torch.stack([ts, ts.flip(0) * 0.9], 1)
+    ps, pl, pb = model_nms_utils.multi_classes_nms(cls_scores, tb, cfg, score_thresh=0.2)
+    assert ps.shape[0] == pl.shape[0] == pb.shape[0] and set(pl.cpu().tolist()) <= {0, 1} and ps.shape[0] <= 200
