@@ -24,7 +24,7 @@ import torch
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
-from lidardetection_amd import synth  # noqa: E402
+from lidardetection_amd import dist_utils, synth  # noqa: E402
 from lidardetection_amd.pointpillar import PointPillarKITTI  # noqa: E402
 
 HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
@@ -80,15 +80,9 @@ def main():
     ap.add_argument("--stages", action="store_true", help="also print per-stage GPU times (stderr)")
     args = ap.parse_args()
 
-    world = int(os.environ.get("WORLD_SIZE", "1"))
-    rank = int(os.environ.get("RANK", "0"))
-    local = int(os.environ.get("LOCAL_RANK", "0"))
-    dist = None
-    if world > 1:
-        import torch.distributed as dist
-        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group(backend="nccl")
+    rank, local, world = dist_utils.env_world()
     torch.cuda.set_device(local)
+    dist = dist_utils.init_from_env("nccl")          # RCCL on ROCm; None for a single process
     device = torch.device("cuda", local)
     torch.backends.cudnn.benchmark = True
 
@@ -97,10 +91,7 @@ def main():
     model = PointPillarKITTI(batch_size=args.batch, max_voxels=16000, n_max=n_max, device=device).randomize_for_bench(0)
 
     def barrier():
-        torch.cuda.synchronize()
-        if dist is not None:
-            dist.barrier()
-        torch.cuda.synchronize()
+        dist_utils.barrier(dist, cuda=True)
 
     with torch.no_grad():
         for _ in range(args.warmup):
@@ -117,10 +108,7 @@ def main():
             out = model.post_process(cls, box, dirs)
         barrier()
         dt = time.perf_counter() - t0
-    if dist is not None:
-        t = torch.tensor([dt], dtype=torch.float64, device=device)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        dt = float(t.item())
+    dt = dist_utils.max_over_ranks(dt, dist, device)
 
     vox_ms = float(np.mean([a.elapsed_time(b) for a, b in ev]))
     total_rows = int(vox["voxel_offsets"][-1].item())
@@ -134,7 +122,7 @@ def main():
         "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": dt / args.steps * 1e3,
         "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
         "config": {"workload": "PointPillar-KITTI bs=16 per GPU: HIP voxelize + PFN + scatter + rotated NMS, "
-                               "stock-torch fp32 2D backbone/head; cloud_uniform 20k pts/frame, 16k pillars/frame "
+                               "stock-torch fp32 2D backbone/head (channels_last); cloud_uniform 20k pts/frame, 16k pillars/frame "
                                "(max_voxels cap), NMS pre 4096 / post 500 / thr 0.01",
                    "frames_per_step": args.batch, "replicas": world},
         "roofline": {"bound": "hbm", "kernel": "lidar_voxelize (vx_hash, vx_tile_sums, vx_assign, vx_insert, vx_rows)",

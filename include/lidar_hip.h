@@ -73,11 +73,13 @@ int lidar_mean_vfe(const float *voxels, const void *num_points, int num_voxels, 
                    int num_features, int num_are_float, float *out, void *stream);
 
 /* PointPillarScatter.forward (pcdet/models/backbones_2d/map_to_bev/pointpillar_scatter.py:14-37), nz == 1:
- * canvas (batch, channels, ny, nx) f32, every element written exactly once. channels in {32,64,128}. */
+ * canvas (batch, channels, ny, nx) f32, every element written exactly once. channels in {32,64,128}.
+ * channels_last = 1 writes the same logical tensor with NHWC strides (torch.channels_last), which MIOpen's fp32
+ * convolutions consume without layout transposes. */
 size_t lidar_pillar_scatter_workspace_bytes(int batch, int nx, int ny);
 int lidar_pillar_scatter(const float *pillar_features, const void *coords, int coords_are_float, int num_voxels,
-                         const int *num_voxels_dev, int channels, int batch, int nx, int ny, float *canvas,
-                         void *ws, size_t ws_bytes, void *stream);
+                         const int *num_voxels_dev, int channels, int batch, int nx, int ny, int channels_last,
+                         float *canvas, void *ws, size_t ws_bytes, void *stream);
 
 /* ------------------------------------------------------------------ iou3d_nms
  * boxes are (N,7) f32 [x, y, z, dx, dy, dz, heading].
@@ -191,6 +193,13 @@ int lidar_spconv_wgrad(const float *in_features, const float *grad_out, const in
 size_t lidar_sparse_to_dense_workspace_bytes(int batch, int D, int H, int W);
 int lidar_sparse_to_dense(const float *features, const int *indices, int n, int channels, int batch, int D, int H, int W,
                           float *out, void *ws, size_t ws_bytes, void *stream);
+
+/* ------------------------------------------------------------------ CPU entry points (HOST pointers, no GPU touched)
+ * Called by the reference from DataLoader workers (augmentation / database creation). */
+/* boxes_iou_bev_cpu (pcdet/ops/iou3d_nms/src/iou3d_cpu.cpp:232-252): out (n_a, n_b) rotated BEV IoU */
+int lidar_boxes_iou_bev_cpu(const float *boxes_a, int n_a, const float *boxes_b, int n_b, float *out);
+/* points_in_boxes_cpu (pcdet/ops/roiaware_pool3d/src/roiaware_pool3d.cpp:143-168): out (n_boxes, n_pts) 0/1, margin 1e-2 */
+int lidar_points_in_boxes_cpu(const float *boxes, int n_boxes, const float *pts, int n_pts, int *out);
 
 #ifdef __cplusplus
 }

@@ -20,7 +20,7 @@ SIGNATURES = {
     "lidar_pillar_vfe": (i32, [vp, vp, vp, i32, vp, i32, i32, vp, vp, vp, i32, vp, vp, i32, i32, i32, vp, vp]),
     "lidar_mean_vfe": (i32, [vp, vp, i32, i32, i32, i32, vp, vp]),
     "lidar_pillar_scatter_workspace_bytes": (sz, [i32, i32, i32]),
-    "lidar_pillar_scatter": (i32, [vp, vp, i32, i32, vp, i32, i32, i32, i32, vp, vp, sz, vp]),
+    "lidar_pillar_scatter": (i32, [vp, vp, i32, i32, vp, i32, i32, i32, i32, i32, vp, vp, sz, vp]),
     "lidar_iou_workspace_bytes": (sz, [i32, i32]),
     "lidar_boxes_pairwise_bev": (i32, [vp, i32, vp, i32, i32, vp, vp, sz, vp]),
     "lidar_nms_workspace_bytes": (sz, [i32, i32]),
@@ -55,6 +55,8 @@ SIGNATURES = {
     "lidar_spconv_wgrad": (i32, [vp, vp, vp, i32, i32, i32, i32, vp, vp]),
     "lidar_sparse_to_dense_workspace_bytes": (sz, [i32, i32, i32, i32]),
     "lidar_sparse_to_dense": (i32, [vp, vp, i32, i32, i32, i32, i32, i32, vp, vp, sz, vp]),
+    "lidar_boxes_iou_bev_cpu": (i32, [vp, i32, vp, i32, vp]),
+    "lidar_points_in_boxes_cpu": (i32, [vp, i32, vp, i32, vp]),
 }
 
 _lib = None

@@ -235,13 +235,29 @@ __global__ __launch_bounds__(256) void scatter_canvas_kernel(const float *__rest
     }
 }
 
+// channels-last canvas (B, ny, nx, CH): a cell's CH channels are contiguous, so the scatter is a row copy or a zero row;
+// one float4 per thread, both sides fully coalesced.  (Logical shape (B, CH, ny, nx) with torch.channels_last strides.)
+template <int CH>
+__global__ __launch_bounds__(256) void scatter_canvas_nhwc_kernel(const float *__restrict__ feat, const int *__restrict__ map,
+                                                                  long long cells, float *__restrict__ canvas) {
+    constexpr int Q = CH / 4;
+    const long long e = (long long)blockIdx.x * 256 + threadIdx.x;
+    if (e >= cells * Q) return;
+    const long long cell = e / Q;
+    const int q = (int)(e - cell * Q);
+    const int v = map[cell];
+    float4 o = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (v >= 0) o = reinterpret_cast<const float4 *>(feat)[(size_t)v * Q + q];
+    reinterpret_cast<float4 *>(canvas)[e] = o;
+}
+
 LIDAR_EXPORT size_t lidar_pillar_scatter_workspace_bytes(int batch, int nx, int ny) {
     return align_up((size_t)batch * nx * ny * 4, 256);
 }
 
 LIDAR_EXPORT int lidar_pillar_scatter(const float *pillar_features, const void *coords, int coords_are_float,
                                       int num_voxels, const int *num_voxels_dev, int channels, int batch, int nx,
-                                      int ny, float *canvas, void *ws, size_t ws_bytes, void *stream) {
+                                      int ny, int channels_last, float *canvas, void *ws, size_t ws_bytes, void *stream) {
     if (!pillar_features || !coords || !canvas || !ws) return LIDAR_ERR_ARG;
     if (batch <= 0 || nx <= 0 || ny <= 0 || num_voxels < 0) return LIDAR_ERR_ARG;
     if (channels != 64 && channels != 32 && channels != 128) return LIDAR_ERR_ARG;
@@ -256,6 +272,13 @@ LIDAR_EXPORT int lidar_pillar_scatter(const float *pillar_features, const void *
         int ib = divup(num_voxels, 256);
         hipLaunchKernelGGL(scatter_index_kernel, dim3(ib), dim3(256), 0, s, coords, coords_are_float, num_voxels,
                            num_voxels_dev, batch, nx, ny, ny, map);
+    }
+    if (channels_last) {
+        const int nb = divup(cells * (channels / 4), 256);
+        if (channels == 64) hipLaunchKernelGGL(scatter_canvas_nhwc_kernel<64>, dim3(nb), dim3(256), 0, s, pillar_features, map, cells, canvas);
+        else if (channels == 32) hipLaunchKernelGGL(scatter_canvas_nhwc_kernel<32>, dim3(nb), dim3(256), 0, s, pillar_features, map, cells, canvas);
+        else hipLaunchKernelGGL(scatter_canvas_nhwc_kernel<128>, dim3(nb), dim3(256), 0, s, pillar_features, map, cells, canvas);
+        return lidar_check_launch("lidar_pillar_scatter(nhwc)");
     }
     const dim3 grid(divup(nx, SC_XT), ny, batch);
     if (channels == 64)

@@ -72,3 +72,15 @@ def nms_mask_debug(boxes, thresh, normal=False):
     off = L.lidar_nms_mask_ptr(_lib.ptr(ws), 1, n) - ws.data_ptr()
     cb = (n + 63) // 64
     return ws[off:off + n * cb * 8].view(torch.int64).view(n, cb).clone()
+
+
+def boxes_iou_bev_cpu(boxes_a, boxes_b, ans_iou):
+    """iou3d_cpu.cpp:232-252 — CPU tensors; fills ans_iou (N, M).  Runs on the host, touches no GPU state."""
+    if boxes_a.is_cuda or boxes_b.is_cuda or ans_iou.is_cuda:
+        raise _lib.LidarHipError("boxes_iou_bev_cpu takes CPU tensors")
+    for t in (boxes_a, boxes_b, ans_iou):
+        if not t.is_contiguous():
+            raise _lib.LidarHipError("expected a contiguous tensor")   # reference: CHECK_CONTIGUOUS + exit(-1)
+    _lib.check(_lib.lib().lidar_boxes_iou_bev_cpu(_lib.ptr(boxes_a), boxes_a.shape[0], _lib.ptr(boxes_b), boxes_b.shape[0],
+                                                  _lib.ptr(ans_iou)), "lidar_boxes_iou_bev_cpu")
+    return 1

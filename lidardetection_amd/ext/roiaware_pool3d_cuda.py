@@ -33,3 +33,12 @@ def points_in_boxes_gpu(boxes, pts, box_idx_of_points):
     _lib.check(_lib.lib().lidar_points_in_boxes(boxes.shape[0], boxes.shape[1], pts.shape[1], _p(boxes), _p(pts),
                                                 _p(box_idx_of_points), _S()), "lidar_points_in_boxes")
     return 1
+
+
+def points_in_boxes_cpu(boxes, pts, pts_indices):
+    """roiaware_pool3d.cpp:143-168 — CPU tensors: boxes (N,7), pts (P,3), pts_indices (N,P) int32 0/1."""
+    if boxes.is_cuda or pts.is_cuda or pts_indices.is_cuda:
+        raise _lib.LidarHipError("points_in_boxes_cpu takes CPU tensors")
+    _lib.check(_lib.lib().lidar_points_in_boxes_cpu(_p(boxes.contiguous()), boxes.shape[0], _p(pts.contiguous()), pts.shape[0],
+                                                    _p(pts_indices)), "lidar_points_in_boxes_cpu")
+    return 1

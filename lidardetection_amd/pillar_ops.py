@@ -43,17 +43,19 @@ def mean_vfe(voxels, num_points):
     return out
 
 
-def pillar_scatter(pillar_features, coords, batch_size, nx, ny, num_voxels_dev=None, out=None):
+def pillar_scatter(pillar_features, coords, batch_size, nx, ny, num_voxels_dev=None, out=None, channels_last=False):
     """PointPillarScatter (pcdet/models/backbones_2d/map_to_bev/pointpillar_scatter.py:14-37), nz == 1.
     pillar_features (V, C) f32, coords (V,4) [b,z,y,x] i32|f32 -> (B, C, ny, nx) f32."""
     _lib.require_cuda(pillar_features, coords)
     V, C = pillar_features.shape
     if out is None:
-        out = torch.empty((batch_size, C, ny, nx), dtype=torch.float32, device=pillar_features.device)
+        out = torch.empty((batch_size, C, ny, nx), dtype=torch.float32, device=pillar_features.device,
+                          memory_format=torch.channels_last if channels_last else torch.contiguous_format)
     L = _lib.lib()
     wsb = L.lidar_pillar_scatter_workspace_bytes(batch_size, nx, ny)
     ws = workspace.get("scatter", wsb, pillar_features.device)
     _lib.check(L.lidar_pillar_scatter(_lib.ptr(pillar_features), _lib.ptr(coords), int(coords.dtype == torch.float32), V,
-                                      _lib.ptr(num_voxels_dev), C, batch_size, nx, ny, _lib.ptr(out), _lib.ptr(ws), wsb,
+                                      _lib.ptr(num_voxels_dev), C, batch_size, nx, ny, int(bool(channels_last)), _lib.ptr(out),
+                                      _lib.ptr(ws), wsb,
                                       _lib.stream()), "lidar_pillar_scatter")
     return out

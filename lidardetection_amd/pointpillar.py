@@ -74,7 +74,7 @@ def limit_period(val, offset=0.5, period=np.pi):
 
 class PointPillarKITTI(nn.Module):
     def __init__(self, batch_size=16, max_voxels=16000, n_max=20000, device="cuda",
-                 score_thresh=0.1, nms_thresh=0.01, nms_pre=4096, nms_post=500):
+                 score_thresh=0.1, nms_thresh=0.01, nms_pre=4096, nms_post=500, channels_last=True):
         super().__init__()
         self.B, self.n_max = batch_size, n_max
         self.pc_range, self.voxel_size = synth.PP_RANGE, synth.PP_VOXEL
@@ -89,7 +89,10 @@ class PointPillarKITTI(nn.Module):
         self.conv_dir_cls = nn.Conv2d(384, self.num_anchor_per_loc * self.num_dir_bins, 1)
         self.dir_offset, self.dir_limit_offset = 0.78539, 0.0
         self.score_thresh, self.nms_thresh, self.nms_pre, self.nms_post = score_thresh, nms_thresh, nms_pre, nms_post
+        self.channels_last = bool(channels_last) and torch.device(device).type == "cuda"
         self.to(device).eval()
+        if self.channels_last:   # NHWC strides: MIOpen's fp32 kernels then run without layout transposes (stock torch)
+            self.to(memory_format=torch.channels_last)
         self.anchors = generate_anchors(self.pc_range, (self.ny // 2, self.nx // 2), device)
         self._vox_out = self.voxelizer.alloc_outputs(batch_size, device)
         self._folded = None
@@ -124,7 +127,8 @@ class PointPillarKITTI(nn.Module):
         total = vox["voxel_offsets"][self.B:self.B + 1]
         feat = pillar_ops.pillar_vfe(vox["voxels"], vox["voxel_num_points"], vox["voxel_coords"], w, s, t,
                                      self.voxel_size, self.pc_range, num_voxels_dev=total)
-        return pillar_ops.pillar_scatter(feat, vox["voxel_coords"], self.B, self.nx, self.ny, num_voxels_dev=total)
+        return pillar_ops.pillar_scatter(feat, vox["voxel_coords"], self.B, self.nx, self.ny, num_voxels_dev=total,
+                                         channels_last=self.channels_last)
 
     def backbone_head(self, canvas):
         ups, x = [], canvas

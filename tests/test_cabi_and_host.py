@@ -72,3 +72,18 @@ def test_synthetic_generators_are_seeded():
     assert r.shape == (64 * 312, 4)
     bx, sc = synth.boxes_nms(3000)
     assert bx.shape == (4096, 7) and len(np.unique(sc)) == 4096
+
+
+def test_cpu_entry_points_bit_exact_vs_reference_golden(golden_dir):
+    """boxes_iou_bev_cpu / points_in_boxes_cpu (host code in the product library) vs the reference's own compiled CPU
+    functions (tests/golden/iou3d_ref.npz) — these run without a GPU, as they do in the reference's DataLoader workers."""
+    from lidardetection_amd.pcdet.ops.iou3d_nms import iou3d_nms_utils
+    from lidardetection_amd.pcdet.ops.roiaware_pool3d import roiaware_pool3d_utils
+    g = np.load(os.path.join(golden_dir, "iou3d_ref.npz"))
+    iou = iou3d_nms_utils.boxes_bev_iou_cpu(g["boxes_a"], g["boxes_b"])            # numpy in -> numpy out
+    assert isinstance(iou, np.ndarray) and np.array_equal(iou.view(np.uint32), g["iou_bev_cpu"].view(np.uint32))
+    iou_t = iou3d_nms_utils.boxes_bev_iou_cpu(torch.from_numpy(g["nms_boxes_sorted"]), torch.from_numpy(g["nms_boxes_sorted"]))
+    assert np.array_equal(iou_t.numpy().view(np.uint32), g["nms_iou_bev_cpu"].view(np.uint32))
+    pib = roiaware_pool3d_utils.points_in_boxes_cpu(g["pib_points"], g["boxes_a"])
+    ref = np.unpackbits(g["pib_cpu"], axis=1)[:, :g["pib_shape"][1]].astype(np.int32)
+    assert np.array_equal(pib, ref)

@@ -101,6 +101,8 @@ def test_pillar_scatter_full_kitti_grid(dev):
     canvas = pillar_ops.pillar_scatter(feat, o["voxel_coords"], 2, 432, 496)
     exp = pp_oracle.pillar_scatter(feat.cpu(), o["voxel_coords"].cpu().float(), 2, 432, 496)
     assert torch.equal(canvas.cpu(), exp)
+    nhwc = pillar_ops.pillar_scatter(feat, o["voxel_coords"], 2, 432, 496, channels_last=True)   # same tensor, NHWC strides
+    assert nhwc.is_contiguous(memory_format=torch.channels_last) and torch.equal(nhwc.cpu(), exp)
 
 
 def test_iou_matrices_vs_reference_golden(dev, golden_dir):
