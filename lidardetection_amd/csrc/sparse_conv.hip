@@ -360,21 +360,57 @@ __global__ __launch_bounds__(256) void sc_implicit_gemm_kernel(const float *__re
     const int CW = NT * 32;
     for (int k = 0; k < K; ++k) {
         __syncthreads();                          // previous offset's LDS reads are done
-        // W[k] -> LDS (zero padded to NT*32 columns)
-        for (int e = t; e < Cin * CW; e += 256) {
-            const int ci = e / CW, co = e - ci * CW;
-            s_w[e] = co < Cout ? Wt[((size_t)k * Cin + ci) * Cout + co] : 0.f;
+        // W[k] -> LDS (zero padded to NT*32 columns); 16-B loads when the row length allows
+        if ((Cout & 3) == 0) {
+            const int CW4 = CW >> 2, Co4 = Cout >> 2;
+            for (int e = t; e < Cin * CW4; e += 256) {
+                const int ci = e / CW4, q4 = e - ci * CW4;
+                float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+                if (q4 < Co4) v = reinterpret_cast<const float4 *>(Wt + ((size_t)k * Cin + ci) * Cout)[q4];
+                reinterpret_cast<float4 *>(s_w + (size_t)ci * CW)[q4] = v;
+            }
+        } else {
+            for (int e = t; e < Cin * CW; e += 256) {
+                const int ci = e / CW, co = e - ci * CW;
+                s_w[e] = co < Cout ? Wt[((size_t)k * Cin + ci) * Cout + co] : 0.f;
+            }
         }
         // this wave's 32 gathered rows -> LDS
         const int myrow = row0 + (l & 31);
         const int src = (myrow < n_out) ? nbr[(size_t)myrow * K + k] : -1;
         const bool any = __ballot(src >= 0) != 0ull;
         if (any) {
-            // lanes 0..31 know the 32 source rows; every (row, channel) element is copied by lane (e % 64)
-            for (int e = l; e < 32 * Cin; e += 64) {
-                const int r = e / Cin, c = e - r * Cin;
-                const int sr = __shfl(src, r, 64);
-                A[r * Cp + c] = sr >= 0 ? in[(size_t)sr * Cin + c] : 0.f;
+            if ((Cin & 3) == 0) {
+                // 16-B gathers: all of a lane's loads are issued before the first LDS store (independent, in flight together)
+                const int C4 = Cin >> 2;
+                const int nq = 32 * C4;                 // float4 pieces of the 32 x Cin tile
+                for (int it0 = 0; it0 * 64 < nq; it0 += 4) {   // 4 independent 16-B loads per lane per pass
+                    float4 v[4];
+                    int rr[4], cc[4];
+#pragma unroll
+                    for (int u = 0; u < 4; ++u) {
+                        const int e = (it0 + u) * 64 + l;
+                        rr[u] = e / C4;
+                        cc[u] = e - rr[u] * C4;
+                        v[u] = make_float4(0.f, 0.f, 0.f, 0.f);
+                        const int sr = __shfl(src, rr[u] & 31, 64);
+                        if (e < nq && sr >= 0) v[u] = reinterpret_cast<const float4 *>(in + (size_t)sr * Cin)[cc[u]];
+                    }
+#pragma unroll
+                    for (int u = 0; u < 4; ++u) {
+                        const int e = (it0 + u) * 64 + l;
+                        if (e < nq) {
+                            float *dst = A + rr[u] * Cp + cc[u] * 4;
+                            dst[0] = v[u].x; dst[1] = v[u].y; dst[2] = v[u].z; dst[3] = v[u].w;
+                        }
+                    }
+                }
+            } else {
+                for (int e = l; e < 32 * Cin; e += 64) {
+                    const int r = e / Cin, c = e - r * Cin;
+                    const int sr = __shfl(src, r, 64);
+                    A[r * Cp + c] = sr >= 0 ? in[(size_t)sr * Cin + c] : 0.f;
+                }
             }
         }
         __syncthreads();
