@@ -7,7 +7,7 @@ import ctypes as C
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-SO_PATH = os.path.join(_HERE, "csrc", "liblidar_hip.so")
+SO_PATH = os.environ.get("LIDAR_HIP_SO") or os.path.join(_HERE, "csrc", "liblidar_hip.so")   # env override: A/B builds (tools/)
 
 vp, i32, f32, sz = C.c_void_p, C.c_int, C.c_float, C.c_size_t
 
