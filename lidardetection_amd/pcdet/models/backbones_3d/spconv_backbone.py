@@ -58,6 +58,10 @@ class _VoxelBackBoneBase(nn.Module):
         """batch_dict: batch_size, voxel_features (N, C), voxel_coords (N, 4) [b, z, y, x] (float or int)."""
         sp = spconv.SparseConvTensor(features=batch_dict['voxel_features'], indices=batch_dict['voxel_coords'].int(),
                                      spatial_shape=self.sparse_shape, batch_size=batch_dict['batch_size'])
+        # all rulebooks first (coordinates only; the 4 strided convs each read one int back), then a sync-free feature pass
+        idx, shp = sp.indices.contiguous(), sp.spatial_shape
+        for name in ('conv_input', 'conv1', 'conv2', 'conv3', 'conv4', 'conv_out'):
+            idx, shp = spconv.prebuild_rulebooks(getattr(self, name), idx, shp, sp.batch_size, sp.indice_dict)
         x = self.conv_input(sp)
         x1 = self.conv1(x)
         x2 = self.conv2(x1)

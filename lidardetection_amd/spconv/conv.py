@@ -40,6 +40,33 @@ class SparseConvolution(SparseModule):
             bound = 1 / math.sqrt(fan_in)
             init.uniform_(self.bias, -bound, bound)
 
+    def build_rulebook(self, indices, spatial_shape, batch_size, indice_dict):
+        """Coordinate-only part of forward(): makes sure this layer's rulebook is in `indice_dict` and returns the
+        (indices, spatial_shape) of its output.  Rulebooks depend on coordinates alone, so a network can build all of
+        them up front (the only host read-backs of the sparse path) and then run its feature pass without a single sync."""
+        if self.conv1x1 and not self.inverse:
+            return indices, spatial_shape
+        datas = indice_dict.get(self.indice_key) if self.indice_key is not None else None
+        if self.inverse:
+            assert datas is not None, "inverse conv needs the rulebook of its paired conv"
+            return datas["in_indices"], datas["in_spatial_shape"]
+        if self.subm:
+            if datas is None:
+                nbr = ops.subm_rulebook(indices, spatial_shape, self.kernel_size)
+                datas = {"subm": True, "nbr": nbr, "nbr_t": nbr, "in_indices": indices, "out_indices": indices,
+                         "in_spatial_shape": spatial_shape, "out_spatial_shape": spatial_shape}
+                if self.indice_key is not None:
+                    indice_dict[self.indice_key] = datas
+            return indices, spatial_shape
+        out_shape = ops.get_conv_output_size(spatial_shape, self.kernel_size, self.stride, self.padding)
+        if datas is None:
+            out_indices, nbr, nbr_t = ops.conv_rulebook(indices, batch_size, spatial_shape, self.kernel_size, self.stride, self.padding)
+            datas = {"subm": False, "nbr": nbr, "nbr_t": nbr_t, "in_indices": indices, "out_indices": out_indices,
+                     "in_spatial_shape": spatial_shape, "out_spatial_shape": out_shape}
+            if self.indice_key is not None:
+                indice_dict[self.indice_key] = datas
+        return datas["out_indices"], out_shape
+
     def forward(self, input):
         assert isinstance(input, SparseConvTensor)
         features, indices = input.features, input.indices

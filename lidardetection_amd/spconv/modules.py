@@ -63,3 +63,19 @@ class SparseSequential(SparseModule):
             else:
                 input = module(input)
         return input
+
+
+def prebuild_rulebooks(module, indices, spatial_shape, batch_size, indice_dict):
+    """Walks `module` (SparseSequential nests, sparse convolutions, and composite SparseModules exposing their
+    sparse children as attributes in execution order) and builds every rulebook from the coordinates alone.
+    Returns the (indices, spatial_shape) leaving the module.  Dense layers (BatchNorm1d, ReLU) are skipped."""
+    from .conv import SparseConvolution
+    if isinstance(module, SparseConvolution):
+        if indices.dtype != torch.int32:
+            indices = indices.int()
+        return module.build_rulebook(indices.contiguous(), spatial_shape, batch_size, indice_dict)
+    if isinstance(module, SparseModule) or isinstance(module, nn.Sequential):
+        for child in module._modules.values():
+            if isinstance(child, (SparseModule, nn.Sequential)):
+                indices, spatial_shape = prebuild_rulebooks(child, indices, spatial_shape, batch_size, indice_dict)
+    return indices, spatial_shape
