@@ -440,6 +440,100 @@ __global__ __launch_bounds__(256) void sc_implicit_gemm_kernel(const float *__re
     }
 }
 
+// Software-pipelined variant for Cin = 4*C4 in {16, 32, 64, 128} and Cout % 4 == 0: the gathered rows and W[k+1] are
+// fetched into registers while the MFMAs of offset k run out of LDS (global latency hidden behind the matrix pipe).
+template <int NT, int C4>
+__global__ __launch_bounds__(256) void sc_implicit_gemm_pipe_kernel(const float *__restrict__ in, const int *__restrict__ nbr, int n_out,
+                                                                    int K, int Cout, const float *__restrict__ Wt,
+                                                                    const float *__restrict__ bias, float *__restrict__ out) {
+    constexpr int Cin = C4 * 4, Cp = Cin + 1, CW = NT * 32, CW4 = CW / 4;
+    constexpr int NG = (32 * C4) / 64;                    // float4 gathers per lane per offset
+    constexpr int NW = (Cin * CW4 + 255) / 256;           // float4 weight pieces per thread per offset
+    extern __shared__ float s_mem[];
+    float *s_w = s_mem;                                   // [Cin][CW]
+    float *s_a = s_mem + (size_t)Cin * CW;                // [4 waves][32][Cp]
+    const int t = threadIdx.x, l = t & 63, wv = t >> 6;
+    const int row0 = blockIdx.x * IG_ROWS + wv * 32;
+    float *A = s_a + (size_t)wv * 32 * Cp;
+    const int myrow = row0 + (l & 31);
+    const int Co4 = Cout >> 2;
+    f32x16 acc[NT];
+#pragma unroll
+    for (int q = 0; q < NT; ++q)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[q][r] = 0.f;
+    const int ar = l & 31, ak = l >> 5;
+    float4 g[NG], wr[NW];
+    bool any_next;
+    auto fetch = [&](int k) {
+        const int src = (myrow < n_out) ? nbr[(size_t)myrow * K + k] : -1;
+        any_next = __ballot(src >= 0) != 0ull;
+#pragma unroll
+        for (int u = 0; u < NG; ++u) {
+            const int e = u * 64 + l, r = e / C4, c = e - r * C4;
+            const int sr = __shfl(src, r, 64);
+            g[u] = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (any_next && sr >= 0) g[u] = reinterpret_cast<const float4 *>(in + (size_t)sr * Cin)[c];
+        }
+#pragma unroll
+        for (int q = 0; q < NW; ++q) {
+            const int e = q * 256 + t, ci = e / CW4, q4 = e - ci * CW4;
+            wr[q] = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (e < Cin * CW4 && q4 < Co4) wr[q] = reinterpret_cast<const float4 *>(Wt + ((size_t)k * Cin + ci) * Cout)[q4];
+        }
+    };
+    fetch(0);
+    for (int k = 0; k < K; ++k) {
+        const bool any = any_next;
+        __syncthreads();                                  // LDS of the previous offset is no longer read
+        // a workgroup-uniform "somebody needs W[k]" is not known per wave: every wave stores its W pieces whenever IT has work;
+        // waves without work skip both the stores and the MFMAs, so W[k] must be written by the waves that do compute.
+        if (any) {
+#pragma unroll
+            for (int u = 0; u < NG; ++u) {
+                const int e = u * 64 + l, r = e / C4, c = e - r * C4;
+                float *dst = A + r * Cp + c * 4;
+                dst[0] = g[u].x; dst[1] = g[u].y; dst[2] = g[u].z; dst[3] = g[u].w;
+            }
+        }
+        {   // W[k]: pieces are distributed over all 256 threads, so every thread must hold them -> fetched unconditionally below
+#pragma unroll
+            for (int q = 0; q < NW; ++q) {
+                const int e = q * 256 + t;
+                if (e < Cin * CW4) reinterpret_cast<float4 *>(s_w)[e] = wr[q];
+            }
+        }
+        __syncthreads();
+        if (k + 1 < K) fetch(k + 1);                      // in flight while the MFMAs below run
+        if (any) {
+#pragma unroll 4
+            for (int c0 = 0; c0 < Cin; c0 += 2) {
+                const float a = A[ar * Cp + c0 + ak];
+#pragma unroll
+                for (int q = 0; q < NT; ++q) {
+                    const float b = s_w[(c0 + ak) * CW + q * 32 + ar];
+                    acc[q] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, acc[q], 0, 0, 0);
+                }
+            }
+        }
+    }
+#pragma unroll
+    for (int q = 0; q < NT; ++q) {
+        const int col = q * 32 + (l & 31);
+        if (col < Cout) {
+            const float bv = bias ? bias[col] : 0.f;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int row = row0 + (r & 3) + 8 * (r >> 2) + 4 * (l >> 5);
+                if (row < n_out) out[(size_t)row * Cout + col] = acc[q][r] + bv;
+            }
+        }
+    }
+}
+
+static int g_sc_pipe = 1;
+LIDAR_EXPORT void lidar_debug_spconv_pipe(int v) { g_sc_pipe = v; }
+
 // indice_conv forward / dgrad (with the transposed table and W^T) — spconv.functional indice_conv (Appendix A.3)
 LIDAR_EXPORT int lidar_spconv_implicit_gemm(const float *in_features, const int *nbr, int n_out, int K, int Cin, int Cout,
                                             const float *weight, const float *bias, float *out_features, void *stream) {
@@ -450,6 +544,15 @@ LIDAR_EXPORT int lidar_spconv_implicit_gemm(const float *in_features, const int 
     const int nt = divup(Cout, 32);
     const size_t lds = ((size_t)Cin * nt * 32 + (size_t)4 * 32 * (Cin + 1)) * sizeof(float);
     const dim3 grid(divup(n_out, IG_ROWS));
+#define IGP(NT, C4) hipLaunchKernelGGL((sc_implicit_gemm_pipe_kernel<NT, C4>), grid, dim3(256), lds, s, in_features, nbr, n_out, K, Cout, weight, bias, out_features)
+    if ((Cout & 3) == 0 && (Cin == 16 || Cin == 32 || Cin == 64 || Cin == 128) && g_sc_pipe) {
+        const int c4 = Cin / 4;
+#define IGP_NT(C4) switch (nt) { case 1: IGP(1, C4); break; case 2: IGP(2, C4); break; case 3: IGP(3, C4); break; default: IGP(4, C4); break; }
+        if (c4 == 4) { IGP_NT(4) } else if (c4 == 8) { IGP_NT(8) } else if (c4 == 16) { IGP_NT(16) } else { IGP_NT(32) }
+#undef IGP_NT
+        return lidar_check_launch("lidar_spconv_implicit_gemm(pipe)");
+    }
+#undef IGP
 #define IG_CASE(NT) hipLaunchKernelGGL(sc_implicit_gemm_kernel<NT>, grid, dim3(256), lds, s, in_features, nbr, n_out, K, Cin, Cout, weight, bias, out_features)
     switch (nt) {
         case 1: IG_CASE(1); break;
