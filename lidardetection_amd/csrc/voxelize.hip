@@ -38,7 +38,6 @@ struct VxParams {
     int grid[3];  // nx, ny, nz
     int C, P, max_voxels, batch, n_max, compact;
     int H, hshift, ntiles;
-    int dbg;
 };
 
 struct VxWs {
@@ -63,10 +62,6 @@ struct VxWs {
     int *nvox;       // [B]
 };
 
-static int g_vx_dbg = 0;
-LIDAR_EXPORT void lidar_debug_set(int v) { g_vx_dbg = v; }
-static size_t vx_carve(void *base, int B, int n_max, int max_voxels, struct VxWs *w);
-
 
 static int vx_hash_capacity(int n_max) {
     int h = 1024;
@@ -87,7 +82,7 @@ static size_t vx_carve(void *base, int B, int n_max, int max_voxels, VxWs *w) {
     p = take((size_t)B * (divup(n_max, 2560) * 6144) * 4); if (w) w->pfirst = (int *)p;  // also the LDS path's staging lists
     p = take((size_t)B * n_max * 4); if (w) w->flagw = (int *)p;
     p = take((size_t)B * n_max * 8); if (w) w->vinfo = (int2 *)p;
-    p = take(65536); if (w) w->err = (int *)p;  // [0] error flag; rest: debug stamps
+    p = take(65536); if (w) w->err = (int *)p;  // [0] sticky error flag
     p = take((size_t)B * divup(n_max, 1024) * divup(n_max, 2560) * 1024 * 8 + 65536); if (w) w->queue = (int2 *)p;  // [B][tile][G][1024]
     p = take((size_t)B * divup(n_max, 1024) * divup(n_max, 2560) * 4 + 256); if (w) w->qcnt = (int *)p;             // [B][tile][G]
     p = take(B * H * 4); if (w) w->keys = (uint32_t *)p;
@@ -495,9 +490,6 @@ __global__ __launch_bounds__(1024) void vxl_bin_kernel(const int *__restrict__ o
     __shared__ int s_wtot[16];
     __shared__ int s_nent, s_total;
     const int g = blockIdx.x, f = blockIdx.y, t = threadIdx.x, l = t & 63, wv = t >> 6;
-    long long *stamp = reinterpret_cast<long long *>(w.err + 16) + (size_t)(f * G + g) * 16;
-#define VXL_STAMP(i) if (p.dbg == 9 && t == 0) stamp[i] = (long long)__builtin_amdgcn_s_memtime();
-    VXL_STAMP(0)
     const int n = min(offsets[f + 1] - offsets[f], p.n_max);
     // ---- phase B1 (loads): my bin's (point, key) pairs from the ITEMS tile segments written by K0.
     // Counts and the first 256 entries of every segment are requested together (one memory round trip,
@@ -519,8 +511,6 @@ __global__ __launch_bounds__(1024) void vxl_bin_kernel(const int *__restrict__ o
         s_cnt[k] = 0;
     }
     __syncthreads();
-    VXL_STAMP(1)
-    if (p.dbg == 1) return;
     {
         int base = 0;
 #pragma unroll
@@ -542,7 +532,6 @@ __global__ __launch_bounds__(1024) void vxl_bin_kernel(const int *__restrict__ o
         if (t == 0) s_nent = base;
     }
     __syncthreads();
-    VXL_STAMP(2)
     const int ne = min(s_nent, VXL_CAP);
     // ---- phase B2: dense insertion into the LDS hash table (first point, count per voxel)
     for (int e = t; e < ne; e += 1024) {
@@ -569,8 +558,6 @@ __global__ __launch_bounds__(1024) void vxl_bin_kernel(const int *__restrict__ o
         }
     }
     __syncthreads();
-    VXL_STAMP(3)
-    if (p.dbg == 2) return;
     // ---- phase C: list offsets = exclusive scan of m = min(count, P) over the slots (8 per thread)
     int mloc[8];
     int run = 0;
@@ -601,8 +588,6 @@ __global__ __launch_bounds__(1024) void vxl_bin_kernel(const int *__restrict__ o
     const int L = min(s_total, VXL_CAP);
     for (int k = t; k < L; k += 1024) s_q[k].y = VX_INF;
     __syncthreads();
-    VXL_STAMP(4)
-    if (p.dbg == 3) return;
     // ---- phase D: ordered lists (P smallest point indices per voxel, ascending) in LDS
     for (int e = t; e < ne; e += 1024) {
         const int en = s_q[e].x;
@@ -623,8 +608,6 @@ __global__ __launch_bounds__(1024) void vxl_bin_kernel(const int *__restrict__ o
         }
     }
     __syncthreads();
-    VXL_STAMP(5)
-    if (p.dbg == 4) return;
     // ---- phase E: per-point word + this bin's packed lists
     int *pinfo = w.flagw + (size_t)f * p.n_max;
     for (int e = t; e < ne; e += 1024) {
@@ -639,8 +622,6 @@ __global__ __launch_bounds__(1024) void vxl_bin_kernel(const int *__restrict__ o
     }
     int *stg = w.pfirst + ((size_t)f * G + g) * VXL_CAP;   // staging lists live in the pfirst/vinfo region
     for (int k = t; k < L; k += 1024) stg[k] = s_q[k].y;
-    VXL_STAMP(6)
-#undef VXL_STAMP
 }
 
 // voxel ids = rank of the first points in point order: ballot scan, one block per frame
@@ -837,12 +818,6 @@ LIDAR_EXPORT int lidar_voxelize_workspace_init(void *ws, size_t ws_bytes, int ba
     return lidar_check_launch("vx_ws_init");
 }
 
-LIDAR_EXPORT void *lidar_debug_stamp_ptr(void *ws, int batch, int n_max, int max_voxels) {
-    VxWs w;
-    vx_carve(ws, batch, n_max, max_voxels, &w);
-    return w.err + 16;
-}
-
 // sticky overflow flag of the LDS-binned path (0 = fine).  Host-synchronous: call outside captures.
 LIDAR_EXPORT int lidar_voxelize_error_flag(void *ws, size_t ws_bytes, int batch, int n_max, int max_voxels) {
     VxWs w;
@@ -880,7 +855,6 @@ LIDAR_EXPORT int lidar_voxelize(const float *points, const int *point_offsets, i
     while ((1 << hb) < p.H) ++hb;
     p.hshift = 32 - hb;
     p.ntiles = divup(n_max, VX_TILE);
-    p.dbg = g_vx_dbg;
     VxWs w;
     if (vx_carve(ws, batch, n_max, max_voxels, &w) > ws_bytes) return LIDAR_ERR_WORKSPACE;
     hipStream_t s = (hipStream_t)stream;
