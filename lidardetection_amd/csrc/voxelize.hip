@@ -456,7 +456,9 @@ __global__ __launch_bounds__(1024) void vxl_key_kernel(const float *__restrict__
     }
     uint32_t key;
     const bool inside = vx_cell(p, x, y, z, key) && (j < n);
-    if (j < n && !inside) w.flagw[(size_t)f * p.n_max + j] = 0;
+    // every point's word starts at 0: outside points keep it, and so does a point dropped by a bin overflow (its word
+    // must never be stale memory — the rank / row kernels index with it)
+    if (j < n) w.flagw[(size_t)f * p.n_max + j] = 0;
     const uint32_t h2 = (key * 0x85EBCA6Bu) >> 16;
     const int bin = inside ? (int)((h2 * (uint32_t)G) >> 16) : -1;
     int myrank = 0;

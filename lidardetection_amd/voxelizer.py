@@ -76,10 +76,13 @@ class BatchVoxelizer:
                                     nbytes, _lib.stream()), "lidar_voxelize")
         return out
 
-    def check_error_flag(self, batch, n_max, device):
-        """Host-synchronous: raises if the LDS-binned path reported a hash-bin overflow."""
+    def error_flag(self, batch, n_max, device):
+        """Host-synchronous read of the LDS-binned path's sticky overflow flag (0 = fine)."""
         ws, nbytes = self._workspace(batch, max(int(n_max), 1), device)
-        flag = _lib.lib().lidar_voxelize_error_flag(_lib.ptr(ws), nbytes, batch, max(int(n_max), 1), self.max_voxels)
+        return _lib.lib().lidar_voxelize_error_flag(_lib.ptr(ws), nbytes, batch, max(int(n_max), 1), self.max_voxels)
+
+    def check_error_flag(self, batch, n_max, device):
+        flag = self.error_flag(batch, n_max, device)
         if flag != 0:
             raise _lib.LidarHipError(f"lidar_voxelize: LDS hash-bin overflow (flag {flag}); use algo=2")
 
@@ -90,8 +93,20 @@ class BatchVoxelizer:
         sizes = [int(t.shape[0]) for t in ts]
         offs = torch.tensor(np.concatenate([[0], np.cumsum(sizes)]), dtype=torch.int32)
         pts = torch.cat(ts, 0).to(device).contiguous() if sum(sizes) > 0 else torch.zeros((1, self.C), device=device)
-        out = self(pts, offs.to(device), max(sizes) if sizes else 1, compact=True)
+        n_max = max(sizes) if sizes else 1
+        offs_d = offs.to(device)
+        out = self(pts, offs_d, n_max, compact=True)
         total = int(out["voxel_offsets"][-1].item())
-        self.check_error_flag(len(sizes), max(sizes) if sizes else 1, pts.device)
+        if self.algo != 2 and self.error_flag(len(sizes), n_max, pts.device) != 0:
+            # a hash bin overflowed its LDS budget (thousands of points in one bin: adversarial or degenerate input):
+            # redo the batch on the global-hash path, which has no such limit (the sticky flag is cleared by re-init)
+            self._ws = {}
+            keep, self.algo = self.algo, 2
+            try:
+                out = self(pts, offs_d, n_max, compact=True)
+                total = int(out["voxel_offsets"][-1].item())
+            finally:
+                self.algo = keep
+                self._ws = {}
         return {"voxels": out["voxels"][:total], "voxel_coords": out["voxel_coords"][:total],
                 "voxel_num_points": out["voxel_num_points"][:total], "voxel_offsets": out["voxel_offsets"]}

@@ -67,6 +67,24 @@ def test_voxelize_out_of_range_and_edges(dev):
     _check_voxel_parity([pts], synth.PP_VOXEL, synth.PP_RANGE, 32, 16000, 4, dev)
 
 
+def test_voxelize_bin_overflow_falls_back(dev):
+    """20 000 points in ONE pillar overflow a single LDS hash bin: voxelize_frames detects the sticky flag and redoes the
+    batch on the global-hash path; results still equal the sequential oracle."""
+    r = np.random.default_rng(3)
+    pts = np.concatenate([r.uniform(10.0, 10.15, (20000, 2)), r.uniform(-2, 0, (20000, 1)), r.uniform(0, 1, (20000, 1))], 1).astype(np.float32)
+    other = synth.cloud_ring(2003)[:3000]
+    vz = BatchVoxelizer(synth.PP_VOXEL, synth.PP_RANGE, 32, 16000)
+    exp = [c_oracle.voxelize(f, synth.PP_VOXEL, synth.PP_RANGE, 32, 16000) for f in (pts, other)]
+    ev, ec, en = pp_oracle.collate(exp)
+    for _ in range(2):
+        out = vz.voxelize_frames([pts, other], device=dev)
+        assert np.array_equal(out["voxel_coords"].cpu().numpy(), ec.astype(np.int32))
+        assert np.array_equal(out["voxel_num_points"].cpu().numpy(), en)
+        assert np.array_equal(out["voxels"].cpu().numpy(), ev)
+    out = vz.voxelize_frames([other], device=dev)      # and the fast path works again afterwards
+    assert np.array_equal(out["voxels"].cpu().numpy(), exp[1][0])
+
+
 def test_pillar_vfe_vs_reference_golden(dev, golden_dir):
     g = np.load(os.path.join(golden_dir, "pp_modules.npz"))
     t = lambda k, dt=None: torch.from_numpy(g[k]).to(dev) if dt is None else torch.from_numpy(g[k]).to(dev).to(dt)
