@@ -194,6 +194,14 @@ size_t lidar_sparse_to_dense_workspace_bytes(int batch, int D, int H, int W);
 int lidar_sparse_to_dense(const float *features, const int *indices, int n, int channels, int batch, int D, int H, int W,
                           float *out, void *ws, size_t ws_bytes, void *stream);
 
+/* ------------------------------------------------------------------ dense BEV backbone epilogue
+ * Eval-mode BatchNorm2d + ReLU after every Conv2d / ConvTranspose2d of BaseBEVBackbone
+ * (pcdet/models/backbones_2d/base_bev_backbone.py:34-45,51-57) with the BN scale folded into the weights: one pass
+ * out[pix][out_off + c] = act(in[pix][c] + bias[c]) over NHWC rows; out may alias in (out_C == C, out_off == 0) or be
+ * the channel slice of the concatenated map (base_bev_backbone.py:103).  C, out_C, out_off multiples of 4. */
+int lidar_bias_act_nhwc(const float *in, const float *bias, long long n_pix, int C, int relu, float *out, int out_C,
+                        int out_off, void *stream);
+
 /* ------------------------------------------------------------------ CPU entry points (HOST pointers, no GPU touched)
  * Called by the reference from DataLoader workers (augmentation / database creation). */
 /* boxes_iou_bev_cpu (pcdet/ops/iou3d_nms/src/iou3d_cpu.cpp:232-252): out (n_a, n_b) rotated BEV IoU */

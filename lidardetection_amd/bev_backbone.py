@@ -1,0 +1,102 @@
+"""Inference fast path of the dense BEV backbone + anchor head.
+
+The convolutions stay stock torch (MIOpen, fp32, channels-last).  What changes is everything around them:
+  * eval-mode BatchNorm2d is folded into the preceding convolution (scale -> weights, shift -> bias) — the
+    reference's Conv2d/BN/ReLU triplets (pcdet/models/backbones_2d/base_bev_backbone.py:34-45) and
+    ConvTranspose2d/BN/ReLU deblocks (base_bev_backbone.py:51-57);
+  * shift + ReLU run as ONE in-place HIP pass (`lidar_bias_act_nhwc`) instead of a BN pass and a ReLU pass;
+  * the deblock epilogues write directly into their channel slice of the concatenated map
+    (base_bev_backbone.py:103), so `torch.cat` disappears;
+  * the three 1x1 heads of AnchorHeadSingle (pcdet/models/dense_heads/anchor_head_single.py:18-33,45-55) read the
+    384-channel map once (one merged 1x1 convolution) instead of three times.
+Results match the unfolded modules to fp32 rounding (folding re-associates one multiply); tests assert 1e-4.
+"""
+import torch
+import torch.nn as nn
+import torch.nn.functional as F
+
+from . import _lib
+
+
+def bias_act_(x, bias, relu=True, out=None, out_offset=0):
+    """x: (B, C, H, W) channels-last fp32.  out=None: in place.  Otherwise out is a channels-last (B, C_out, H, W)
+    tensor and the result lands in channels [out_offset, out_offset + C)."""
+    _lib.require_cuda(bias)
+    if not (x.is_cuda and x.dim() == 4 and x.is_contiguous(memory_format=torch.channels_last)):
+        raise _lib.LidarHipError("bias_act_: expected a channels-last CUDA tensor")
+    B, C, H, W = x.shape
+    if out is None:
+        out, out_offset = x, 0
+    elif not (out.is_contiguous(memory_format=torch.channels_last) and out.shape[0] == B and out.shape[2:] == x.shape[2:]):
+        raise _lib.LidarHipError("bias_act_: output must be channels-last with the same batch / spatial shape")
+    _lib.check(_lib.lib().lidar_bias_act_nhwc(_lib.ptr(x), _lib.ptr(bias), B * H * W, C, int(bool(relu)), _lib.ptr(out),
+                                              out.shape[1], int(out_offset), _lib.stream()), "lidar_bias_act_nhwc")
+    return out
+
+
+def _fold(weight, bn, out_dim):
+    """scale the conv weight along its output-channel dim by gamma/sqrt(var+eps); return (weight, shift)."""
+    scale = bn.weight.detach() / torch.sqrt(bn.running_var + bn.eps)
+    shift = bn.bias.detach() - bn.running_mean * scale
+    shape = [1] * weight.dim()
+    shape[out_dim] = -1
+    return (weight.detach() * scale.view(shape)), shift.contiguous()
+
+
+class FoldedBEVBackbone:
+    """Built from the (eval-mode) reference-shaped modules; call with the channels-last canvas."""
+
+    def __init__(self, blocks, deblocks, heads):
+        self.stages = []
+        for blk, de in zip(blocks, deblocks):
+            convs, mods, i = [], list(blk), 0
+            while i < len(mods):
+                pad = 0
+                if isinstance(mods[i], nn.ZeroPad2d):
+                    pad, i = int(mods[i].padding[0]), i + 1
+                conv, bn = mods[i], mods[i + 1]
+                assert isinstance(conv, nn.Conv2d) and isinstance(bn, nn.BatchNorm2d) and isinstance(mods[i + 2], nn.ReLU)
+                w, b = _fold(conv.weight, bn, 0)
+                convs.append((w.contiguous(memory_format=torch.channels_last), b, conv.stride, conv.padding[0] + pad))
+                i += 3
+            up, bn = de[0], de[1]
+            if isinstance(up, nn.ConvTranspose2d):
+                w, b = _fold(up.weight, bn, 1)
+                upc = ("deconv", w.contiguous(memory_format=torch.channels_last), b, up.stride)
+            else:   # stride < 1 in the reference config: a strided Conv2d (base_bev_backbone.py:60-69)
+                w, b = _fold(up.weight, bn, 0)
+                upc = ("conv", w.contiguous(memory_format=torch.channels_last), b, up.stride)
+            self.stages.append((convs, upc))
+        self.up_channels = [s[1][2].numel() for s in self.stages]
+        self.head_w = torch.cat([h.weight.detach() for h in heads], 0).contiguous(memory_format=torch.channels_last)
+        self.head_b = torch.cat([h.bias.detach() for h in heads], 0).contiguous()
+        self.head_split = [h.weight.shape[0] for h in heads]
+        self._cat = None
+
+    def features(self, canvas):
+        """-> the concatenated upsampled map (B, sum(up_channels), H, W), channels-last."""
+        x, cat, off = canvas, None, 0
+        for convs, (kind, uw, ub, ustride) in self.stages:
+            for w, b, stride, pad in convs:
+                x = F.conv2d(x, w, None, stride, pad)
+                if not x.is_contiguous(memory_format=torch.channels_last):
+                    x = x.contiguous(memory_format=torch.channels_last)
+                bias_act_(x, b)
+            y = F.conv_transpose2d(x, uw, None, ustride) if kind == "deconv" else F.conv2d(x, uw, None, ustride)
+            if not y.is_contiguous(memory_format=torch.channels_last):
+                y = y.contiguous(memory_format=torch.channels_last)
+            if cat is None:
+                shape = (y.shape[0], sum(self.up_channels), y.shape[2], y.shape[3])
+                if self._cat is None or self._cat.shape != shape or self._cat.device != y.device:
+                    self._cat = torch.empty(shape, dtype=torch.float32, device=y.device,
+                                            memory_format=torch.channels_last)
+                cat = self._cat
+            bias_act_(y, ub, out=cat, out_offset=off)
+            off += y.shape[1]
+        return cat
+
+    def __call__(self, canvas):
+        """-> per-head maps in (B, H, W, C_head) layout (views of one merged head output)."""
+        cat = self.features(canvas)
+        out = F.conv2d(cat, self.head_w, self.head_b).permute(0, 2, 3, 1)
+        return torch.split(out, self.head_split, dim=-1)

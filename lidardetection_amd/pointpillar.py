@@ -22,6 +22,7 @@ import torch
 import torch.nn as nn
 
 from . import pillar_ops, synth
+from .bev_backbone import FoldedBEVBackbone
 from .ext import iou3d_nms_cuda
 from .voxelizer import BatchVoxelizer, grid_size_of
 
@@ -74,7 +75,7 @@ def limit_period(val, offset=0.5, period=np.pi):
 
 class PointPillarKITTI(nn.Module):
     def __init__(self, batch_size=16, max_voxels=16000, n_max=20000, device="cuda",
-                 score_thresh=0.1, nms_thresh=0.01, nms_pre=4096, nms_post=500, channels_last=True):
+                 score_thresh=0.1, nms_thresh=0.01, nms_pre=4096, nms_post=500, channels_last=True, fold_bn=True):
         super().__init__()
         self.B, self.n_max = batch_size, n_max
         self.pc_range, self.voxel_size = synth.PP_RANGE, synth.PP_VOXEL
@@ -96,6 +97,8 @@ class PointPillarKITTI(nn.Module):
         self.anchors = generate_anchors(self.pc_range, (self.ny // 2, self.nx // 2), device)
         self._vox_out = self.voxelizer.alloc_outputs(batch_size, device)
         self._folded = None
+        self.fold_bn = bool(fold_bn) and self.channels_last   # folded BN + HIP epilogue (bev_backbone.py)
+        self._bev = None
 
     def randomize_for_bench(self, seed=0):
         """Random-init weights; BN running stats and the class bias are perturbed so that every frame
@@ -108,7 +111,7 @@ class PointPillarKITTI(nn.Module):
                     m.running_var.copy_(torch.empty(m.num_features).uniform_(0.8, 1.2, generator=g))
             self.conv_cls.bias.zero_()
             self.conv_cls.weight.mul_(4.0)
-        self._folded = None
+        self._folded = self._bev = None
         return self
 
     def _pfn_folded(self):
@@ -131,6 +134,15 @@ class PointPillarKITTI(nn.Module):
                                          channels_last=self.channels_last)
 
     def backbone_head(self, canvas):
+        if self.fold_bn:
+            if self._bev is None:
+                self._bev = FoldedBEVBackbone(self.blocks, self.deblocks, [self.conv_cls, self.conv_box, self.conv_dir_cls])
+            cls, box, dirs = self._bev(canvas)
+            return (cls.reshape(self.B, -1, self.num_class), box.reshape(self.B, -1, 7),
+                    dirs.reshape(self.B, -1, self.num_dir_bins))
+        return self.backbone_head_stock(canvas)
+
+    def backbone_head_stock(self, canvas):
         ups, x = [], canvas
         for blk, de in zip(self.blocks, self.deblocks):
             x = blk(x)

@@ -201,3 +201,42 @@ def test_nms_batched_counts(dev):
     keep, num = iou3d_nms_cuda.nms_batch(bt.to(dev), torch.tensor(cnt, dtype=torch.int32, device=dev), 0.1)
     for k in range(4):
         assert keep[k, :int(num[k])].cpu().tolist() == exp[k].tolist()
+
+
+# ------------------------------------------------------------------ dense BEV backbone epilogue
+@pytest.mark.parametrize("shape,cout,off,relu", [((2, 64, 31, 17), 64, 0, True), ((3, 128, 8, 12), 384, 128, True),
+                                                 ((1, 72, 5, 7), 72, 0, False)])
+def test_bias_act_nhwc_bit_exact(dev, shape, cout, off, relu):
+    from lidardetection_amd.bev_backbone import bias_act_
+    g = torch.Generator(device="cpu").manual_seed(7)
+    x = torch.randn(shape, generator=g).to(dev).contiguous(memory_format=torch.channels_last)
+    b = torch.randn(shape[1], generator=g).to(dev)
+    want = x + b.view(1, -1, 1, 1)
+    want = torch.relu(want) if relu else want
+    if cout == shape[1]:
+        got = bias_act_(x.clone(memory_format=torch.channels_last), b, relu=relu)
+        assert torch.equal(got, want)
+    else:
+        out = torch.full((shape[0], cout, shape[2], shape[3]), -7.0, device=dev).contiguous(memory_format=torch.channels_last)
+        bias_act_(x, b, relu=relu, out=out, out_offset=off)
+        assert torch.equal(out[:, off:off + shape[1]], want)
+        rest = torch.cat([out[:, :off], out[:, off + shape[1]:]], 1)
+        assert torch.all(rest == -7.0)          # neighbouring channel slices untouched
+
+
+def test_folded_bev_backbone_matches_stock_modules(dev):
+    """BN folded into the convs + one-pass HIP epilogue + merged heads vs the unfolded torch modules (fp32, 1e-4)."""
+    from lidardetection_amd.pointpillar import PointPillarKITTI
+    m = PointPillarKITTI(batch_size=2, device=dev).randomize_for_bench(3)
+    assert m.fold_bn
+    g = torch.Generator(device="cpu").manual_seed(11)
+    canvas = torch.randn(2, 64, m.ny, m.nx, generator=g).to(dev)
+    canvas[:, :, ::3] = 0
+    canvas = canvas.contiguous(memory_format=torch.channels_last)
+    with torch.no_grad():
+        got = m.backbone_head(canvas)
+        want = m.backbone_head_stock(canvas)
+    for a, b, name in zip(got, want, ("cls", "box", "dir")):
+        assert a.shape == b.shape, name
+        scale = float(b.abs().max())
+        assert float((a - b).abs().max()) <= 1e-4 * max(scale, 1.0), name

@@ -1,50 +1,43 @@
-"""Explores stock-torch options for the (out-of-scope) dense 2D backbone: memory format, BN folding."""
-import os, sys, time, copy
-import torch, torch.nn as nn
+"""Dense 2D backbone + head of PointPillar-KITTI (bs 16, fp32): stock modules vs the folded-BN fast path
+(lidardetection_amd/bev_backbone.py), plus a probe of torch's fused MIOpen conv+bias+relu op."""
+import os, sys, time
+import torch, torch.nn.functional as F
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from lidardetection_amd.pointpillar import PointPillarKITTI
 dev = torch.device("cuda:0")
-torch.backends.cudnn.benchmark = True
 m = PointPillarKITTI(batch_size=16, device=dev).randomize_for_bench(0)
 x = torch.randn(16, 64, 496, 432, device=dev)
 x[:, :, ::3] = 0
+x = x.contiguous(memory_format=torch.channels_last)
 
-def fold(seq):
-    """Conv2d/ConvTranspose2d + BatchNorm2d (eval) -> conv with bias."""
-    out, mods = [], list(seq)
-    i = 0
-    while i < len(mods):
-        a = mods[i]
-        if isinstance(a, (nn.Conv2d, nn.ConvTranspose2d)) and i + 1 < len(mods) and isinstance(mods[i + 1], nn.BatchNorm2d):
-            bn = mods[i + 1]
-            s = bn.weight / torch.sqrt(bn.running_var + bn.eps)
-            c = copy.deepcopy(a)
-            if isinstance(a, nn.Conv2d):
-                c.weight.data = a.weight.data * s.view(-1, 1, 1, 1)
-            else:
-                c.weight.data = a.weight.data * s.view(1, -1, 1, 1)
-            c.bias = nn.Parameter(bn.bias.data - bn.running_mean * s)
-            out.append(c); i += 2
-        else:
-            out.append(a); i += 1
-    return nn.Sequential(*out)
 
-def run(model, inp, n=10):
+def run(fn, n=10):
     with torch.no_grad():
-        for _ in range(3): model.backbone_head(inp)
+        for _ in range(3): fn()
         torch.cuda.synchronize(); t = time.perf_counter()
-        for _ in range(n): model.backbone_head(inp)
+        for _ in range(n): fn()
         torch.cuda.synchronize()
     return (time.perf_counter() - t) / n * 1e3
 
-print("baseline NCHW            %.2f ms" % run(m, x))
-m2 = copy.deepcopy(m)
-m2.blocks = nn.ModuleList([fold(b) for b in m2.blocks]); m2.deblocks = nn.ModuleList([fold(b) for b in m2.deblocks])
+
+print("stock modules (channels_last)  %.2f ms" % run(lambda: m.backbone_head_stock(x)), flush=True)
+print("folded + HIP epilogue          %.2f ms" % run(lambda: m.backbone_head(x)), flush=True)
+bev = m._bev
+print("  features only                %.2f ms" % run(lambda: bev.features(x)), flush=True)
 with torch.no_grad():
-    a = m.backbone_head(x); b = m2.backbone_head(x)
-print("BN folded  max abs diff cls %.2e box %.2e" % ((a[0]-b[0]).abs().max().item(), (a[1]-b[1]).abs().max().item()))
-print("BN folded NCHW           %.2f ms" % run(m2, x))
-m3 = copy.deepcopy(m2).to(memory_format=torch.channels_last)
-print("BN folded channels_last  %.2f ms" % run(m3, x.contiguous(memory_format=torch.channels_last)))
-m4 = copy.deepcopy(m).to(memory_format=torch.channels_last)
-print("baseline channels_last   %.2f ms" % run(m4, x.contiguous(memory_format=torch.channels_last)))
+    a, b = m.backbone_head(x), m.backbone_head_stock(x)
+print("max abs diff cls %.2e box %.2e dir %.2e" % tuple((p - q).abs().max().item() for p, q in zip(a, b)))
+# probe: MIOpen fusion plan conv+bias+relu through torch
+try:
+    w, bb, stride, pad = bev.stages[0][0][1]
+    y0 = F.conv2d(x, bev.stages[0][0][0][0], None, 2, 1)
+    from lidardetection_amd.bev_backbone import bias_act_
+    bias_act_(y0, bev.stages[0][0][0][1])
+    ref = torch.relu(F.conv2d(y0, w, bb, stride, pad))
+    got = torch.miopen_convolution_relu(y0, w, bb, list(stride), [pad, pad], [1, 1], 1)
+    print("miopen_convolution_relu diff %.2e" % (got - ref).abs().max().item())
+    print("  conv + HIP epilogue  %.3f ms" % run(lambda: bias_act_(F.conv2d(y0, w, None, stride, pad), bb), 20))
+    print("  miopen conv_relu     %.3f ms" % run(lambda: torch.miopen_convolution_relu(y0, w, bb, list(stride), [pad, pad], [1, 1], 1), 20))
+    print("  conv only            %.3f ms" % run(lambda: F.conv2d(y0, w, None, stride, pad), 20))
+except Exception as e:  # noqa: BLE001
+    print("miopen_convolution_relu probe failed:", repr(e)[:300])
