@@ -201,6 +201,10 @@ int lidar_sparse_to_dense(const float *features, const int *indices, int n, int 
  * the channel slice of the concatenated map (base_bev_backbone.py:103).  C, out_C, out_off multiples of 4. */
 int lidar_bias_act_nhwc(const float *in, const float *bias, long long n_pix, int C, int relu, float *out, int out_C,
                         int out_off, void *stream);
+/* Same epilogue for a ConvTranspose2d with kernel == stride == s (base_bev_backbone.py:51-55) evaluated as a GEMM:
+ * in (batch*h*w, s*s*C) with column order (ky, kx, c); out[b][s*y+ky][s*x+kx][out_off + c] = act(in + bias[c]). */
+int lidar_bias_act_upsample_nhwc(const float *in, const float *bias, int batch, int h, int w, int s, int C, int relu,
+                                 float *out, int out_C, int out_off, void *stream);
 
 /* ------------------------------------------------------------------ CPU entry points (HOST pointers, no GPU touched)
  * Called by the reference from DataLoader workers (augmentation / database creation). */

@@ -56,6 +56,7 @@ SIGNATURES = {
     "lidar_sparse_to_dense_workspace_bytes": (sz, [i32, i32, i32, i32]),
     "lidar_sparse_to_dense": (i32, [vp, vp, i32, i32, i32, i32, i32, i32, vp, vp, sz, vp]),
     "lidar_bias_act_nhwc": (i32, [vp, vp, C.c_longlong, i32, i32, vp, i32, i32, vp]),
+    "lidar_bias_act_upsample_nhwc": (i32, [vp, vp, i32, i32, i32, i32, i32, i32, vp, i32, i32, vp]),
     "lidar_boxes_iou_bev_cpu": (i32, [vp, i32, vp, i32, vp]),
     "lidar_points_in_boxes_cpu": (i32, [vp, i32, vp, i32, vp]),
 }

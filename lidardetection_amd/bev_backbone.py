@@ -7,8 +7,10 @@ The convolutions stay stock torch (MIOpen, fp32, channels-last).  What changes i
   * shift + ReLU run as ONE in-place HIP pass (`lidar_bias_act_nhwc`) instead of a BN pass and a ReLU pass;
   * the deblock epilogues write directly into their channel slice of the concatenated map
     (base_bev_backbone.py:103), so `torch.cat` disappears;
+  * ConvTranspose2d with kernel == stride (every deblock of the reference configs) is evaluated as one plain GEMM on
+    the NHWC map (rocBLAS/hipBLASLt through torch.mm) and the epilogue does the pixel shuffle;
   * the three 1x1 heads of AnchorHeadSingle (pcdet/models/dense_heads/anchor_head_single.py:18-33,45-55) read the
-    384-channel map once (one merged 1x1 convolution) instead of three times.
+    384-channel map once (one merged GEMM, torch.addmm) instead of three times.
 Results match the unfolded modules to fp32 rounding (folding re-associates one multiply); tests assert 1e-4.
 """
 import torch
@@ -31,6 +33,22 @@ def bias_act_(x, bias, relu=True, out=None, out_offset=0):
         raise _lib.LidarHipError("bias_act_: output must be channels-last with the same batch / spatial shape")
     _lib.check(_lib.lib().lidar_bias_act_nhwc(_lib.ptr(x), _lib.ptr(bias), B * H * W, C, int(bool(relu)), _lib.ptr(out),
                                               out.shape[1], int(out_offset), _lib.stream()), "lidar_bias_act_nhwc")
+    return out
+
+
+def bias_act_upsample_(y2d, bias, batch, h, w, s, out, out_offset=0, relu=True):
+    """y2d: (batch*h*w, s*s*C) GEMM output of a kernel==stride transposed conv, columns ordered (ky, kx, c).
+    Writes act(y + bias) pixel-shuffled into channels [out_offset, out_offset + C) of the channels-last `out`."""
+    _lib.require_cuda(y2d, bias)
+    C = bias.numel()
+    if y2d.shape != (batch * h * w, s * s * C):
+        raise _lib.LidarHipError("bias_act_upsample_: GEMM output shape does not match (batch*h*w, s*s*C)")
+    if not (out.is_contiguous(memory_format=torch.channels_last) and out.shape[0] == batch
+            and tuple(out.shape[2:]) == (h * s, w * s)):
+        raise _lib.LidarHipError("bias_act_upsample_: output must be channels-last (batch, C_out, h*s, w*s)")
+    _lib.check(_lib.lib().lidar_bias_act_upsample_nhwc(_lib.ptr(y2d), _lib.ptr(bias), batch, h, w, s, C, int(bool(relu)),
+                                                       _lib.ptr(out), out.shape[1], int(out_offset), _lib.stream()),
+               "lidar_bias_act_upsample_nhwc")
     return out
 
 
@@ -62,13 +80,20 @@ class FoldedBEVBackbone:
             up, bn = de[0], de[1]
             if isinstance(up, nn.ConvTranspose2d):
                 w, b = _fold(up.weight, bn, 1)
-                upc = ("deconv", w.contiguous(memory_format=torch.channels_last), b, up.stride)
+                if tuple(up.kernel_size) == tuple(up.stride) and up.stride[0] == up.stride[1] and \
+                        tuple(up.padding) == (0, 0) and tuple(up.output_padding) == (0, 0):
+                    # kernel == stride: every input pixel owns its own s x s output patch -> a plain GEMM
+                    upc = ("gemm", w.permute(0, 2, 3, 1).reshape(w.shape[0], -1).contiguous(), b, up.stride[0])
+                else:
+                    upc = ("deconv", w.contiguous(memory_format=torch.channels_last), b, up.stride)
             else:   # stride < 1 in the reference config: a strided Conv2d (base_bev_backbone.py:60-69)
                 w, b = _fold(up.weight, bn, 0)
                 upc = ("conv", w.contiguous(memory_format=torch.channels_last), b, up.stride)
             self.stages.append((convs, upc))
         self.up_channels = [s[1][2].numel() for s in self.stages]
-        self.head_w = torch.cat([h.weight.detach() for h in heads], 0).contiguous(memory_format=torch.channels_last)
+        for h in heads:
+            assert tuple(h.kernel_size) == (1, 1) and tuple(h.stride) == (1, 1)
+        self.head_wt = torch.cat([h.weight.detach().flatten(1) for h in heads], 0).t().contiguous()   # (C_in, sum C_head)
         self.head_b = torch.cat([h.bias.detach() for h in heads], 0).contiguous()
         self.head_split = [h.weight.shape[0] for h in heads]
         self._cat = None
@@ -82,21 +107,31 @@ class FoldedBEVBackbone:
                 if not x.is_contiguous(memory_format=torch.channels_last):
                     x = x.contiguous(memory_format=torch.channels_last)
                 bias_act_(x, b)
-            y = F.conv_transpose2d(x, uw, None, ustride) if kind == "deconv" else F.conv2d(x, uw, None, ustride)
-            if not y.is_contiguous(memory_format=torch.channels_last):
-                y = y.contiguous(memory_format=torch.channels_last)
+            B, _, h, w = x.shape
+            if kind == "gemm":
+                y = torch.mm(x.permute(0, 2, 3, 1).reshape(B * h * w, -1), uw)      # the NHWC map IS the row-major A
+                oh, ow = h * ustride, w * ustride
+            else:
+                y = F.conv_transpose2d(x, uw, None, ustride) if kind == "deconv" else F.conv2d(x, uw, None, ustride)
+                if not y.is_contiguous(memory_format=torch.channels_last):
+                    y = y.contiguous(memory_format=torch.channels_last)
+                oh, ow = y.shape[2], y.shape[3]
             if cat is None:
-                shape = (y.shape[0], sum(self.up_channels), y.shape[2], y.shape[3])
-                if self._cat is None or self._cat.shape != shape or self._cat.device != y.device:
-                    self._cat = torch.empty(shape, dtype=torch.float32, device=y.device,
+                shape = (B, sum(self.up_channels), oh, ow)
+                if self._cat is None or self._cat.shape != shape or self._cat.device != x.device:
+                    self._cat = torch.empty(shape, dtype=torch.float32, device=x.device,
                                             memory_format=torch.channels_last)
                 cat = self._cat
-            bias_act_(y, ub, out=cat, out_offset=off)
-            off += y.shape[1]
+            if kind == "gemm":
+                bias_act_upsample_(y, ub, B, h, w, ustride, cat, off)
+            else:
+                bias_act_(y, ub, out=cat, out_offset=off)
+            off += ub.numel()
         return cat
 
     def __call__(self, canvas):
         """-> per-head maps in (B, H, W, C_head) layout (views of one merged head output)."""
         cat = self.features(canvas)
-        out = F.conv2d(cat, self.head_w, self.head_b).permute(0, 2, 3, 1)
-        return torch.split(out, self.head_split, dim=-1)
+        B, C, H, W = cat.shape
+        out = torch.addmm(self.head_b, cat.permute(0, 2, 3, 1).reshape(B * H * W, C), self.head_wt)   # 1x1 heads = one GEMM
+        return torch.split(out.view(B, H, W, -1), self.head_split, dim=-1)

@@ -240,3 +240,20 @@ def test_folded_bev_backbone_matches_stock_modules(dev):
         assert a.shape == b.shape, name
         scale = float(b.abs().max())
         assert float((a - b).abs().max()) <= 1e-4 * max(scale, 1.0), name
+
+
+@pytest.mark.parametrize("s", [1, 2, 4])
+def test_deblock_as_gemm_with_pixel_shuffle_epilogue(dev, s):
+    """ConvTranspose2d(kernel == stride) = GEMM + shuffle epilogue, vs torch's conv_transpose2d (fp32, 1e-5)."""
+    from lidardetection_amd.bev_backbone import bias_act_upsample_
+    g = torch.Generator(device="cpu").manual_seed(5 + s)
+    B, Cin, Cout, h, w = 2, 24, 16, 7, 9
+    x = torch.randn(B, Cin, h, w, generator=g).to(dev).contiguous(memory_format=torch.channels_last)
+    wt = (torch.randn(Cin, Cout, s, s, generator=g) * 0.2).to(dev)
+    b = torch.randn(Cout, generator=g).to(dev)
+    want = torch.relu(torch.nn.functional.conv_transpose2d(x, wt, b, stride=s))
+    out = torch.full((B, 40, h * s, w * s), -3.0, device=dev).contiguous(memory_format=torch.channels_last)
+    y = torch.mm(x.permute(0, 2, 3, 1).reshape(B * h * w, Cin), wt.permute(0, 2, 3, 1).reshape(Cin, -1).contiguous())
+    bias_act_upsample_(y, b, B, h, w, s, out, 8)
+    np.testing.assert_allclose(out[:, 8:24].cpu().numpy(), want.cpu().numpy(), rtol=0, atol=1e-5)
+    assert torch.all(out[:, :8] == -3.0) and torch.all(out[:, 24:] == -3.0)
