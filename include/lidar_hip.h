@@ -186,6 +186,12 @@ int lidar_spconv_conv_tables(int n, int kD, int kH, int kW, int sD, int sH, int 
  * out (n_out, Cout) = sum_k in[nbr[., k]] @ weight[k] (+ bias); weight (K, Cin, Cout); fp32 MFMA; Cin, Cout <= 128 */
 int lidar_spconv_implicit_gemm(const float *in_features, const int *nbr, int n_out, int K, int Cin, int Cout,
                                const float *weight, const float *bias, float *out_features, void *stream);
+/* the same GEMM with the inference epilogue of the reference's SubMConv3d/SparseConv3d + BatchNorm1d + ReLU triplets
+ * (pcdet/models/backbones_3d/spconv_backbone.py:20-26; BN scale folded into `weight`, shift passed as `bias`) and of
+ * SparseBasicBlock (spconv_backbone.py:49-63): out = act(gemm + bias + residual); residual (n_out, Cout) or NULL */
+int lidar_spconv_implicit_gemm_fused(const float *in_features, const int *nbr, int n_out, int K, int Cin, int Cout,
+                                     const float *weight, const float *bias, const float *residual, int relu,
+                                     float *out_features, void *stream);
 /* weight gradient: grad_weight (K, Cin, Cout) += sum_j in[nbr[j][k]]^T (x) grad_out[j]; zero-filled by the caller */
 int lidar_spconv_wgrad(const float *in_features, const float *grad_out, const int *nbr, int n_out, int K, int Cin, int Cout,
                        float *grad_weight, void *stream);

@@ -343,7 +343,8 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
 template <int NT>
 __global__ __launch_bounds__(256) void sc_implicit_gemm_kernel(const float *__restrict__ in, const int *__restrict__ nbr, int n_out, int K,
                                                                int Cin, int Cout, const float *__restrict__ Wt,
-                                                               const float *__restrict__ bias, float *__restrict__ out) {
+                                                               const float *__restrict__ bias, const float *__restrict__ residual,
+                                                               int relu, float *__restrict__ out) {
     extern __shared__ float s_mem[];
     const int Cp = Cin + 1;                       // padded row stride of the gathered tiles
     float *s_w = s_mem;                           // [Cin][NT*32]
@@ -434,7 +435,11 @@ __global__ __launch_bounds__(256) void sc_implicit_gemm_kernel(const float *__re
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
                 const int row = row0 + (r & 3) + 8 * (r >> 2) + 4 * (l >> 5);
-                if (row < n_out) out[(size_t)row * Cout + col] = acc[q][r] + bv;
+                if (row < n_out) {              // fused epilogue: (+ bias) (+ residual) (ReLU)
+                    float v = acc[q][r] + bv;
+                    if (residual) v += residual[(size_t)row * Cout + col];
+                    out[(size_t)row * Cout + col] = relu ? fmaxf(v, 0.f) : v;
+                }
             }
         }
     }
@@ -445,7 +450,8 @@ __global__ __launch_bounds__(256) void sc_implicit_gemm_kernel(const float *__re
 template <int NT, int C4>
 __global__ __launch_bounds__(256) void sc_implicit_gemm_pipe_kernel(const float *__restrict__ in, const int *__restrict__ nbr, int n_out,
                                                                     int K, int Cout, const float *__restrict__ Wt,
-                                                                    const float *__restrict__ bias, float *__restrict__ out) {
+                                                                    const float *__restrict__ bias, const float *__restrict__ residual,
+                                                                    int relu, float *__restrict__ out) {
     constexpr int Cin = C4 * 4, Cp = Cin + 1, CW = NT * 32, CW4 = CW / 4;
     constexpr int NG = (32 * C4) / 64;                    // float4 gathers per lane per offset
     constexpr int NW = (Cin * CW4 + 255) / 256;           // float4 weight pieces per thread per offset
@@ -525,18 +531,22 @@ __global__ __launch_bounds__(256) void sc_implicit_gemm_pipe_kernel(const float 
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
                 const int row = row0 + (r & 3) + 8 * (r >> 2) + 4 * (l >> 5);
-                if (row < n_out) out[(size_t)row * Cout + col] = acc[q][r] + bv;
+                if (row < n_out) {              // fused epilogue: (+ bias) (+ residual) (ReLU)
+                    float v = acc[q][r] + bv;
+                    if (residual) v += residual[(size_t)row * Cout + col];
+                    out[(size_t)row * Cout + col] = relu ? fmaxf(v, 0.f) : v;
+                }
             }
         }
     }
 }
 
-static int g_sc_pipe = 1;
-LIDAR_EXPORT void lidar_debug_spconv_pipe(int v) { g_sc_pipe = v; }
-
-// indice_conv forward / dgrad (with the transposed table and W^T) — spconv.functional indice_conv (Appendix A.3)
-LIDAR_EXPORT int lidar_spconv_implicit_gemm(const float *in_features, const int *nbr, int n_out, int K, int Cin, int Cout,
-                                            const float *weight, const float *bias, float *out_features, void *stream) {
+// indice_conv forward / dgrad (with the transposed table and W^T) — spconv.functional indice_conv (Appendix A.3) —
+// with the inference epilogue of the reference's conv/BatchNorm1d/ReLU triplets (spconv_backbone.py:20-26) and of
+// SparseBasicBlock (spconv_backbone.py:49-63): out = act(gemm + bias + residual).
+LIDAR_EXPORT int lidar_spconv_implicit_gemm_fused(const float *in_features, const int *nbr, int n_out, int K, int Cin, int Cout,
+                                                  const float *weight, const float *bias, const float *residual, int relu,
+                                                  float *out_features, void *stream) {
     if (n_out < 0 || K <= 0 || Cin <= 0 || Cout <= 0 || Cin > IG_MAX_C || Cout > IG_MAX_C) return LIDAR_ERR_ARG;
     if (n_out == 0) return LIDAR_OK;
     if (!in_features || !nbr || !weight || !out_features) return LIDAR_ERR_ARG;
@@ -544,8 +554,8 @@ LIDAR_EXPORT int lidar_spconv_implicit_gemm(const float *in_features, const int 
     const int nt = divup(Cout, 32);
     const size_t lds = ((size_t)Cin * nt * 32 + (size_t)4 * 32 * (Cin + 1)) * sizeof(float);
     const dim3 grid(divup(n_out, IG_ROWS));
-#define IGP(NT, C4) hipLaunchKernelGGL((sc_implicit_gemm_pipe_kernel<NT, C4>), grid, dim3(256), lds, s, in_features, nbr, n_out, K, Cout, weight, bias, out_features)
-    if ((Cout & 3) == 0 && (Cin == 16 || Cin == 32 || Cin == 64 || Cin == 128) && g_sc_pipe) {
+#define IGP(NT, C4) hipLaunchKernelGGL((sc_implicit_gemm_pipe_kernel<NT, C4>), grid, dim3(256), lds, s, in_features, nbr, n_out, K, Cout, weight, bias, residual, relu, out_features)
+    if ((Cout & 3) == 0 && (Cin == 16 || Cin == 32 || Cin == 64 || Cin == 128)) {
         const int c4 = Cin / 4;
 #define IGP_NT(C4) switch (nt) { case 1: IGP(1, C4); break; case 2: IGP(2, C4); break; case 3: IGP(3, C4); break; default: IGP(4, C4); break; }
         if (c4 == 4) { IGP_NT(4) } else if (c4 == 8) { IGP_NT(8) } else if (c4 == 16) { IGP_NT(16) } else { IGP_NT(32) }
@@ -553,7 +563,7 @@ LIDAR_EXPORT int lidar_spconv_implicit_gemm(const float *in_features, const int 
         return lidar_check_launch("lidar_spconv_implicit_gemm(pipe)");
     }
 #undef IGP
-#define IG_CASE(NT) hipLaunchKernelGGL(sc_implicit_gemm_kernel<NT>, grid, dim3(256), lds, s, in_features, nbr, n_out, K, Cin, Cout, weight, bias, out_features)
+#define IG_CASE(NT) hipLaunchKernelGGL(sc_implicit_gemm_kernel<NT>, grid, dim3(256), lds, s, in_features, nbr, n_out, K, Cin, Cout, weight, bias, residual, relu, out_features)
     switch (nt) {
         case 1: IG_CASE(1); break;
         case 2: IG_CASE(2); break;
@@ -562,6 +572,12 @@ LIDAR_EXPORT int lidar_spconv_implicit_gemm(const float *in_features, const int 
     }
 #undef IG_CASE
     return lidar_check_launch("lidar_spconv_implicit_gemm");
+}
+
+LIDAR_EXPORT int lidar_spconv_implicit_gemm(const float *in_features, const int *nbr, int n_out, int K, int Cin, int Cout,
+                                            const float *weight, const float *bias, float *out_features, void *stream) {
+    return lidar_spconv_implicit_gemm_fused(in_features, nbr, n_out, K, Cin, Cout, weight, bias, nullptr, 0, out_features,
+                                            stream);
 }
 
 // ------------------------------------------------------------------ weight gradient

@@ -37,6 +37,12 @@ class SparseBasicBlock(spconv.SparseModule):
         self.stride = stride
 
     def forward(self, x):
+        import torch
+        if not torch.is_grad_enabled() and not self.bn1.training and x.indices.shape[0] != 0:
+            # inference: each conv + BN (+ residual) + ReLU is one launch (spconv.conv.forward_fused)
+            identity = x if self.downsample is None else self.downsample(x)
+            out = self.conv1.forward_fused(x, self.bn1, relu=True)
+            return self.conv2.forward_fused(out, self.bn2, relu=True, residual=identity.features)
         identity = x
         out = self.conv1(x)
         out.features = self.relu(self.bn1(out.features))

@@ -67,56 +67,88 @@ class SparseConvolution(SparseModule):
                 indice_dict[self.indice_key] = datas
         return datas["out_indices"], out_shape
 
-    def forward(self, input):
-        assert isinstance(input, SparseConvTensor)
-        features, indices = input.features, input.indices
+    def _resolve(self, input):
+        """-> (indices, out_indices, out_shape, fwd_table, bwd_table, flip) for this layer on `input` (rulebook built
+        or fetched through indice_key); tables are None for a 1x1 convolution."""
+        indices = input.indices
         spatial_shape, batch_size = input.spatial_shape, input.batch_size
         if indices.dtype != torch.int32:
             indices = indices.int()
         indices = indices.contiguous()
-        if self.subm:
-            out_shape = spatial_shape
-        elif self.inverse:
-            out_shape = None
-        else:
-            out_shape = ops.get_conv_output_size(spatial_shape, self.kernel_size, self.stride, self.padding)
-
         if self.conv1x1 and not self.inverse:
-            f = torch.mm(features, self.weight.view(self.in_channels, self.out_channels))
-            if self.bias is not None:
-                f = f + self.bias
-            out = SparseConvTensor(f, indices, spatial_shape, batch_size)
-            out.indice_dict, out.grid = input.indice_dict, input.grid
-            return out
-
+            return indices, indices, spatial_shape, None, None, False
         datas = input.find_indice_pair(self.indice_key)
         if self.inverse:
             assert datas is not None and self.indice_key is not None, "inverse conv needs the rulebook of its paired conv"
-            out_indices, out_shape = datas["in_indices"], datas["in_spatial_shape"]
-            fwd_table, bwd_table, flip = datas["nbr_t"], datas["nbr"], False
             assert datas["out_indices"].shape[0] == indices.shape[0], "inverse conv input does not match the paired conv's output"
-        elif self.subm:
+            return indices, datas["in_indices"], datas["in_spatial_shape"], datas["nbr_t"], datas["nbr"], False
+        if self.subm:
             if datas is None:
                 nbr = ops.subm_rulebook(indices, spatial_shape, self.kernel_size)
                 datas = {"subm": True, "nbr": nbr, "nbr_t": nbr, "in_indices": indices, "out_indices": indices,
                          "in_spatial_shape": spatial_shape, "out_spatial_shape": spatial_shape}
                 if self.indice_key is not None:
                     input.indice_dict[self.indice_key] = datas
-            out_indices = indices
-            fwd_table, bwd_table, flip = datas["nbr"], datas["nbr"], True
-        else:
-            if datas is None:
-                out_indices, nbr, nbr_t = ops.conv_rulebook(indices, batch_size, spatial_shape, self.kernel_size, self.stride,
-                                                            self.padding)
-                datas = {"subm": False, "nbr": nbr, "nbr_t": nbr_t, "in_indices": indices, "out_indices": out_indices,
-                         "in_spatial_shape": spatial_shape, "out_spatial_shape": out_shape}
-                if self.indice_key is not None:
-                    input.indice_dict[self.indice_key] = datas
-            out_indices = datas["out_indices"]
-            fwd_table, bwd_table, flip = datas["nbr"], datas["nbr_t"], False
+            return indices, indices, spatial_shape, datas["nbr"], datas["nbr"], True
+        out_shape = ops.get_conv_output_size(spatial_shape, self.kernel_size, self.stride, self.padding)
+        if datas is None:
+            out_indices, nbr, nbr_t = ops.conv_rulebook(indices, batch_size, spatial_shape, self.kernel_size, self.stride,
+                                                        self.padding)
+            datas = {"subm": False, "nbr": nbr, "nbr_t": nbr_t, "in_indices": indices, "out_indices": out_indices,
+                     "in_spatial_shape": spatial_shape, "out_spatial_shape": out_shape}
+            if self.indice_key is not None:
+                input.indice_dict[self.indice_key] = datas
+        return indices, datas["out_indices"], out_shape, datas["nbr"], datas["nbr_t"], False
 
-        out_features = ops.indice_conv(features, self.weight, self.bias, fwd_table, bwd_table, flip)
-        out = SparseConvTensor(out_features, out_indices, out_shape, batch_size)
+    def forward(self, input):
+        assert isinstance(input, SparseConvTensor)
+        indices, out_indices, out_shape, fwd_table, bwd_table, flip = self._resolve(input)
+        if fwd_table is None:
+            f = torch.mm(input.features, self.weight.view(self.in_channels, self.out_channels))
+            if self.bias is not None:
+                f = f + self.bias
+        else:
+            f = ops.indice_conv(input.features, self.weight, self.bias, fwd_table, bwd_table, flip)
+        out = SparseConvTensor(f, out_indices, out_shape, input.batch_size)
+        out.indice_dict, out.grid = input.indice_dict, input.grid
+        return out
+
+    # ---- inference fast path: conv + BatchNorm1d(eval) (+ residual) (+ ReLU) in one launch -------------------------
+    def _folded(self, bn):
+        """(weight (K, Cin, Cout) * bn scale, bn shift (+ scaled conv bias)); cached until a parameter changes."""
+        srcs = [self.weight, self.bias] + ([bn.weight, bn.bias, bn.running_mean, bn.running_var] if bn is not None else [])
+        key = tuple((t.data_ptr(), t._version) for t in srcs if t is not None) + (id(bn),)
+        cache = getattr(self, "_fold_cache", None)
+        if cache is None or cache[0] != key:
+            with torch.no_grad():
+                w = self.weight.detach().reshape(-1, self.in_channels, self.out_channels)
+                b = self.bias.detach() if self.bias is not None else None
+                if bn is not None:
+                    scale = bn.weight.detach() / torch.sqrt(bn.running_var + bn.eps)
+                    shift = bn.bias.detach() - bn.running_mean * scale
+                    w = w * scale.view(1, 1, -1)
+                    b = shift if b is None else b * scale + shift
+                cache = (key, w.contiguous(), None if b is None else b.contiguous())
+            self._fold_cache = cache
+        return cache[1], cache[2]
+
+    def forward_fused(self, input, bn=None, relu=False, residual=None):
+        """act(bn(conv(input)) + residual) with eval-mode BatchNorm1d folded into the weights; no autograd graph.
+        Equals the unfused module sequence to fp32 rounding (one re-associated multiply)."""
+        assert isinstance(input, SparseConvTensor)
+        assert bn is None or (not bn.training and bn.track_running_stats), "BatchNorm must be in eval mode to be folded"
+        indices, out_indices, out_shape, fwd_table, _, _ = self._resolve(input)
+        w, b = self._folded(bn)
+        feats = input.features.detach().contiguous()
+        if fwd_table is None:
+            f = torch.mm(feats, w[0]) if b is None else torch.addmm(b, feats, w[0])
+            if residual is not None:
+                f = f + residual
+            if relu:
+                f = torch.relu_(f)
+        else:
+            f = ops.indice_conv_fused(feats, fwd_table, w, b, None if residual is None else residual.contiguous(), relu)
+        out = SparseConvTensor(f, out_indices, out_shape, input.batch_size)
         out.indice_dict, out.grid = input.indice_dict, input.grid
         return out
 

@@ -53,6 +53,8 @@ class SparseSequential(SparseModule):
         self.add_module(name, module)
 
     def forward(self, input):
+        if not torch.is_grad_enabled():
+            return self._forward_inference(input)
         for module in self._modules.values():
             if is_spconv_module(module):
                 assert isinstance(input, SparseConvTensor)
@@ -63,6 +65,36 @@ class SparseSequential(SparseModule):
             else:
                 input = module(input)
         return input
+
+
+def _forward_inference(self, input):
+    """no-grad path: a sparse convolution followed by an eval-mode BatchNorm1d (and a ReLU) runs as ONE launch with the
+    normalisation folded into the weights and the activation in the GEMM epilogue (conv.forward_fused)."""
+    from .conv import SparseConvolution
+    mods = list(self._modules.values())
+    i = 0
+    while i < len(mods):
+        module = mods[i]
+        if isinstance(module, SparseConvolution) and isinstance(input, SparseConvTensor) and input.indices.shape[0] != 0:
+            bn = mods[i + 1] if i + 1 < len(mods) else None
+            if isinstance(bn, nn.BatchNorm1d) and not bn.training and bn.track_running_stats:
+                relu = i + 2 < len(mods) and isinstance(mods[i + 2], nn.ReLU)
+                input = module.forward_fused(input, bn, relu)
+                i += 3 if relu else 2
+                continue
+        if is_spconv_module(module):
+            assert isinstance(input, SparseConvTensor)
+            input = module(input)
+        elif isinstance(input, SparseConvTensor):
+            if input.indices.shape[0] != 0:
+                input.features = module(input.features)
+        else:
+            input = module(input)
+        i += 1
+    return input
+
+
+SparseSequential._forward_inference = _forward_inference
 
 
 def prebuild_rulebooks(module, indices, spatial_shape, batch_size, indice_dict):

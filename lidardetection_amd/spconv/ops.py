@@ -77,6 +77,22 @@ def _implicit_gemm(feats, nbr, weight_kcc, bias, n_out):
     return out
 
 
+def indice_conv_fused(feats, nbr, weight_kcc, bias, residual=None, relu=False):
+    """Inference-only: act(sum_k feats[nbr[:, k]] @ weight_kcc[k] + bias + residual) in one launch (no autograd)."""
+    K, Cin, Cout = weight_kcc.shape
+    n_out = nbr.shape[0]
+    _lib.require_cuda(feats, weight_kcc, nbr, bias, residual)
+    out = torch.empty((n_out, Cout), dtype=torch.float32, device=feats.device)
+    if n_out == 0:
+        return out
+    if residual is not None and tuple(residual.shape) != (n_out, Cout):
+        raise _lib.LidarHipError("indice_conv_fused: residual must be (n_out, Cout)")
+    _lib.check(_lib.lib().lidar_spconv_implicit_gemm_fused(_lib.ptr(feats), _lib.ptr(nbr), n_out, K, Cin, Cout,
+                                                           _lib.ptr(weight_kcc), _lib.ptr(bias), _lib.ptr(residual), int(bool(relu)),
+                                                           _lib.ptr(out), _lib.stream()), "lidar_spconv_implicit_gemm_fused")
+    return out
+
+
 class SparseConvFunction(Function):
     """features (N_in, Cin), weight (kD,kH,kW,Cin,Cout) [, bias] -> (N_out, Cout) through a neighbour table.
 

@@ -138,3 +138,53 @@ def test_dense_and_sequential_and_empty(dev):
     assert oe.features.shape[0] == 0
     dw = spconv.SparseConv3d(128, 16, 3, stride=2, padding=1).to(dev)(empty)
     assert dw.features.shape == (0, 16)
+
+
+def _randomize_bn(m, seed):
+    g = torch.Generator(device="cpu").manual_seed(seed)
+    with torch.no_grad():
+        for mod in m.modules():
+            if isinstance(mod, torch.nn.BatchNorm1d):
+                mod.weight.copy_(torch.empty(mod.num_features).uniform_(0.5, 1.5, generator=g))
+                mod.bias.copy_(torch.empty(mod.num_features).uniform_(-0.3, 0.3, generator=g))
+                mod.running_mean.copy_(torch.empty(mod.num_features).uniform_(-0.2, 0.2, generator=g))
+                mod.running_var.copy_(torch.empty(mod.num_features).uniform_(0.6, 1.4, generator=g))
+
+
+def test_inference_fused_conv_bn_relu_matches_module_sequence(dev):
+    """no-grad path (BatchNorm folded into the weights, ReLU / residual in the GEMM epilogue, one launch per layer) vs the
+    plain module sequence (conv kernel, torch BatchNorm1d, torch ReLU), for subm / strided / inverse / 1x1 / residual."""
+    from lidardetection_amd.pcdet.models.backbones_3d.spconv_backbone import SparseBasicBlock, post_act_block
+    from functools import partial
+    shape, B, n = [9, 14, 12], 2, 700
+    idx = _sites(21, B, shape, n)
+    feats = torch.from_numpy(np.random.default_rng(5).standard_normal((n, 16)).astype(np.float32)).to(dev)
+    norm = partial(torch.nn.BatchNorm1d, eps=1e-3, momentum=0.01)
+    torch.manual_seed(4)
+    net = spconv.SparseSequential(
+        post_act_block(16, 16, 3, norm_fn=norm, padding=1, indice_key="subm1"),
+        SparseBasicBlock(16, 16, norm_fn=norm, indice_key="res1"),
+        post_act_block(16, 32, 3, norm_fn=norm, stride=2, padding=1, indice_key="spconv2", conv_type="spconv"),
+        spconv.SparseSequential(spconv.SubMConv3d(32, 32, 1, bias=True), norm(32)),          # 1x1, BN, no ReLU
+        post_act_block(32, 16, 3, norm_fn=norm, indice_key="spconv2", conv_type="inverseconv"),
+        spconv.SubMConv3d(16, 8, 3, padding=1, bias=True, indice_key="subm1"),               # bare conv: unfused path
+    ).to(dev).eval()
+    _randomize_bn(net, 9)
+    x = lambda: spconv.SparseConvTensor(feats, torch.from_numpy(idx).to(dev), shape, B)
+    with torch.enable_grad():
+        want = net(x())
+    with torch.no_grad():
+        got = net(x())
+        got2 = net(x())                                   # folded weights come from the cache the second time
+    assert torch.equal(got.indices, want.indices) and got.spatial_shape == want.spatial_shape
+    scale = float(want.features.abs().max())
+    assert float((got.features - want.features.detach()).abs().max()) <= 1e-5 * max(scale, 1.0)
+    assert torch.equal(got.features, got2.features)
+    # the cache notices a parameter update
+    with torch.no_grad():
+        net[0][1].bias.add_(0.5)
+        moved = net(x())
+    with torch.enable_grad():
+        want2 = net(x())
+    assert float((moved.features - want2.features.detach()).abs().max()) <= 1e-5 * max(scale, 1.0)
+    assert not torch.equal(moved.features, got.features)
