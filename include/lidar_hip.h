@@ -192,6 +192,16 @@ int lidar_spconv_implicit_gemm(const float *in_features, const int *nbr, int n_o
 int lidar_spconv_implicit_gemm_fused(const float *in_features, const int *nbr, int n_out, int K, int Cin, int Cout,
                                      const float *weight, const float *bias, const float *residual, int relu,
                                      float *out_features, void *stream);
+/* Mask-sorted execution of the same GEMM: on LiDAR occupancy a site has 3-13 of its 27 neighbours, so in table order most
+ * MFMA rows of a 32-row tile are padding.  lidar_spconv_row_masks gives each row's offset bit mask (K <= 32); the caller
+ * argsorts the masks (any device sort) and passes the order: workgroup row i computes table / output row order[i], so
+ * rows with equal masks share MFMA tiles and offsets unused by a whole workgroup are skipped entirely.  Every output
+ * still sums the same products in the same (offset) order: results are bit-identical to the table-order call. */
+int lidar_spconv_row_masks(const int *nbr, int n_out, int K, int *masks, void *stream);
+int lidar_spconv_sorted_gemm_supported(int K, int Cin, int Cout);
+int lidar_spconv_implicit_gemm_sorted(const float *in_features, const int *nbr, const int *row_mask, const int *order,
+                                      int n_out, int K, int Cin, int Cout, const float *weight, const float *bias,
+                                      const float *residual, int relu, float *out_features, void *stream);
 /* weight gradient: grad_weight (K, Cin, Cout) += sum_j in[nbr[j][k]]^T (x) grad_out[j]; zero-filled by the caller */
 int lidar_spconv_wgrad(const float *in_features, const float *grad_out, const int *nbr, int n_out, int K, int Cin, int Cout,
                        float *grad_weight, void *stream);

@@ -451,7 +451,8 @@ template <int NT, int C4>
 __global__ __launch_bounds__(256) void sc_implicit_gemm_pipe_kernel(const float *__restrict__ in, const int *__restrict__ nbr, int n_out,
                                                                     int K, int Cout, const float *__restrict__ Wt,
                                                                     const float *__restrict__ bias, const float *__restrict__ residual,
-                                                                    int relu, float *__restrict__ out) {
+                                                                    int relu, float *__restrict__ out,
+                                                                    const int *__restrict__ row_mask, const int *__restrict__ out_row) {
     constexpr int Cin = C4 * 4, Cp = Cin + 1, CW = NT * 32, CW4 = CW / 4;
     constexpr int NG = (32 * C4) / 64;                    // float4 gathers per lane per offset
     constexpr int NW = (Cin * CW4 + 255) / 256;           // float4 weight pieces per thread per offset
@@ -462,6 +463,8 @@ __global__ __launch_bounds__(256) void sc_implicit_gemm_pipe_kernel(const float 
     const int row0 = blockIdx.x * IG_ROWS + wv * 32;
     float *A = s_a + (size_t)wv * 32 * Cp;
     const int myrow = row0 + (l & 31);
+    // table row this lane-row reads: the permutation entry for mask-sorted execution (out_row), else the row itself
+    const int trow = (out_row && myrow < n_out) ? out_row[myrow] : myrow;
     const int Co4 = Cout >> 2;
     f32x16 acc[NT];
 #pragma unroll
@@ -471,9 +474,28 @@ __global__ __launch_bounds__(256) void sc_implicit_gemm_pipe_kernel(const float 
     const int ar = l & 31, ak = l >> 5;
     float4 g[NG], wr[NW];
     bool any_next;
+    // Mask-sorted tables (row_mask != NULL, K <= 32): rows arrive grouped by their neighbour-offset bit mask, so the 32 rows
+    // of a wave tile (and the 128 of the workgroup) mostly share one mask: offsets no row of the WORKGROUP uses are skipped
+    // outright (no W staging, no barriers) and a wave's MFMAs run only for offsets its own rows use.
+    __shared__ unsigned s_wmask[4];
+    unsigned wave_mask = 0xffffffffu, wg_mask = 0xffffffffu;
+    if (row_mask) {
+        unsigned m = (myrow < n_out) ? (unsigned)row_mask[trow] : 0u;
+#pragma unroll
+        for (int d = 1; d < 64; d <<= 1) m |= (unsigned)__shfl_xor((int)m, d, 64);
+        wave_mask = m;
+        if (l == 0) s_wmask[wv] = m;
+        __syncthreads();
+        wg_mask = s_wmask[0] | s_wmask[1] | s_wmask[2] | s_wmask[3];
+    }
+    auto next_k = [&](int k) {                            // next offset > k some row of the workgroup uses (K when none)
+        if (!row_mask) return k + 1;
+        const unsigned rest = (k + 1 < 32) ? (wg_mask >> (k + 1)) : 0u;
+        return rest ? k + 1 + __builtin_ctz(rest) : K;
+    };
     auto fetch = [&](int k) {
-        const int src = (myrow < n_out) ? nbr[(size_t)myrow * K + k] : -1;
-        any_next = __ballot(src >= 0) != 0ull;
+        const int src = (myrow < n_out) ? nbr[(size_t)trow * K + k] : -1;
+        any_next = row_mask ? ((wave_mask >> k) & 1u) != 0u : __ballot(src >= 0) != 0ull;
 #pragma unroll
         for (int u = 0; u < NG; ++u) {
             const int e = u * 64 + l, r = e / C4, c = e - r * C4;
@@ -488,8 +510,10 @@ __global__ __launch_bounds__(256) void sc_implicit_gemm_pipe_kernel(const float 
             if (e < Cin * CW4 && q4 < Co4) wr[q] = reinterpret_cast<const float4 *>(Wt + ((size_t)k * Cin + ci) * Cout)[q4];
         }
     };
-    fetch(0);
-    for (int k = 0; k < K; ++k) {
+    int k = next_k(-1);
+    if (k < K) fetch(k);
+    for (; k < K;) {
+        const int kn = next_k(k);
         const bool any = any_next;
         __syncthreads();                                  // LDS of the previous offset is no longer read
         // a workgroup-uniform "somebody needs W[k]" is not known per wave: every wave stores its W pieces whenever IT has work;
@@ -510,7 +534,7 @@ __global__ __launch_bounds__(256) void sc_implicit_gemm_pipe_kernel(const float 
             }
         }
         __syncthreads();
-        if (k + 1 < K) fetch(k + 1);                      // in flight while the MFMAs below run
+        if (kn < K) fetch(kn);                            // in flight while the MFMAs below run
         if (any) {
 #pragma unroll 4
             for (int c0 = 0; c0 < Cin; c0 += 2) {
@@ -522,6 +546,7 @@ __global__ __launch_bounds__(256) void sc_implicit_gemm_pipe_kernel(const float 
                 }
             }
         }
+        k = kn;
     }
 #pragma unroll
     for (int q = 0; q < NT; ++q) {
@@ -531,10 +556,11 @@ __global__ __launch_bounds__(256) void sc_implicit_gemm_pipe_kernel(const float 
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
                 const int row = row0 + (r & 3) + 8 * (r >> 2) + 4 * (l >> 5);
-                if (row < n_out) {              // fused epilogue: (+ bias) (+ residual) (ReLU)
+                if (row < n_out) {              // fused epilogue: (+ bias) (+ residual) (ReLU); sorted tables scatter rows
+                    const size_t orow = out_row ? (size_t)out_row[row] : (size_t)row;
                     float v = acc[q][r] + bv;
-                    if (residual) v += residual[(size_t)row * Cout + col];
-                    out[(size_t)row * Cout + col] = relu ? fmaxf(v, 0.f) : v;
+                    if (residual) v += residual[orow * Cout + col];
+                    out[orow * Cout + col] = relu ? fmaxf(v, 0.f) : v;
                 }
             }
         }
@@ -544,9 +570,9 @@ __global__ __launch_bounds__(256) void sc_implicit_gemm_pipe_kernel(const float 
 // indice_conv forward / dgrad (with the transposed table and W^T) — spconv.functional indice_conv (Appendix A.3) —
 // with the inference epilogue of the reference's conv/BatchNorm1d/ReLU triplets (spconv_backbone.py:20-26) and of
 // SparseBasicBlock (spconv_backbone.py:49-63): out = act(gemm + bias + residual).
-LIDAR_EXPORT int lidar_spconv_implicit_gemm_fused(const float *in_features, const int *nbr, int n_out, int K, int Cin, int Cout,
-                                                  const float *weight, const float *bias, const float *residual, int relu,
-                                                  float *out_features, void *stream) {
+static int sc_gemm_launch(const float *in_features, const int *nbr, int n_out, int K, int Cin, int Cout, const float *weight,
+                          const float *bias, const float *residual, int relu, float *out_features, const int *row_mask,
+                          const int *out_row, void *stream) {
     if (n_out < 0 || K <= 0 || Cin <= 0 || Cout <= 0 || Cin > IG_MAX_C || Cout > IG_MAX_C) return LIDAR_ERR_ARG;
     if (n_out == 0) return LIDAR_OK;
     if (!in_features || !nbr || !weight || !out_features) return LIDAR_ERR_ARG;
@@ -554,8 +580,10 @@ LIDAR_EXPORT int lidar_spconv_implicit_gemm_fused(const float *in_features, cons
     const int nt = divup(Cout, 32);
     const size_t lds = ((size_t)Cin * nt * 32 + (size_t)4 * 32 * (Cin + 1)) * sizeof(float);
     const dim3 grid(divup(n_out, IG_ROWS));
-#define IGP(NT, C4) hipLaunchKernelGGL((sc_implicit_gemm_pipe_kernel<NT, C4>), grid, dim3(256), lds, s, in_features, nbr, n_out, K, Cout, weight, bias, residual, relu, out_features)
-    if ((Cout & 3) == 0 && (Cin == 16 || Cin == 32 || Cin == 64 || Cin == 128)) {
+#define IGP(NT, C4) hipLaunchKernelGGL((sc_implicit_gemm_pipe_kernel<NT, C4>), grid, dim3(256), lds, s, in_features, nbr, n_out, K, Cout, weight, bias, residual, relu, out_features, row_mask, out_row)
+    const bool pipe = (Cout & 3) == 0 && (Cin == 16 || Cin == 32 || Cin == 64 || Cin == 128);
+    if ((row_mask || out_row) && (!pipe || K > 32 || !row_mask || !out_row)) return LIDAR_ERR_ARG;
+    if (pipe) {
         const int c4 = Cin / 4;
 #define IGP_NT(C4) switch (nt) { case 1: IGP(1, C4); break; case 2: IGP(2, C4); break; case 3: IGP(3, C4); break; default: IGP(4, C4); break; }
         if (c4 == 4) { IGP_NT(4) } else if (c4 == 8) { IGP_NT(8) } else if (c4 == 16) { IGP_NT(16) } else { IGP_NT(32) }
@@ -572,6 +600,47 @@ LIDAR_EXPORT int lidar_spconv_implicit_gemm_fused(const float *in_features, cons
     }
 #undef IG_CASE
     return lidar_check_launch("lidar_spconv_implicit_gemm");
+}
+
+LIDAR_EXPORT int lidar_spconv_implicit_gemm_fused(const float *in_features, const int *nbr, int n_out, int K, int Cin, int Cout,
+                                                  const float *weight, const float *bias, const float *residual, int relu,
+                                                  float *out_features, void *stream) {
+    return sc_gemm_launch(in_features, nbr, n_out, K, Cin, Cout, weight, bias, residual, relu, out_features, nullptr, nullptr,
+                          stream);
+}
+
+// Per-row neighbour-offset bit masks of an (n_out, K <= 32) table: bit k set when nbr[row][k] >= 0.
+__global__ void sc_row_masks_kernel(const int *__restrict__ nbr, int n_out, int K, int *__restrict__ masks) {
+    const int row = blockIdx.x * blockDim.x + threadIdx.x;
+    if (row >= n_out) return;
+    unsigned m = 0;
+    for (int k = 0; k < K; ++k) m |= (nbr[(size_t)row * K + k] >= 0) ? (1u << k) : 0u;
+    masks[row] = (int)m;
+}
+
+LIDAR_EXPORT int lidar_spconv_row_masks(const int *nbr, int n_out, int K, int *masks, void *stream) {
+    if (n_out < 0 || K <= 0 || K > 32) return LIDAR_ERR_ARG;
+    if (n_out == 0) return LIDAR_OK;
+    if (!nbr || !masks) return LIDAR_ERR_ARG;
+    hipLaunchKernelGGL(sc_row_masks_kernel, dim3(divup(n_out, 256)), dim3(256), 0, (hipStream_t)stream, nbr, n_out, K, masks);
+    return lidar_check_launch("lidar_spconv_row_masks");
+}
+
+// 1 when lidar_spconv_implicit_gemm_sorted can run this shape
+LIDAR_EXPORT int lidar_spconv_sorted_gemm_supported(int K, int Cin, int Cout) {
+    return (K > 0 && K <= 32 && (Cout & 3) == 0 && Cout > 0 && Cout <= IG_MAX_C &&
+            (Cin == 16 || Cin == 32 || Cin == 64 || Cin == 128)) ? 1 : 0;
+}
+
+// The fused GEMM with its rows visited in mask order: workgroup row i computes table / output row order[i] (row_mask is in
+// table order).  Same sums in the same order as the table-order call: bit-identical results.
+LIDAR_EXPORT int lidar_spconv_implicit_gemm_sorted(const float *in_features, const int *nbr, const int *row_mask,
+                                                   const int *out_row, int n_out, int K, int Cin, int Cout,
+                                                   const float *weight, const float *bias, const float *residual, int relu,
+                                                   float *out_features, void *stream) {
+    if (!lidar_spconv_sorted_gemm_supported(K, Cin, Cout) || (n_out > 0 && (!row_mask || !out_row))) return LIDAR_ERR_ARG;
+    return sc_gemm_launch(in_features, nbr, n_out, K, Cin, Cout, weight, bias, residual, relu, out_features, row_mask,
+                          out_row, stream);
 }
 
 LIDAR_EXPORT int lidar_spconv_implicit_gemm(const float *in_features, const int *nbr, int n_out, int K, int Cin, int Cout,

@@ -10,6 +10,28 @@ from .modules import SparseModule
 from .tensor import SparseConvTensor
 
 
+_SIDE_STREAMS = {}
+
+
+def _schedule_mask_order(datas, key, table):
+    """Inference: compute the mask order of a freshly built table on a side stream (tiny, latency-bound kernels) so it
+    overlaps the remaining rulebook builds; consumers wait on the recorded event (forward_fused)."""
+    dev = table.device
+    main = torch.cuda.current_stream(dev)
+    side = _SIDE_STREAMS.get(dev)
+    if side is None:
+        side = _SIDE_STREAMS[dev] = torch.cuda.Stream(dev)
+    side.wait_stream(main)                      # the table is produced on the main stream
+    table.record_stream(side)
+    with torch.cuda.stream(side):
+        masks, perm = ops.mask_order(table)
+    ev = torch.cuda.Event()
+    ev.record(side)
+    masks.record_stream(main)
+    perm.record_stream(main)
+    datas[key] = [masks, perm, ev]
+
+
 def _triple(v):
     return [int(v)] * 3 if isinstance(v, int) else [int(x) for x in v]
 
@@ -57,6 +79,7 @@ class SparseConvolution(SparseModule):
                          "in_spatial_shape": spatial_shape, "out_spatial_shape": spatial_shape}
                 if self.indice_key is not None:
                     indice_dict[self.indice_key] = datas
+                self._maybe_schedule_order(datas)
             return indices, spatial_shape
         out_shape = ops.get_conv_output_size(spatial_shape, self.kernel_size, self.stride, self.padding)
         if datas is None:
@@ -65,11 +88,19 @@ class SparseConvolution(SparseModule):
                      "in_spatial_shape": spatial_shape, "out_spatial_shape": out_shape}
             if self.indice_key is not None:
                 indice_dict[self.indice_key] = datas
+            self._maybe_schedule_order(datas)
         return datas["out_indices"], out_shape
+
+    def _maybe_schedule_order(self, datas):
+        """called right after this layer built a new table inside a no-grad prebuild pass"""
+        if (not torch.is_grad_enabled() and datas["nbr"].is_cuda and datas["nbr"].shape[0] > 0
+                and ops.sorted_gemm_supported(datas["nbr"].shape[1], self.in_channels, self.out_channels)):
+            _schedule_mask_order(datas, "order", datas["nbr"])
 
     def _resolve(self, input):
         """-> (indices, out_indices, out_shape, fwd_table, bwd_table, flip) for this layer on `input` (rulebook built
-        or fetched through indice_key); tables are None for a 1x1 convolution."""
+        or fetched through indice_key); tables are None for a 1x1 convolution.  self._datas = the rulebook dict used."""
+        self._datas = None
         indices = input.indices
         spatial_shape, batch_size = input.spatial_shape, input.batch_size
         if indices.dtype != torch.int32:
@@ -81,6 +112,7 @@ class SparseConvolution(SparseModule):
         if self.inverse:
             assert datas is not None and self.indice_key is not None, "inverse conv needs the rulebook of its paired conv"
             assert datas["out_indices"].shape[0] == indices.shape[0], "inverse conv input does not match the paired conv's output"
+            self._datas = datas
             return indices, datas["in_indices"], datas["in_spatial_shape"], datas["nbr_t"], datas["nbr"], False
         if self.subm:
             if datas is None:
@@ -89,6 +121,7 @@ class SparseConvolution(SparseModule):
                          "in_spatial_shape": spatial_shape, "out_spatial_shape": spatial_shape}
                 if self.indice_key is not None:
                     input.indice_dict[self.indice_key] = datas
+            self._datas = datas
             return indices, indices, spatial_shape, datas["nbr"], datas["nbr"], True
         out_shape = ops.get_conv_output_size(spatial_shape, self.kernel_size, self.stride, self.padding)
         if datas is None:
@@ -98,6 +131,7 @@ class SparseConvolution(SparseModule):
                      "in_spatial_shape": spatial_shape, "out_spatial_shape": out_shape}
             if self.indice_key is not None:
                 input.indice_dict[self.indice_key] = datas
+        self._datas = datas
         return indices, datas["out_indices"], out_shape, datas["nbr"], datas["nbr_t"], False
 
     def forward(self, input):
@@ -109,6 +143,7 @@ class SparseConvolution(SparseModule):
                 f = f + self.bias
         else:
             f = ops.indice_conv(input.features, self.weight, self.bias, fwd_table, bwd_table, flip)
+        self._datas = None
         out = SparseConvTensor(f, out_indices, out_shape, input.batch_size)
         out.indice_dict, out.grid = input.indice_dict, input.grid
         return out
@@ -147,7 +182,18 @@ class SparseConvolution(SparseModule):
             if relu:
                 f = torch.relu_(f)
         else:
-            f = ops.indice_conv_fused(feats, fwd_table, w, b, None if residual is None else residual.contiguous(), relu)
+            st, datas = None, self._datas
+            if ops.sorted_gemm_supported(w.shape[0], self.in_channels, self.out_channels):
+                key = "order_t" if self.inverse else "order"         # mask order of the table's rows, shared through indice_key
+                st = datas.get(key)
+                if st is None:
+                    st = datas[key] = list(ops.mask_order(fwd_table)) + [None]
+                if st[2] is not None:                                  # computed on the side stream: join once
+                    torch.cuda.current_stream(feats.device).wait_event(st[2])
+                    st[2] = None
+                st = (st[0], st[1])
+            f = ops.indice_conv_fused(feats, fwd_table, w, b, None if residual is None else residual.contiguous(), relu, st)
+        self._datas = None
         out = SparseConvTensor(f, out_indices, out_shape, input.batch_size)
         out.indice_dict, out.grid = input.indice_dict, input.grid
         return out

@@ -77,8 +77,24 @@ def _implicit_gemm(feats, nbr, weight_kcc, bias, n_out):
     return out
 
 
-def indice_conv_fused(feats, nbr, weight_kcc, bias, residual=None, relu=False):
-    """Inference-only: act(sum_k feats[nbr[:, k]] @ weight_kcc[k] + bias + residual) in one launch (no autograd)."""
+def sorted_gemm_supported(K, Cin, Cout):
+    return K <= 31 and bool(_lib.lib().lidar_spconv_sorted_gemm_supported(K, Cin, Cout))
+
+
+def mask_order(nbr):
+    """(n_out, K <= 31) neighbour table -> (row offset bit masks, the row order that sorts them).  Visiting rows in that
+    order puts equal masks into the same MFMA tiles, so tiles stop multiplying padding rows and whole offsets drop out per
+    workgroup (include/lidar_hip.h: lidar_spconv_implicit_gemm_sorted)."""
+    n_out, K = nbr.shape
+    masks = torch.empty(n_out, dtype=torch.int32, device=nbr.device)
+    if n_out:
+        _lib.check(_lib.lib().lidar_spconv_row_masks(_lib.ptr(nbr), n_out, K, _lib.ptr(masks), _lib.stream()), "lidar_spconv_row_masks")
+    return masks, torch.argsort(masks).int()
+
+
+def indice_conv_fused(feats, nbr, weight_kcc, bias, residual=None, relu=False, order=None):
+    """Inference-only: act(sum_k feats[nbr[:, k]] @ weight_kcc[k] + bias + residual) in one launch (no autograd).
+    order = mask_order(nbr) visits the rows in mask order (bit-identical result, far fewer padding MFMA tiles)."""
     K, Cin, Cout = weight_kcc.shape
     n_out = nbr.shape[0]
     _lib.require_cuda(feats, weight_kcc, nbr, bias, residual)
@@ -87,6 +103,13 @@ def indice_conv_fused(feats, nbr, weight_kcc, bias, residual=None, relu=False):
         return out
     if residual is not None and tuple(residual.shape) != (n_out, Cout):
         raise _lib.LidarHipError("indice_conv_fused: residual must be (n_out, Cout)")
+    if order is not None:
+        masks, perm = order
+        _lib.check(_lib.lib().lidar_spconv_implicit_gemm_sorted(_lib.ptr(feats), _lib.ptr(nbr), _lib.ptr(masks), _lib.ptr(perm),
+                                                                n_out, K, Cin, Cout, _lib.ptr(weight_kcc), _lib.ptr(bias),
+                                                                _lib.ptr(residual), int(bool(relu)), _lib.ptr(out), _lib.stream()),
+                   "lidar_spconv_implicit_gemm_sorted")
+        return out
     _lib.check(_lib.lib().lidar_spconv_implicit_gemm_fused(_lib.ptr(feats), _lib.ptr(nbr), n_out, K, Cin, Cout,
                                                            _lib.ptr(weight_kcc), _lib.ptr(bias), _lib.ptr(residual), int(bool(relu)),
                                                            _lib.ptr(out), _lib.stream()), "lidar_spconv_implicit_gemm_fused")

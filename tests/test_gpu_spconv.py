@@ -188,3 +188,39 @@ def test_inference_fused_conv_bn_relu_matches_module_sequence(dev):
         want2 = net(x())
     assert float((moved.features - want2.features.detach()).abs().max()) <= 1e-5 * max(scale, 1.0)
     assert not torch.equal(moved.features, got.features)
+
+
+@pytest.mark.parametrize("cin,cout,n_out,p_valid", [(16, 16, 1000, 0.15), (16, 32, 257, 0.4), (32, 32, 128, 1.0),
+                                                    (32, 64, 901, 0.35), (64, 64, 3000, 0.08), (64, 48, 130, 0.5),
+                                                    (128, 128, 300, 0.3), (16, 64, 1, 1.0)])
+def test_mask_sorted_gemm_is_bit_identical(dev, cin, cout, n_out, p_valid):
+    """The fused GEMM on the mask-sorted table (skips padding MFMA tiles / unused offsets) must give exactly the bits of the
+    table-order call (same products, same summation order), with bias / residual / ReLU; also checked against float64."""
+    from lidardetection_amd.spconv import ops
+    K, n_in = 27, 777
+    g = torch.Generator(device="cpu").manual_seed(cin * 131 + cout + n_out)
+    nbr = torch.randint(0, n_in, (n_out, K), generator=g, dtype=torch.int32)
+    nbr[torch.rand(n_out, K, generator=g) >= p_valid] = -1
+    nbr[n_out // 2] = -1                                                  # a row without any neighbour
+    feats = torch.randn(n_in, cin, generator=g)
+    w = torch.randn(K, cin, cout, generator=g) * 0.2
+    b = torch.randn(cout, generator=g)
+    res = torch.randn(n_out, cout, generator=g)
+    ref = torch.zeros(n_out, cout, dtype=torch.float64)
+    for k in range(K):
+        m = nbr[:, k] >= 0
+        ref[m] += feats[nbr[m, k].long()].double() @ w[k].double()
+    ref = torch.relu(ref + b.double() + res.double())
+    nbr_d, f_d, w_d, b_d, r_d = (x.to(dev) for x in (nbr, feats, w, b, res))
+    assert ops.sorted_gemm_supported(K, cin, cout)
+    st = ops.mask_order(nbr_d)
+    masks, perm = (x.cpu() for x in st)
+    assert torch.equal(torch.sort(perm.long())[0], torch.arange(n_out))
+    assert torch.equal(masks.long(), ((nbr >= 0).long() << torch.arange(K)).sum(1))
+    ms = masks[perm.long()]
+    assert bool((ms[1:] >= ms[:-1]).all())
+    got = ops.indice_conv_fused(f_d, nbr_d, w_d, b_d, r_d, True, st)
+    base = ops.indice_conv_fused(f_d, nbr_d, w_d, b_d, r_d, True, None)
+    assert torch.equal(got, base)
+    np.testing.assert_allclose(got.cpu().double().numpy(), ref.numpy(), rtol=0, atol=1e-4)
+    assert not ops.sorted_gemm_supported(125, 16, 16) and not ops.sorted_gemm_supported(K, 4, 16)

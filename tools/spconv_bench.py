@@ -49,7 +49,13 @@ with torch.no_grad():
                 e1.record(); torch.cuda.synchronize()
                 ms = e0.elapsed_time(e1) / 10
                 tot_flops += fl; tot_t += ms
-                print(f"  {c.indice_key:13s} {c.in_channels:3d}->{c.out_channels:3d} rows {nbr.shape[0]:7d} pairs {nk:9d} {ms*1e3:8.1f} us {fl/ms/1e9:7.2f} TFLOP/s")
+                def eff(T):   # useful fraction of MFMA rows if valid rows were packed per (T-row tile, offset)
+                    n = nbr.shape[0]; pad = (-n) % T
+                    v = torch.nn.functional.pad((nbr >= 0), (0, 0, 0, pad)).view(-1, T, nbr.shape[1]).sum(1)
+                    return nk / float((((v + 31) // 32) * 32).sum())
+                print(f"  {c.indice_key:13s} {c.in_channels:3d}->{c.out_channels:3d} rows {nbr.shape[0]:7d} pairs {nk:9d} "
+                      f"({nk / nbr.shape[0]:5.2f}/row) {ms*1e3:8.1f} us {fl/ms/1e9:7.2f} TFLOP/s | MFMA row efficiency: "
+                      f"now(32-row skip) {eff(32):.2f}, packed/128 {eff(128):.2f}, packed/256 {eff(256):.2f}")
                 x = y
             else:
                 x.features = c(x.features)
