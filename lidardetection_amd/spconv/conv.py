@@ -92,8 +92,8 @@ class SparseConvolution(SparseModule):
         return datas["out_indices"], out_shape
 
     def _maybe_schedule_order(self, datas):
-        """called right after this layer built a new table inside a no-grad prebuild pass"""
-        if (not torch.is_grad_enabled() and datas["nbr"].is_cuda and datas["nbr"].shape[0] > 0
+        """called right after this layer built a new table inside a prebuild pass"""
+        if (datas["nbr"].is_cuda and datas["nbr"].shape[0] > 0
                 and ops.sorted_gemm_supported(datas["nbr"].shape[1], self.in_channels, self.out_channels)):
             _schedule_mask_order(datas, "order", datas["nbr"])
 
@@ -142,7 +142,11 @@ class SparseConvolution(SparseModule):
             if self.bias is not None:
                 f = f + self.bias
         else:
-            f = ops.indice_conv(input.features, self.weight, self.bias, fwd_table, bwd_table, flip)
+            # mask orders are cached per table in the rulebook dict: "order" belongs to datas["nbr"], "order_t" to datas["nbr_t"]
+            datas = self._datas
+            keys = ("order_t", "order") if self.inverse else (("order", "order") if self.subm else ("order", "order_t"))
+            orders = (datas, *keys) if (input.features.is_cuda and fwd_table.shape[1] <= 31) else None
+            f = ops.indice_conv(input.features, self.weight, self.bias, fwd_table, bwd_table, flip, orders)
         self._datas = None
         out = SparseConvTensor(f, out_indices, out_shape, input.batch_size)
         out.indice_dict, out.grid = input.indice_dict, input.grid
@@ -184,14 +188,8 @@ class SparseConvolution(SparseModule):
         else:
             st, datas = None, self._datas
             if ops.sorted_gemm_supported(w.shape[0], self.in_channels, self.out_channels):
-                key = "order_t" if self.inverse else "order"         # mask order of the table's rows, shared through indice_key
-                st = datas.get(key)
-                if st is None:
-                    st = datas[key] = list(ops.mask_order(fwd_table)) + [None]
-                if st[2] is not None:                                  # computed on the side stream: join once
-                    torch.cuda.current_stream(feats.device).wait_event(st[2])
-                    st[2] = None
-                st = (st[0], st[1])
+                # mask order of the table's rows, shared through indice_key
+                st = ops.cached_mask_order(datas, "order_t" if self.inverse else "order", fwd_table)
             f = ops.indice_conv_fused(feats, fwd_table, w, b, None if residual is None else residual.contiguous(), relu, st)
         self._datas = None
         out = SparseConvTensor(f, out_indices, out_shape, input.batch_size)

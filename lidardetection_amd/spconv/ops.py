@@ -66,11 +66,28 @@ def conv_rulebook(indices, batch_size, spatial_shape, ksize, stride, padding):
     return out_idx[:n_out].clone(), nbr, nbr_t
 
 
-def _implicit_gemm(feats, nbr, weight_kcc, bias, n_out):
-    """out (n_out, Cout) = sum_k feats[nbr[:, k]] @ weight_kcc[k] (+ bias)."""
+def cached_mask_order(datas, key, table):
+    """mask order of `table`, kept in the rulebook dict under `key` ([masks, order, event-or-None]); joins the side stream
+    once when the order was scheduled there (conv._schedule_mask_order)."""
+    st = datas.get(key)
+    if st is None:
+        st = datas[key] = list(mask_order(table)) + [None]
+    if st[2] is not None:
+        torch.cuda.current_stream(table.device).wait_event(st[2])
+        st[2] = None
+    return st[0], st[1]
+
+
+def _implicit_gemm(feats, nbr, weight_kcc, bias, n_out, order=None):
+    """out (n_out, Cout) = sum_k feats[nbr[:, k]] @ weight_kcc[k] (+ bias); `order` = mask_order(nbr) (same bits, faster)."""
     K, Cin, Cout = weight_kcc.shape
     out = torch.empty((n_out, Cout), dtype=torch.float32, device=feats.device)
     if n_out == 0:
+        return out
+    if order is not None:
+        _lib.check(_lib.lib().lidar_spconv_implicit_gemm_sorted(_lib.ptr(feats), _lib.ptr(nbr), _lib.ptr(order[0]), _lib.ptr(order[1]),
+                                                                n_out, K, Cin, Cout, _lib.ptr(weight_kcc), _lib.ptr(bias), None, 0,
+                                                                _lib.ptr(out), _lib.stream()), "lidar_spconv_implicit_gemm_sorted")
         return out
     _lib.check(_lib.lib().lidar_spconv_implicit_gemm(_lib.ptr(feats), _lib.ptr(nbr), n_out, K, Cin, Cout, _lib.ptr(weight_kcc),
                                                      _lib.ptr(bias), _lib.ptr(out), _lib.stream()), "lidar_spconv_implicit_gemm")
@@ -123,14 +140,19 @@ class SparseConvFunction(Function):
     flip_bwd: submanifold tables are symmetric (bwd_table is fwd_table itself, read with the kernel flipped)."""
 
     @staticmethod
-    def forward(ctx, features, weight, bias, fwd_table, bwd_table, flip_bwd):
+    def forward(ctx, features, weight, bias, fwd_table, bwd_table, flip_bwd, orders=None):
+        """orders = (rulebook dict, key of the forward table's mask order, key of the backward table's) or None: the GEMMs
+        then visit rows in mask order (bit-identical results, see lidar_spconv_implicit_gemm_sorted)."""
         feats = features.contiguous()
         Cin, Cout = weight.shape[-2], weight.shape[-1]
         w = weight.reshape(-1, Cin, Cout).contiguous()
         _lib.require_cuda(feats, w, fwd_table)
-        out = _implicit_gemm(feats, fwd_table, w, bias.contiguous() if bias is not None else None, fwd_table.shape[0])
+        order = None
+        if orders is not None and fwd_table.shape[0] > 0 and sorted_gemm_supported(w.shape[0], Cin, Cout):
+            order = cached_mask_order(orders[0], orders[1], fwd_table)
+        out = _implicit_gemm(feats, fwd_table, w, bias.contiguous() if bias is not None else None, fwd_table.shape[0], order)
         ctx.save_for_backward(feats, w, fwd_table, bwd_table)
-        ctx.flip_bwd, ctx.has_bias, ctx.wshape = flip_bwd, bias is not None, weight.shape
+        ctx.flip_bwd, ctx.has_bias, ctx.wshape, ctx.orders = flip_bwd, bias is not None, weight.shape, orders
         return out
 
     @staticmethod
@@ -141,7 +163,10 @@ class SparseConvFunction(Function):
         grad_feats = grad_w = grad_b = None
         if ctx.needs_input_grad[0]:
             wt = w.flip(0) if ctx.flip_bwd else w
-            grad_feats = _implicit_gemm(g, bwd_table, wt.transpose(1, 2).contiguous(), None, feats.shape[0])
+            order = None
+            if ctx.orders is not None and bwd_table.shape[0] > 0 and sorted_gemm_supported(K, Cout, Cin):
+                order = cached_mask_order(ctx.orders[0], ctx.orders[2], bwd_table)
+            grad_feats = _implicit_gemm(g, bwd_table, wt.transpose(1, 2).contiguous(), None, feats.shape[0], order)
         if ctx.needs_input_grad[1]:
             grad_w = torch.zeros_like(w)
             if fwd_table.shape[0] > 0:
@@ -150,7 +175,7 @@ class SparseConvFunction(Function):
             grad_w = grad_w.view(ctx.wshape)
         if ctx.has_bias and ctx.needs_input_grad[2]:
             grad_b = g.sum(0)
-        return grad_feats, grad_w, grad_b, None, None, None
+        return grad_feats, grad_w, grad_b, None, None, None, None
 
 
 indice_conv = SparseConvFunction.apply
