@@ -107,8 +107,7 @@ def main():
             vox = model.voxelize(pts, offs)
             ev[k][1].record()
             canvas = model.vfe_scatter(vox)
-            cls, box, dirs = model.backbone_head(canvas)
-            out = model.post_process(cls, box, dirs)
+            out = model.post_process(*model.backbone_head(canvas))
         barrier()
         dt = time.perf_counter() - t0
     dt = dist_utils.max_over_ranks(dt, dist, device)

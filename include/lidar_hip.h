@@ -222,6 +222,21 @@ int lidar_bias_act_nhwc(const float *in, const float *bias, long long n_pix, int
 int lidar_bias_act_upsample_nhwc(const float *in, const float *bias, int batch, int h, int w, int s, int C, int relu,
                                  float *out, int out_C, int out_off, void *stream);
 
+/* ------------------------------------------------------------------ anchor-head post-processing feeding NMS (8f rank 1)
+ * head: (n_loc = B*H*W, row_stride) rows of the merged head output [cls | box | dir] as the 1x1 heads emit it
+ * (pcdet/models/dense_heads/anchor_head_single.py:45-55).  Anchor index = loc * anchors_per_loc + a, class logit
+ * channel = cls_off + a * num_class + c (the view(batch, num_anchors, -1) of anchor_head_template.py:247-250).
+ * lidar_anchor_scores: scores[i] = max_c sigmoid(logit) if >= score_thresh else -1, labels[i] = argmax_c
+ *   (detector3d_template.py:205-230 + model_nms_utils.py:6-10).
+ * lidar_decode_topk: boxes (batch, k, 7) = ResidualCoder.decode_torch (box_coder_utils.py:45-77) + direction-bin
+ *   correction (anchor_head_template.py:253-266) of the anchors picked by top_idx (batch, k) int64 (per-frame anchor ids);
+ *   anchors (n_anchor_per_frame, 7). */
+int lidar_anchor_scores(const float *head, long long n_loc, int row_stride, int cls_off, int anchors_per_loc, int num_class,
+                        float score_thresh, float *scores, unsigned char *labels, void *stream);
+int lidar_decode_topk(const float *head, int batch, long long locs_per_frame, int row_stride, int box_off, int dir_off,
+                      int anchors_per_loc, int num_dir_bins, const long long *top_idx, int k, const float *anchors,
+                      float dir_offset, float dir_limit_offset, float period, float *boxes, void *stream);
+
 /* ------------------------------------------------------------------ CPU entry points (HOST pointers, no GPU touched)
  * Called by the reference from DataLoader workers (augmentation / database creation). */
 /* boxes_iou_bev_cpu (pcdet/ops/iou3d_nms/src/iou3d_cpu.cpp:232-252): out (n_a, n_b) rotated BEV IoU */

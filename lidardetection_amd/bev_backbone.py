@@ -129,9 +129,13 @@ class FoldedBEVBackbone:
             off += ub.numel()
         return cat
 
-    def __call__(self, canvas):
-        """-> per-head maps in (B, H, W, C_head) layout (views of one merged head output)."""
+    def merged(self, canvas):
+        """-> the merged head output (B, H, W, sum C_head), channels [cls | box | dir] as the heads were given."""
         cat = self.features(canvas)
         B, C, H, W = cat.shape
         out = torch.addmm(self.head_b, cat.permute(0, 2, 3, 1).reshape(B * H * W, C), self.head_wt)   # 1x1 heads = one GEMM
-        return torch.split(out.view(B, H, W, -1), self.head_split, dim=-1)
+        return out.view(B, H, W, -1)
+
+    def __call__(self, canvas):
+        """-> per-head maps in (B, H, W, C_head) layout (views of the merged head output)."""
+        return torch.split(self.merged(canvas), self.head_split, dim=-1)

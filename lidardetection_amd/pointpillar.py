@@ -21,7 +21,7 @@ import numpy as np
 import torch
 import torch.nn as nn
 
-from . import pillar_ops, synth
+from . import anchor_post, pillar_ops, synth
 from .bev_backbone import FoldedBEVBackbone
 from .ext import iou3d_nms_cuda
 from .voxelizer import BatchVoxelizer, grid_size_of
@@ -137,10 +137,14 @@ class PointPillarKITTI(nn.Module):
         if self.fold_bn:
             if self._bev is None:
                 self._bev = FoldedBEVBackbone(self.blocks, self.deblocks, [self.conv_cls, self.conv_box, self.conv_dir_cls])
-            cls, box, dirs = self._bev(canvas)
-            return (cls.reshape(self.B, -1, self.num_class), box.reshape(self.B, -1, 7),
-                    dirs.reshape(self.B, -1, self.num_dir_bins))
+            return (self._bev.merged(canvas),)          # (B, H, W, 18 + 42 + 12): consumed in place by post_process
         return self.backbone_head_stock(canvas)
+
+    def split_heads(self, head):
+        """merged head (B, H, W, C) -> cls (B, N, 3), box (B, N, 7), dir (B, N, 2) as the reference's view() calls give"""
+        a = self.num_anchor_per_loc
+        cls, box, dirs = torch.split(head, [a * self.num_class, a * 7, a * self.num_dir_bins], dim=-1)
+        return (cls.reshape(self.B, -1, self.num_class), box.reshape(self.B, -1, 7), dirs.reshape(self.B, -1, self.num_dir_bins))
 
     def backbone_head_stock(self, canvas):
         ups, x = [], canvas
@@ -165,8 +169,25 @@ class PointPillarKITTI(nn.Module):
         boxes[..., 6] = rot + self.dir_offset + period * dir_labels.to(boxes.dtype)
         return boxes
 
-    def post_process(self, cls, box, dirs):
-        """-> boxes (B, post, 7), scores (B, post), labels (B, post), counts (B); all on the device."""
+    def post_process(self, *heads):
+        """-> boxes (B, post, 7), scores (B, post), labels (B, post), counts (B); all on the device.
+        heads = (merged head,) from the folded backbone (HIP score / decode kernels) or (cls, box, dirs) (torch ops)."""
+        if len(heads) == 1:
+            return self.post_process_fused(heads[0])
+        return self.post_process_torch(*heads)
+
+    def post_process_fused(self, head):
+        a = self.num_anchor_per_loc
+        masked, labels_all = anchor_post.anchor_scores(head, a, self.num_class, self.score_thresh, cls_off=0)
+        k = min(self.nms_pre, masked.shape[1])
+        top_scores, top_idx = torch.topk(masked, k, dim=1)            # sorted descending == nms_gpu's sort
+        counts = (top_scores >= self.score_thresh).sum(dim=1).to(torch.int32)
+        boxes = anchor_post.decode_topk(head, top_idx, self.anchors, a, box_off=a * self.num_class,
+                                        dir_off=a * (self.num_class + 7), num_dir_bins=self.num_dir_bins,
+                                        dir_offset=self.dir_offset, dir_limit_offset=self.dir_limit_offset)
+        return self._nms_and_gather(boxes, top_scores, top_idx, labels_all, counts, k)
+
+    def post_process_torch(self, cls, box, dirs):
         scores_all, labels_all = torch.sigmoid(cls).max(dim=-1)
         masked = torch.where(scores_all >= self.score_thresh, scores_all, scores_all.new_full((), -1.0))
         k = min(self.nms_pre, masked.shape[1])
@@ -175,6 +196,9 @@ class PointPillarKITTI(nn.Module):
         gi = top_idx.unsqueeze(-1)
         boxes = self.decode(torch.gather(box, 1, gi.expand(-1, -1, 7)), self.anchors[top_idx],
                             torch.gather(dirs, 1, gi.expand(-1, -1, self.num_dir_bins))).contiguous()
+        return self._nms_and_gather(boxes, top_scores, top_idx, labels_all, counts, k)
+
+    def _nms_and_gather(self, boxes, top_scores, top_idx, labels_all, counts, k):
         keep, num = iou3d_nms_cuda.nms_batch(boxes, counts, self.nms_thresh)
         post = min(self.nms_post, k)
         sel = keep[:, :post].clamp_(0, k - 1)
@@ -183,12 +207,11 @@ class PointPillarKITTI(nn.Module):
         sel = torch.where(valid, sel, torch.zeros_like(sel))
         out_boxes = torch.gather(boxes, 1, sel.unsqueeze(-1).expand(-1, -1, 7))
         out_scores = torch.gather(top_scores, 1, sel)
-        out_labels = torch.gather(labels_all, 1, torch.gather(top_idx, 1, sel)) + 1
+        out_labels = torch.gather(labels_all, 1, torch.gather(top_idx, 1, sel)).long() + 1
         return out_boxes, out_scores, out_labels, num
 
     @torch.no_grad()
     def forward(self, points, point_offsets):
         vox = self.voxelize(points, point_offsets)
         canvas = self.vfe_scatter(vox)
-        cls, box, dirs = self.backbone_head(canvas)
-        return self.post_process(cls, box, dirs)
+        return self.post_process(*self.backbone_head(canvas))

@@ -234,7 +234,7 @@ def test_folded_bev_backbone_matches_stock_modules(dev):
     canvas[:, :, ::3] = 0
     canvas = canvas.contiguous(memory_format=torch.channels_last)
     with torch.no_grad():
-        got = m.backbone_head(canvas)
+        got = m.split_heads(m.backbone_head(canvas)[0])
         want = m.backbone_head_stock(canvas)
     for a, b, name in zip(got, want, ("cls", "box", "dir")):
         assert a.shape == b.shape, name
@@ -257,3 +257,36 @@ def test_deblock_as_gemm_with_pixel_shuffle_epilogue(dev, s):
     bias_act_upsample_(y, b, B, h, w, s, out, 8)
     np.testing.assert_allclose(out[:, 8:24].cpu().numpy(), want.cpu().numpy(), rtol=0, atol=1e-5)
     assert torch.all(out[:, :8] == -3.0) and torch.all(out[:, 24:] == -3.0)
+
+
+def test_fused_anchor_post_processing_matches_torch_ops(dev):
+    """HIP score / top-k decode kernels on the merged head output vs the reference's op sequence in torch (sigmoid, max,
+    threshold mask, topk, ResidualCoder.decode_torch, direction bins): scores, labels and boxes bit-exact, NMS output equal."""
+    from lidardetection_amd import anchor_post
+    from lidardetection_amd.pointpillar import PointPillarKITTI
+    m = PointPillarKITTI(batch_size=2, device=dev).randomize_for_bench(5)
+    g = torch.Generator(device="cpu").manual_seed(17)
+    H, W, a = m.ny // 2, m.nx // 2, m.num_anchor_per_loc
+    head = torch.randn(2, H, W, a * (m.num_class + 7 + m.num_dir_bins), generator=g)
+    head[..., :a * m.num_class] *= 3.0                                   # spread the class logits across the threshold
+    head[..., a * m.num_class:a * (m.num_class + 7)] *= 0.3
+    head = head.to(dev)
+    cls, box, dirs = m.split_heads(head)
+    with torch.no_grad():
+        scores_all, labels_all = torch.sigmoid(cls).max(dim=-1)
+        want_masked = torch.where(scores_all >= m.score_thresh, scores_all, scores_all.new_full((), -1.0))
+        got_masked, got_labels = anchor_post.anchor_scores(head, a, m.num_class, m.score_thresh)
+        assert torch.equal(got_masked, want_masked)
+        assert torch.equal(got_labels.long(), labels_all)
+        k = 4096
+        top_scores, top_idx = torch.topk(want_masked, k, dim=1)
+        gi = top_idx.unsqueeze(-1)
+        want_boxes = m.decode(torch.gather(box, 1, gi.expand(-1, -1, 7)), m.anchors[top_idx],
+                              torch.gather(dirs, 1, gi.expand(-1, -1, m.num_dir_bins)))
+        got_boxes = anchor_post.decode_topk(head, top_idx, m.anchors, a, a * m.num_class, a * (m.num_class + 7),
+                                            m.num_dir_bins, m.dir_offset, m.dir_limit_offset)
+        assert torch.equal(got_boxes, want_boxes)
+        fused = m.post_process(head)
+        plain = m.post_process(cls, box, dirs)
+    for x, y in zip(fused, plain):
+        assert torch.equal(x, y)

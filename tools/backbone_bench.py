@@ -25,7 +25,7 @@ print("folded + HIP epilogue          %.2f ms" % run(lambda: m.backbone_head(x))
 bev = m._bev
 print("  features only                %.2f ms" % run(lambda: bev.features(x)), flush=True)
 with torch.no_grad():
-    a, b = m.backbone_head(x), m.backbone_head_stock(x)
+    a, b = m.split_heads(m.backbone_head(x)[0]), m.backbone_head_stock(x)
 print("max abs diff cls %.2e box %.2e dir %.2e" % tuple((p - q).abs().max().item() for p, q in zip(a, b)))
 # probe: MIOpen fusion plan conv+bias+relu through torch
 try:
