@@ -43,83 +43,109 @@ __device__ __forceinline__ void pn_batch_of(const int *__restrict__ cnt, int B, 
 // ------------------------------------------------------------------ ball query
 // STACK: ball_query_kernel_stack (pointnet2_stack/src/ball_query_gpu.cu:16-66), -1 sentinel for empty balls.
 // !STACK: ball_query_kernel_fast (pointnet2_batch/src/ball_query_gpu.cu:15-51), dense (b, m, .) layout.
+// The reference walks the candidates of one query serially in one thread.  Here a WAVE owns a query: its 64 lanes test 64
+// consecutive candidates at a time (LDS tile, structure-of-arrays), a ballot + prefix count appends the hits in candidate
+// order, so the result is the reference's "first nsample in index order" exactly, with 64x the parallelism per query
+// (PV-RCNN has only 2 048 keypoints per frame: one thread per query leaves the GPU 1 % occupied).
+#define BQ_QPW 4                    // queries per wave, processed one after the other against each staged tile (2/4/8 measured: 4 best)
+#define BQ_QPB (4 * BQ_QPW)         // queries per 256-thread workgroup
 template <bool STACK>
 __global__ __launch_bounds__(PN_TPB) void ball_query_kernel(int B, int M, int N, float radius, int nsample,
                                                             const float *__restrict__ new_xyz, const int *__restrict__ new_cnt,
                                                             const float *__restrict__ xyz, const int *__restrict__ xyz_cnt,
                                                             int *__restrict__ idx) {
-    __shared__ float s_pts[PN_TILE * 3];
-    __shared__ int s_range[2];
-    const int t = threadIdx.x;
-    int q, bs = 0, start = 0, n = N;
-    bool valid;
-    if (STACK) {
-        q = blockIdx.x * PN_TPB + t;
-        valid = q < M;
-        if (valid) pn_batch_of(new_cnt, B, q, xyz_cnt, bs, start, n);
-    } else {
-        bs = blockIdx.y;
-        q = blockIdx.x * PN_TPB + t;
-        valid = q < M;
-        start = bs * N;
-        q += bs * M;
-    }
-    if (STACK) {  // batches covered by this block's queries (usually one)
-        if (t == 0) {
-            int b0, s0, n0, b1, s1, n1;
-            const int qa = blockIdx.x * PN_TPB, qb = min(qa + PN_TPB, M) - 1;
-            pn_batch_of(new_cnt, B, qa, xyz_cnt, b0, s0, n0);
-            pn_batch_of(new_cnt, B, qb, xyz_cnt, b1, s1, n1);
-            s_range[0] = b0;
-            s_range[1] = b1;
+    __shared__ float s_x[PN_TILE], s_y[PN_TILE], s_z[PN_TILE];
+    const int t = threadIdx.x, l = t & 63;
+    const int wv = __builtin_amdgcn_readfirstlane(t >> 6);
+    const int q0 = blockIdx.x * BQ_QPB;                       // first query (within the batch element for !STACK) of this block
+    const size_t qbase = STACK ? 0 : (size_t)blockIdx.y * M;  // row offset of the batch element in new_xyz / idx
+    // per-query state of this wave (wave-uniform)
+    int qb[BQ_QPW], cnt[BQ_QPW], first[BQ_QPW];
+    float qx[BQ_QPW], qy[BQ_QPW], qz[BQ_QPW];
+    int b_lo = 0x7fffffff, b_hi = -1;
+#pragma unroll
+    for (int i = 0; i < BQ_QPW; ++i) {
+        const int q = q0 + wv * BQ_QPW + i;
+        cnt[i] = 0; first[i] = 0; qb[i] = -1;
+        qx[i] = qy[i] = qz[i] = 0.f;
+        if (q < M) {
+            if (STACK) {
+                int s0, n0;
+                pn_batch_of(new_cnt, B, q, xyz_cnt, qb[i], s0, n0);
+            } else {
+                qb[i] = blockIdx.y;
+            }
+            qx[i] = new_xyz[(qbase + q) * 3 + 0];
+            qy[i] = new_xyz[(qbase + q) * 3 + 1];
+            qz[i] = new_xyz[(qbase + q) * 3 + 2];
         }
-        __syncthreads();
     }
-    const int b_lo = STACK ? s_range[0] : bs, b_hi = STACK ? s_range[1] : bs;
+    {   // batch elements covered by the block's queries (block-uniform; usually one)
+        const int qa = q0, qe = min(q0 + BQ_QPB, M) - 1;
+        if (STACK) {
+            int s0, n0;
+            pn_batch_of(new_cnt, B, qa, xyz_cnt, b_lo, s0, n0);
+            pn_batch_of(new_cnt, B, qe, xyz_cnt, b_hi, s0, n0);
+        } else {
+            b_lo = b_hi = blockIdx.y;
+        }
+    }
     const float r2 = radius * radius;
-    float qx = 0.f, qy = 0.f, qz = 0.f;
-    if (valid) {
-        qx = new_xyz[(size_t)q * 3 + 0];
-        qy = new_xyz[(size_t)q * 3 + 1];
-        qz = new_xyz[(size_t)q * 3 + 2];
-    }
-    int *o = idx + (size_t)q * nsample;
-    int cnt = 0;
-    bool done = !valid;
     for (int bb = b_lo; bb <= b_hi; ++bb) {
-        int bstart = start, bn = n;   // dense layout: block-uniform already
-        if (STACK) {                  // stacked layout: derive the candidate range from bb (block-uniform bounds)
+        int bstart, bn;
+        if (STACK) {
             bstart = 0;
             for (int k = 0; k < bb; ++k) bstart += xyz_cnt[k];
             bn = xyz_cnt[bb];
+        } else {
+            bstart = bb * N;
+            bn = N;
         }
-        const bool mine = valid && (bs == bb);
         for (int t0 = 0; t0 < bn; t0 += PN_TILE) {
             const int tn = min(PN_TILE, bn - t0);
+            bool wave_busy = false;
+#pragma unroll
+            for (int i = 0; i < BQ_QPW; ++i) wave_busy = wave_busy || (qb[i] == bb && cnt[i] < nsample);
+            if (__syncthreads_or(wave_busy) == 0) break;      // every query of the block that uses this batch element is full
+            for (int k = t; k < tn * 3; k += PN_TPB) {
+                const float v = xyz[((size_t)bstart + t0) * 3 + k];
+                const int p = k / 3, c = k - p * 3;
+                (c == 0 ? s_x : (c == 1 ? s_y : s_z))[p] = v;
+            }
             __syncthreads();
-            for (int k = t; k < tn * 3; k += PN_TPB) s_pts[k] = xyz[((size_t)bstart + t0) * 3 + k];
-            __syncthreads();
-            if (mine && !done) {
-                for (int k = 0; k < tn; ++k) {
-                    const float d2 = pn_dist2(qx, qy, qz, s_pts[3 * k], s_pts[3 * k + 1], s_pts[3 * k + 2]);
-                    if (d2 < r2) {
-                        const int gi = t0 + k;
-                        if (cnt == 0)
-                            for (int l = 0; l < nsample; ++l) o[l] = gi;
-                        o[cnt] = gi;
-                        if (++cnt >= nsample) {
-                            done = true;
-                            break;
-                        }
+#pragma unroll
+            for (int i = 0; i < BQ_QPW; ++i) {
+                if (qb[i] != bb || cnt[i] >= nsample) continue;               // wave-uniform
+                int *o = idx + (qbase + q0 + wv * BQ_QPW + i) * (size_t)nsample;
+                for (int k0 = 0; k0 < tn; k0 += 64) {
+                    const int k = k0 + l;
+                    const int kc = min(k, tn - 1);
+                    const float d2 = pn_dist2(qx[i], qy[i], qz[i], s_x[kc], s_y[kc], s_z[kc]);
+                    const bool hit = (k < tn) && (d2 < r2);
+                    const unsigned long long bal = __ballot(hit);
+                    if (bal) {
+                        if (cnt[i] == 0) first[i] = t0 + k0 + __builtin_ctzll(bal);
+                        const int pos = cnt[i] + __popcll(bal & lanemask_lt());
+                        if (hit && pos < nsample) o[pos] = t0 + k;
+                        cnt[i] += __popcll(bal);
+                        if (cnt[i] >= nsample) break;
                     }
                 }
             }
-            if (__syncthreads_and(done || !mine || !valid) && (b_lo == b_hi)) {
-                t0 = bn;  // every query of the block is finished
-            }
         }
     }
-    if (STACK && valid && cnt == 0) o[0] = -1;
+    // the reference pre-fills all nsample slots with the first hit: slots past the last hit keep it
+#pragma unroll
+    for (int i = 0; i < BQ_QPW; ++i) {
+        const int q = q0 + wv * BQ_QPW + i;
+        if (q >= M) continue;
+        int *o = idx + (qbase + q) * (size_t)nsample;
+        if (cnt[i] == 0) {
+            if (STACK && l == 0) o[0] = -1;
+        } else {
+            for (int p = cnt[i] + l; p < nsample; p += 64) o[p] = first[i];
+        }
+    }
 }
 
 LIDAR_EXPORT int lidar_ball_query_stack(int B, int M, float radius, int nsample, const float *new_xyz,
@@ -128,7 +154,7 @@ LIDAR_EXPORT int lidar_ball_query_stack(int B, int M, float radius, int nsample,
     if (B <= 0 || M < 0 || nsample <= 0) return LIDAR_ERR_ARG;
     if (M == 0) return LIDAR_OK;
     if (!new_xyz || !new_xyz_batch_cnt || !xyz || !xyz_batch_cnt || !idx) return LIDAR_ERR_ARG;
-    hipLaunchKernelGGL(ball_query_kernel<true>, dim3(divup(M, PN_TPB)), dim3(PN_TPB), 0, (hipStream_t)stream, B, M, 0,
+    hipLaunchKernelGGL(ball_query_kernel<true>, dim3(divup(M, BQ_QPB)), dim3(PN_TPB), 0, (hipStream_t)stream, B, M, 0,
                        radius, nsample, new_xyz, new_xyz_batch_cnt, xyz, xyz_batch_cnt, idx);
     return lidar_check_launch("lidar_ball_query_stack");
 }
@@ -138,7 +164,7 @@ LIDAR_EXPORT int lidar_ball_query_batch(int b, int n, int m, float radius, int n
     if (b <= 0 || n < 0 || m < 0 || nsample <= 0) return LIDAR_ERR_ARG;
     if (m == 0) return LIDAR_OK;
     if (!new_xyz || !xyz || !idx) return LIDAR_ERR_ARG;
-    hipLaunchKernelGGL(ball_query_kernel<false>, dim3(divup(m, PN_TPB), b), dim3(PN_TPB), 0, (hipStream_t)stream, b, m, n,
+    hipLaunchKernelGGL(ball_query_kernel<false>, dim3(divup(m, BQ_QPB), b), dim3(PN_TPB), 0, (hipStream_t)stream, b, m, n,
                        radius, nsample, new_xyz, (const int *)nullptr, xyz, (const int *)nullptr, idx);
     return lidar_check_launch("lidar_ball_query_batch");
 }

@@ -610,12 +610,22 @@ LIDAR_EXPORT int lidar_spconv_implicit_gemm_fused(const float *in_features, cons
 }
 
 // Per-row neighbour-offset bit masks of an (n_out, K <= 32) table: bit k set when nbr[row][k] >= 0.
-__global__ void sc_row_masks_kernel(const int *__restrict__ nbr, int n_out, int K, int *__restrict__ masks) {
-    const int row = blockIdx.x * blockDim.x + threadIdx.x;
-    if (row >= n_out) return;
-    unsigned m = 0;
-    for (int k = 0; k < K; ++k) m |= (nbr[(size_t)row * K + k] >= 0) ? (1u << k) : 0u;
-    masks[row] = (int)m;
+__global__ __launch_bounds__(256) void sc_row_masks_kernel(const int *__restrict__ nbr, int n_out, int K, int *__restrict__ masks) {
+    // a block owns 256 consecutive rows = one contiguous run of 256*K table entries, read coalesced; bits meet in LDS
+    __shared__ unsigned s_mask[256];
+    const int t = threadIdx.x;
+    const long long row0 = (long long)blockIdx.x * 256;
+    const int rows = (int)min((long long)256, (long long)n_out - row0);
+    s_mask[t] = 0u;
+    __syncthreads();
+    const int *base = nbr + row0 * K;
+    const int total = rows * K;
+    for (int i = t; i < total; i += 256) {
+        const int r = i / K, k = i - r * K;
+        if (base[i] >= 0) atomicOr(&s_mask[r], 1u << k);
+    }
+    __syncthreads();
+    if (t < rows) masks[row0 + t] = (int)s_mask[t];
 }
 
 LIDAR_EXPORT int lidar_spconv_row_masks(const int *nbr, int n_out, int K, int *masks, void *stream) {

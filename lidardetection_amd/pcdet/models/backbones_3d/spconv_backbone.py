@@ -65,9 +65,8 @@ class _VoxelBackBoneBase(nn.Module):
         sp = spconv.SparseConvTensor(features=batch_dict['voxel_features'], indices=batch_dict['voxel_coords'].int(),
                                      spatial_shape=self.sparse_shape, batch_size=batch_dict['batch_size'])
         # all rulebooks first (coordinates only; the 4 strided convs each read one int back), then a sync-free feature pass
-        idx, shp = sp.indices.contiguous(), sp.spatial_shape
-        for name in ('conv_input', 'conv1', 'conv2', 'conv3', 'conv4', 'conv_out'):
-            idx, shp = spconv.prebuild_rulebooks(getattr(self, name), idx, shp, sp.batch_size, sp.indice_dict)
+        stages = [getattr(self, name) for name in ('conv_input', 'conv1', 'conv2', 'conv3', 'conv4', 'conv_out')]
+        spconv.prebuild_rulebooks(stages, sp.indices.contiguous(), sp.spatial_shape, sp.batch_size, sp.indice_dict)
         x = self.conv_input(sp)
         x1 = self.conv1(x)
         x2 = self.conv2(x1)

@@ -62,7 +62,17 @@ class SparseConvolution(SparseModule):
             bound = 1 / math.sqrt(fan_in)
             init.uniform_(self.bias, -bound, bound)
 
-    def build_rulebook(self, indices, spatial_shape, batch_size, indice_dict):
+    def needs_new_rulebook(self, indice_dict):
+        if self.conv1x1 or self.inverse:
+            return False
+        return self.indice_key is None or self.indice_key not in indice_dict
+
+    def begin_rulebook(self, indices, spatial_shape, batch_size):
+        """regular (strided) conv only: start the output-site search early (ops.conv_rulebook_begin)"""
+        assert not self.subm and not self.inverse and not self.conv1x1
+        return ops.conv_rulebook_begin(indices, batch_size, spatial_shape, self.kernel_size, self.stride, self.padding)
+
+    def build_rulebook(self, indices, spatial_shape, batch_size, indice_dict, pending=None):
         """Coordinate-only part of forward(): makes sure this layer's rulebook is in `indice_dict` and returns the
         (indices, spatial_shape) of its output.  Rulebooks depend on coordinates alone, so a network can build all of
         them up front (the only host read-backs of the sparse path) and then run its feature pass without a single sync."""
@@ -83,7 +93,9 @@ class SparseConvolution(SparseModule):
             return indices, spatial_shape
         out_shape = ops.get_conv_output_size(spatial_shape, self.kernel_size, self.stride, self.padding)
         if datas is None:
-            out_indices, nbr, nbr_t = ops.conv_rulebook(indices, batch_size, spatial_shape, self.kernel_size, self.stride, self.padding)
+            if pending is None:
+                pending = self.begin_rulebook(indices, spatial_shape, batch_size)
+            out_indices, nbr, nbr_t = ops.conv_rulebook_finish(pending)
             datas = {"subm": False, "nbr": nbr, "nbr_t": nbr_t, "in_indices": indices, "out_indices": out_indices,
                      "in_spatial_shape": spatial_shape, "out_spatial_shape": out_shape}
             if self.indice_key is not None:

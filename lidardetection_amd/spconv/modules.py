@@ -97,17 +97,39 @@ def _forward_inference(self, input):
 SparseSequential._forward_inference = _forward_inference
 
 
-def prebuild_rulebooks(module, indices, spatial_shape, batch_size, indice_dict):
-    """Walks `module` (SparseSequential nests, sparse convolutions, and composite SparseModules exposing their
-    sparse children as attributes in execution order) and builds every rulebook from the coordinates alone.
-    Returns the (indices, spatial_shape) leaving the module.  Dense layers (BatchNorm1d, ReLU) are skipped."""
+def _sparse_convs(module):
+    """sparse convolutions of `module` in execution order (SparseSequential nests and composite SparseModules exposing
+    their sparse children as attributes in execution order)"""
     from .conv import SparseConvolution
-    if isinstance(module, SparseConvolution):
-        if indices.dtype != torch.int32:
-            indices = indices.int()
-        return module.build_rulebook(indices.contiguous(), spatial_shape, batch_size, indice_dict)
-    if isinstance(module, SparseModule) or isinstance(module, nn.Sequential):
+    if isinstance(module, (list, tuple)):
+        for m in module:
+            yield from _sparse_convs(m)
+    elif isinstance(module, SparseConvolution):
+        yield module
+    elif isinstance(module, (SparseModule, nn.Sequential)):
         for child in module._modules.values():
             if isinstance(child, (SparseModule, nn.Sequential)):
-                indices, spatial_shape = prebuild_rulebooks(child, indices, spatial_shape, batch_size, indice_dict)
+                yield from _sparse_convs(child)
+
+
+def prebuild_rulebooks(module, indices, spatial_shape, batch_size, indice_dict):
+    """Builds every rulebook of `module` (a module or a list of modules run back to back) from the coordinates alone and
+    returns the (indices, spatial_shape) leaving it.
+    Dense layers (BatchNorm1d, ReLU) are skipped.  Scheduling: a strided conv's rulebook needs one host read-back (the
+    number of output sites); when a SubM layer is about to build a table for the level that strided conv consumes, the
+    strided conv's output-site search is enqueued FIRST, so the SubM table build runs while the host waits for the count."""
+    convs = list(_sparse_convs(module))
+    pending = {}
+    if indices.dtype != torch.int32:
+        indices = indices.int()
+    indices = indices.contiguous()
+    for i, conv in enumerate(convs):
+        if conv.subm and conv.needs_new_rulebook(indice_dict) and indices.shape[0] > 0:
+            for nxt in convs[i + 1:]:
+                if nxt.conv1x1 or nxt.subm:
+                    continue                      # stays on this level
+                if not nxt.inverse and nxt.needs_new_rulebook(indice_dict) and id(nxt) not in pending:
+                    pending[id(nxt)] = nxt.begin_rulebook(indices, spatial_shape, batch_size)
+                break
+        indices, spatial_shape = conv.build_rulebook(indices, spatial_shape, batch_size, indice_dict, pending.pop(id(conv), None))
     return indices, spatial_shape

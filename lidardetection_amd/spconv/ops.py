@@ -37,33 +37,55 @@ def subm_rulebook(indices, spatial_shape, ksize):
     return nbr
 
 
-def conv_rulebook(indices, batch_size, spatial_shape, ksize, stride, padding):
-    """-> out_indices (N_out, 4) int32, nbr (N_out, K), nbr_t (N_in, K).  One host sync (N_out)."""
+def conv_rulebook_begin(indices, batch_size, spatial_shape, ksize, stride, padding):
+    """Phase 1 of the SparseConv3d rulebook: enqueue the search for the unique output sites and an asynchronous copy of
+    their count to pinned host memory.  Returns the pending state for conv_rulebook_finish; work enqueued on the stream
+    after this call (e.g. the SubM table of the same level) overlaps the host's wait for the count."""
     _lib.require_cuda(indices)
     L = _lib.lib()
     n = indices.shape[0]
     K = ksize[0] * ksize[1] * ksize[2]
     dev = indices.device
+    st = {"n": n, "K": K, "dev": dev, "ksize": list(ksize), "stride": list(stride)}
     if n == 0:
-        return (torch.empty((0, 4), dtype=torch.int32, device=dev), torch.empty((0, K), dtype=torch.int32, device=dev),
-                torch.empty((0, K), dtype=torch.int32, device=dev))
+        return st
     bound = n
     for k, s in zip(ksize, stride):
         bound *= -(-k // s)
     bound = min(bound, n * K)
     wsb = L.lidar_spconv_conv_table_workspace_bytes(n, *ksize, *stride)
-    ws = workspace.get("spconv_rulebook", wsb, dev)
+    ws = torch.empty(wsb, dtype=torch.uint8, device=dev)          # lives until finish (several rulebooks may be in flight)
     out_idx = torch.empty((bound, 4), dtype=torch.int32, device=dev)
     num = torch.empty((1,), dtype=torch.int32, device=dev)
     D, H, W = spatial_shape
     _lib.check(L.lidar_spconv_conv_outputs(_lib.ptr(indices), n, batch_size, D, H, W, *ksize, *stride, *padding, _lib.ptr(out_idx), bound,
                                            _lib.ptr(num), _lib.ptr(ws), wsb, _lib.stream()), "lidar_spconv_conv_outputs")
-    n_out = int(num.item())
+    num_host = torch.empty((1,), dtype=torch.int32, pin_memory=True)
+    num_host.copy_(num, non_blocking=True)
+    ev = torch.cuda.Event()
+    ev.record(torch.cuda.current_stream(dev))
+    st.update(ws=ws, wsb=wsb, out_idx=out_idx, num=num, num_host=num_host, ev=ev)
+    return st
+
+
+def conv_rulebook_finish(st):
+    """Phase 2: wait for the count only (not for later work on the stream), allocate and fill the tables."""
+    n, K, dev = st["n"], st["K"], st["dev"]
+    if n == 0:
+        return (torch.empty((0, 4), dtype=torch.int32, device=dev), torch.empty((0, K), dtype=torch.int32, device=dev),
+                torch.empty((0, K), dtype=torch.int32, device=dev))
+    st["ev"].synchronize()
+    n_out = int(st["num_host"][0])
     nbr = torch.empty((n_out, K), dtype=torch.int32, device=dev)
     nbr_t = torch.empty((n, K), dtype=torch.int32, device=dev)
-    _lib.check(L.lidar_spconv_conv_tables(n, *ksize, *stride, n_out, _lib.ptr(nbr), _lib.ptr(nbr_t), _lib.ptr(ws), wsb, _lib.stream()),
-               "lidar_spconv_conv_tables")
-    return out_idx[:n_out].clone(), nbr, nbr_t
+    _lib.check(_lib.lib().lidar_spconv_conv_tables(n, *st["ksize"], *st["stride"], n_out, _lib.ptr(nbr), _lib.ptr(nbr_t), _lib.ptr(st["ws"]),
+                                                   st["wsb"], _lib.stream()), "lidar_spconv_conv_tables")
+    return st["out_idx"][:n_out].clone(), nbr, nbr_t
+
+
+def conv_rulebook(indices, batch_size, spatial_shape, ksize, stride, padding):
+    """-> out_indices (N_out, 4) int32, nbr (N_out, K), nbr_t (N_in, K).  One host read-back (N_out)."""
+    return conv_rulebook_finish(conv_rulebook_begin(indices, batch_size, spatial_shape, ksize, stride, padding))
 
 
 def cached_mask_order(datas, key, table):
