@@ -23,6 +23,9 @@
 #define VX_INF 0x7FFFFFFF
 #define VX_TILE 1024
 #define VX_ROWS_PER_BLOCK 64
+#ifndef VXL_PTS_PER_BIN
+#define VXL_PTS_PER_BIN 2560   // LDS-binned path: expected points per hash bin (bins per frame = n_max / this)
+#endif
 
 typedef float vx_f4 __attribute__((ext_vector_type(4)));
 // streaming (non-temporal) 16-B store: the padded voxel rows are written once and not re-read here
@@ -79,12 +82,12 @@ static size_t vx_carve(void *base, int B, int n_max, int max_voxels, VxWs *w) {
         return (char *)base + o;
     };
     char *p;
-    p = take((size_t)B * (divup(n_max, 2560) * 6144) * 4); if (w) w->pfirst = (int *)p;  // also the LDS path's staging lists
+    p = take((size_t)B * (divup(n_max, VXL_PTS_PER_BIN) * 6144) * 4); if (w) w->pfirst = (int *)p;  // also the LDS path's staging lists
     p = take((size_t)B * n_max * 4); if (w) w->flagw = (int *)p;
     p = take((size_t)B * n_max * 8); if (w) w->vinfo = (int2 *)p;
     p = take(65536); if (w) w->err = (int *)p;  // [0] sticky error flag
-    p = take((size_t)B * divup(n_max, 1024) * divup(n_max, 2560) * 1024 * 8 + 65536); if (w) w->queue = (int2 *)p;  // [B][tile][G][1024]
-    p = take((size_t)B * divup(n_max, 1024) * divup(n_max, 2560) * 4 + 256); if (w) w->qcnt = (int *)p;             // [B][tile][G]
+    p = take((size_t)B * divup(n_max, 1024) * divup(n_max, VXL_PTS_PER_BIN) * 1024 * 8 + 65536); if (w) w->queue = (int2 *)p;  // [B][tile][G][1024]
+    p = take((size_t)B * divup(n_max, 1024) * divup(n_max, VXL_PTS_PER_BIN) * 4 + 256); if (w) w->qcnt = (int *)p;             // [B][tile][G]
     p = take(B * H * 4); if (w) w->keys = (uint32_t *)p;
     p = take(B * H * 4); if (w) w->first = (int *)p;
     p = take(B * H * 4); if (w) w->cnt = (int *)p;
@@ -401,7 +404,6 @@ __global__ __launch_bounds__(256) void vx_rows_kernel(const float *__restrict__ 
 // (= voxel ids in first-appearance order), and the row writer streams the padded rows.
 #define VXL_S 8192          // LDS table slots per bin
 #define VXL_CAP 6144        // LDS entry / list capacity (points per bin)
-#define VXL_PTS_PER_BIN 2560
 #define VXL_MBITS 14        // pinfo word: m = min(count, P) in the low 14 bits, list position above
 #define VXL_MMASK ((1 << VXL_MBITS) - 1)
 #define VXL_MAX_ITEMS 32    // rank kernel: n_max <= 32 * 1024
