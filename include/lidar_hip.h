@@ -237,6 +237,12 @@ int lidar_decode_topk(const float *head, int batch, long long locs_per_frame, in
                       int anchors_per_loc, int num_dir_bins, const long long *top_idx, int k, const float *anchors,
                       float dir_offset, float dir_limit_offset, float period, float *boxes, void *stream);
 
+/* HeightCompression in one pass (pcdet/models/backbones_2d/map_to_bev/height_compression.py:21-24): the (N, C*D, H, W) BEV
+ * map of a sparse tensor written directly channels-last: out[b][h][w][c*D + d]; D <= 4, channels % 4 == 0; same workspace
+ * as lidar_sparse_to_dense. */
+int lidar_sparse_to_bev_nhwc(const float *features, const int *indices, int n, int channels, int batch, int D, int H, int W,
+                             float *out, void *ws, size_t ws_bytes, void *stream);
+
 /* ------------------------------------------------------------------ CPU entry points (HOST pointers, no GPU touched)
  * Called by the reference from DataLoader workers (augmentation / database creation). */
 /* boxes_iou_bev_cpu (pcdet/ops/iou3d_nms/src/iou3d_cpu.cpp:232-252): out (n_a, n_b) rotated BEV IoU */

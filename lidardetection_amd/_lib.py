@@ -59,6 +59,7 @@ SIGNATURES = {
     "lidar_spconv_wgrad": (i32, [vp, vp, vp, i32, i32, i32, i32, vp, vp]),
     "lidar_sparse_to_dense_workspace_bytes": (sz, [i32, i32, i32, i32]),
     "lidar_sparse_to_dense": (i32, [vp, vp, i32, i32, i32, i32, i32, i32, vp, vp, sz, vp]),
+    "lidar_sparse_to_bev_nhwc": (i32, [vp, vp, i32, i32, i32, i32, i32, i32, vp, vp, sz, vp]),
     "lidar_bias_act_nhwc": (i32, [vp, vp, C.c_longlong, i32, i32, vp, i32, i32, vp]),
     "lidar_bias_act_upsample_nhwc": (i32, [vp, vp, i32, i32, i32, i32, i32, i32, vp, i32, i32, vp]),
     "lidar_anchor_scores": (i32, [vp, C.c_longlong, i32, i32, i32, i32, f32, vp, vp, vp]),

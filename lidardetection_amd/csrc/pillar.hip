@@ -317,3 +317,58 @@ LIDAR_EXPORT int lidar_sparse_to_dense(const float *features, const int *indices
     else hipLaunchKernelGGL(scatter_canvas_kernel<128>, grid, dim3(256), 0, s, features, map, W, D * H, out);
     return lidar_check_launch("lidar_sparse_to_dense");
 }
+
+// HeightCompression output straight in NHWC (height_compression.py:21-24: dense (N, C, D, H, W).view(N, C*D, H, W), which
+// the dense BEV backbone then wants channels-last): out[b][h][w][c*D + d] = features[row at (b, d, h, w)][c] or 0, every
+// element written once; saves the NCDHW volume + the layout conversion pass.  map: (B, D*H, W) inverse index from
+// scatter_index_kernel.  One thread = one pixel's 4 consecutive source channels x all D levels = 4*D consecutive floats.
+template <int D>
+__global__ __launch_bounds__(256) void bev_nhwc_kernel(const float *__restrict__ feat, const int *__restrict__ map, long long n_pix,
+                                                       int C4, int H, int W, float *__restrict__ out) {
+    const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
+    if (i >= n_pix * C4) return;
+    const long long pix = i / C4;
+    const int c4 = (int)(i - pix * C4);
+    const int w = (int)(pix % W);
+    const long long bh = pix / W;
+    const int h = (int)(bh % H);
+    const long long b = bh / H;
+    float4 v[D];
+#pragma unroll
+    for (int d = 0; d < D; ++d) {
+        const int row = map[((b * D + d) * H + h) * (long long)W + w];
+        v[d] = row >= 0 ? reinterpret_cast<const float4 *>(feat)[(size_t)row * C4 + c4] : make_float4(0.f, 0.f, 0.f, 0.f);
+    }
+    float *o = out + (pix * C4 + c4) * (4 * D);
+#pragma unroll
+    for (int d = 0; d < D; ++d) {
+        o[0 * D + d] = v[d].x;
+        o[1 * D + d] = v[d].y;
+        o[2 * D + d] = v[d].z;
+        o[3 * D + d] = v[d].w;
+    }
+}
+
+LIDAR_EXPORT int lidar_sparse_to_bev_nhwc(const float *features, const int *indices, int n, int channels, int batch, int D, int H,
+                                          int W, float *out, void *ws, size_t ws_bytes, void *stream) {
+    if (!features || !indices || !out || !ws || batch <= 0 || D <= 0 || D > 4 || H <= 0 || W <= 0 || n < 0) return LIDAR_ERR_ARG;
+    if (channels <= 0 || (channels & 3)) return LIDAR_ERR_ARG;
+    if (ws_bytes < lidar_sparse_to_dense_workspace_bytes(batch, D, H, W)) return LIDAR_ERR_WORKSPACE;
+    hipStream_t s = (hipStream_t)stream;
+    int *map = (int *)ws;
+    const long long cells = (long long)batch * D * H * W;
+    int fb = divup(cells, 256 * 4);
+    if (fb > 2048) fb = 2048;
+    hipLaunchKernelGGL(scatter_fill_kernel, dim3(fb), dim3(256), 0, s, map, cells);
+    if (n > 0)
+        hipLaunchKernelGGL(scatter_index_kernel, dim3(divup(n, 256)), dim3(256), 0, s, (const void *)indices, 0, n,
+                           (const int *)nullptr, batch, W, D * H, H, map);
+    const long long n_pix = (long long)batch * H * W;
+    const int C4 = channels / 4;
+    const long long blocks = (n_pix * C4 + 255) / 256;
+    if (blocks > 0x7fffffffll) return LIDAR_ERR_ARG;
+#define BEV_CASE(DD) hipLaunchKernelGGL(bev_nhwc_kernel<DD>, dim3((unsigned)blocks), dim3(256), 0, s, features, map, n_pix, C4, H, W, out)
+    if (D == 1) BEV_CASE(1); else if (D == 2) BEV_CASE(2); else if (D == 3) BEV_CASE(3); else BEV_CASE(4);
+#undef BEV_CASE
+    return lidar_check_launch("lidar_sparse_to_bev_nhwc");
+}

@@ -52,9 +52,7 @@ class SECONDKitti(PointPillarKITTI):
 
     def sparse_backbone(self, feats, coords):
         bd = self.backbone3d({"voxel_features": feats, "voxel_coords": coords, "batch_size": self.B})
-        dense = bd["encoded_spconv_tensor"].dense()             # (B, 128, 2, 200, 176)
-        n, c, d, h, w = dense.shape
-        return dense.view(n, c * d, h, w).contiguous(memory_format=torch.channels_last)
+        return bd["encoded_spconv_tensor"].dense_bev()          # (B, 128 * 2, 200, 176), channels-last, one pass
 
     def backbone_head(self, canvas):
         if self._bev is None:

@@ -46,6 +46,24 @@ class SparseConvTensor(object):
         out[idx[:, 0], idx[:, 1], idx[:, 2], idx[:, 3]] = feats
         return out.permute(0, 4, 1, 2, 3).contiguous() if channels_first else out
 
+    def dense_bev(self):
+        """HeightCompression in one pass: (B, C*D, H, W) with channels-last strides, equal to
+        dense().view(B, C*D, H, W).contiguous(memory_format=torch.channels_last) (height_compression.py:21-24)."""
+        feats = self.features.contiguous()
+        N, C = feats.shape
+        B, (D, H, W) = self.batch_size, self.spatial_shape
+        if not (feats.is_cuda and feats.dtype == torch.float32 and C % 4 == 0 and D <= 4 and not feats.requires_grad):
+            d = self.dense()
+            return d.view(B, C * D, H, W).contiguous(memory_format=torch.channels_last)
+        L = _lib.lib()
+        out = torch.empty((B, C * D, H, W), dtype=torch.float32, device=feats.device, memory_format=torch.channels_last)
+        wsb = L.lidar_sparse_to_dense_workspace_bytes(B, D, H, W)
+        ws = workspace.get("dense", wsb, feats.device)
+        idx = self.indices.int().contiguous()
+        _lib.check(L.lidar_sparse_to_bev_nhwc(_lib.ptr(feats), _lib.ptr(idx), N, C, B, D, H, W, _lib.ptr(out), _lib.ptr(ws), wsb,
+                                              _lib.stream()), "lidar_sparse_to_bev_nhwc")
+        return out
+
     @property
     def sparity(self):
         return self.indices.shape[0] / self.spatial_size / self.batch_size

@@ -224,3 +224,18 @@ def test_mask_sorted_gemm_is_bit_identical(dev, cin, cout, n_out, p_valid):
     assert torch.equal(got, base)
     np.testing.assert_allclose(got.cpu().double().numpy(), ref.numpy(), rtol=0, atol=1e-4)
     assert not ops.sorted_gemm_supported(125, 16, 16) and not ops.sorted_gemm_supported(K, 4, 16)
+
+
+@pytest.mark.parametrize("C,D", [(128, 2), (64, 1), (32, 3), (16, 4)])
+def test_dense_bev_nhwc_equals_dense_view(dev, C, D):
+    shape, B = [D, 20, 24], 2
+    idx = _sites(31 + D, B, shape, 300)
+    f = torch.randn(300, C, device=dev)
+    x = spconv.SparseConvTensor(f, torch.from_numpy(idx).to(dev), shape, B)
+    got = x.dense_bev()
+    ref = torch.zeros(B, C, *shape)
+    ii = torch.from_numpy(idx).long()
+    ref[ii[:, 0], :, ii[:, 1], ii[:, 2], ii[:, 3]] = f.cpu()
+    want = ref.view(B, C * D, shape[1], shape[2])
+    assert got.shape == want.shape and got.is_contiguous(memory_format=torch.channels_last)
+    assert torch.equal(got.cpu(), want)
