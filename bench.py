@@ -43,9 +43,10 @@ def cpu_baseline(frames, model, nframes):
     (torch CPU) + dense backbone/head (torch CPU, all threads) + rotated NMS (C, 1 thread)."""
     from oracle import c_oracle, pp_oracle
     import copy
-    bev, model._bev = model._bev, None      # device-side folded weights / concat buffer: not part of the host copy
+    keep = (model._bev, model._canvas)      # device-side folded weights / concat + canvas buffers: not part of the host copy
+    model._bev = model._canvas = None
     m = copy.deepcopy(model).to("cpu")
-    model._bev = bev
+    model._bev, model._canvas = keep
     m.B = 1
     m.fold_bn = False           # the HIP epilogue has no CPU path: stock modules on the host
     m.anchors = m.anchors.cpu()

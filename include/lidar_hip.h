@@ -95,6 +95,10 @@ int lidar_boxes_pairwise_bev(const float *boxes_a, int n_a, const float *boxes_b
 size_t lidar_nms_workspace_bytes(int batch, int n_max);
 int lidar_nms_batch(const float *boxes, const int *counts, int batch, int n_max, float thresh, int normal,
                     long long *keep, int *num_keep, void *ws, size_t ws_bytes, void *stream);
+/* same, but only the first max_keep survivors of each frame are wanted (the caller truncates to NMS_POST_MAXSIZE anyway,
+ * pcdet/models/model_utils/model_nms_utils.py:19-21): the greedy pass stops early; num_keep <= max_keep */
+int lidar_nms_batch_limited(const float *boxes, const int *counts, int batch, int n_max, float thresh, int normal,
+                            int max_keep, long long *keep, int *num_keep, void *ws, size_t ws_bytes, void *stream);
 /* test hook: device pointer to the (batch, n_max, ceil(n_max/64)) u64 suppression mask inside ws */
 const void *lidar_nms_mask_ptr(void *ws, int batch, int n_max);
 

@@ -25,6 +25,7 @@ SIGNATURES = {
     "lidar_boxes_pairwise_bev": (i32, [vp, i32, vp, i32, i32, vp, vp, sz, vp]),
     "lidar_nms_workspace_bytes": (sz, [i32, i32]),
     "lidar_nms_batch": (i32, [vp, vp, i32, i32, f32, i32, vp, vp, vp, sz, vp]),
+    "lidar_nms_batch_limited": (i32, [vp, vp, i32, i32, f32, i32, i32, vp, vp, vp, sz, vp]),
     "lidar_nms_mask_ptr": (vp, [vp, i32, i32]),
     "lidar_ball_query_stack": (i32, [i32, i32, f32, i32, vp, vp, vp, vp, vp, vp]),
     "lidar_group_points_stack": (i32, [i32, i32, i32, i32, vp, vp, vp, vp, vp, vp]),

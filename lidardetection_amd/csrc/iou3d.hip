@@ -374,7 +374,7 @@ __global__ __launch_bounds__(256) void nms_mask_kernel(const float *__restrict__
 // one block per frame (iou3d_nms.cpp:116-132).  keep: int64 positions; num_keep: int per frame.
 #define GREEDY_TPB 1024
 __global__ __launch_bounds__(GREEDY_TPB) void nms_greedy_kernel(const unsigned long long *__restrict__ mask_all,
-                                                                const int *__restrict__ counts, int n_max,
+                                                                const int *__restrict__ counts, int n_max, int max_keep,
                                                                 long long *__restrict__ keep_all,
                                                                 int *__restrict__ num_keep) {
     __shared__ unsigned long long s_remv[1024];  // cb words (n_max <= 65536)
@@ -427,7 +427,7 @@ __global__ __launch_bounds__(GREEDY_TPB) void nms_greedy_kernel(const unsigned l
         }
         __syncthreads();
     }
-    if (t == 0) num_keep[f] = s_nkeep;
+    if (t == 0) num_keep[f] = min(s_nkeep, max_keep);
 }
 
 // ------------------------------------------------------------------ greedy keep, N <= 4096 fast path
@@ -438,10 +438,11 @@ __global__ __launch_bounds__(GREEDY_TPB) void nms_greedy_kernel(const unsigned l
 //   the kept rows are then OR-ed into remv from LDS (one conflict-free 512-B row read each).
 #define GF_TPB 256
 __global__ __launch_bounds__(GF_TPB) void nms_greedy_fast_kernel(const unsigned long long *__restrict__ mask_all,
-                                                                 const int *__restrict__ counts, int n_max,
+                                                                 const int *__restrict__ counts, int n_max, int max_keep,
                                                                  long long *__restrict__ keep_all,
                                                                  int *__restrict__ num_keep) {
     __shared__ unsigned long long s_tile[2][64][64];
+    __shared__ int s_stop;
     const int f = blockIdx.x;
     const int n = counts ? min(counts[f], n_max) : n_max;
     const int cb_total = (n_max + 63) / 64;   // <= 64
@@ -449,65 +450,79 @@ __global__ __launch_bounds__(GF_TPB) void nms_greedy_fast_kernel(const unsigned 
     const unsigned long long *mask = mask_all + (size_t)f * n_max * cb_total;
     long long *keep = keep_all + (size_t)f * n_max;
     const int t = threadIdx.x, l = t & 63;
-    unsigned long long pre[16];
-    auto fetch = [&](int rb) {  // rows rb*64 .. +63, columns 0..cb_total-1 -> registers
+    // register ring: the 64-row blocks rb+1 and rb+2 are in flight while block rb (already in LDS) is decided, so a block's
+    // global-load latency is spread over two decision steps instead of sitting in front of every step
+    unsigned long long pre[3][16];
+    auto fetch = [&](int rb, unsigned long long (&dst)[16]) {  // rows rb*64 .. +63, columns 0..cb_total-1 -> registers
 #pragma unroll
         for (int k = 0; k < 16; ++k) {
             const int idx = t + GF_TPB * k, row = idx >> 6, col = idx & 63;
             const int grow = rb * 64 + row;
-            pre[k] = (rb < cb && grow < n && col < cb_total && col >= rb) ? mask[(size_t)grow * cb_total + col] : 0ull;
+            // unconditional load from a clamped address + select: a guarded load compiles to a branch with a full
+            // s_waitcnt per load, which serialises the 16 loads of a block
+            const unsigned long long v = mask[(size_t)min(grow, max(n - 1, 0)) * cb_total + min(col, cb_total - 1)];
+            dst[k] = (rb < cb && grow < n && col < cb_total && col >= rb) ? v : 0ull;
         }
     };
-    auto stash = [&](int buf) {
+    auto stash = [&](int buf, const unsigned long long (&src)[16]) {
 #pragma unroll
         for (int k = 0; k < 16; ++k) {
             const int idx = t + GF_TPB * k;
-            s_tile[buf][idx >> 6][idx & 63] = pre[k];
+            s_tile[buf][idx >> 6][idx & 63] = src[k];
         }
     };
-    fetch(0);
-    stash(0);
+    fetch(0, pre[0]);
+    fetch(1, pre[1]);
+    fetch(2, pre[2]);
+    stash(0, pre[0]);
     __syncthreads();
     unsigned long long remv = 0ull;  // wave 0: lane c owns column block c
     int nkeep = 0;
-    for (int rb = 0; rb < cb; ++rb) {
-        const int buf = rb & 1;
-        fetch(rb + 1);  // in flight while wave 0 decides
-        if (t < 64) {
-            const int row0 = rb * 64;
-            const int lim = min(64, n - row0);
-            const unsigned long long valid = lim >= 64 ? ~0ull : ((1ull << lim) - 1ull);
-            const unsigned long long diag = s_tile[buf][l][rb];   // lane i: diagonal word of row i
-            const unsigned int dlo = (unsigned int)diag, dhi = (unsigned int)(diag >> 32);
-            unsigned long long r = __shfl(remv, rb, 64);
-            r = ((unsigned long long)(unsigned int)__builtin_amdgcn_readfirstlane((int)(r >> 32)) << 32) |
-                (unsigned long long)(unsigned int)__builtin_amdgcn_readfirstlane((int)r);
-            unsigned long long km = 0ull;
-            unsigned long long avail = ~r & valid;
-            while (avail) {   // wave-uniform: one iteration per KEPT box of this block
-                const int i = __ffsll((long long)avail) - 1;
-                km |= 1ull << i;
-                const unsigned long long d =
-                    ((unsigned long long)(unsigned int)__builtin_amdgcn_readlane((int)dhi, i) << 32) |
-                    (unsigned long long)(unsigned int)__builtin_amdgcn_readlane((int)dlo, i);
-                r |= d | (1ull << i);
-                avail = ~r & valid & ~((2ull << i) - 1ull);
+    for (int rb0 = 0; rb0 < cb; rb0 += 3) {
+#pragma unroll
+        for (int ph = 0; ph < 3; ++ph) {
+            const int rb = rb0 + ph;
+            if (rb >= cb) break;                   // block-uniform
+            const int buf = rb & 1;
+            fetch(rb + 3, pre[ph]);                // slot ph held block rb (stashed one step ago)
+            if (t < 64) {
+                const int row0 = rb * 64;
+                const int lim = min(64, n - row0);
+                const unsigned long long valid = lim >= 64 ? ~0ull : ((1ull << lim) - 1ull);
+                const unsigned long long diag = s_tile[buf][l][rb];   // lane i: diagonal word of row i
+                const unsigned int dlo = (unsigned int)diag, dhi = (unsigned int)(diag >> 32);
+                unsigned long long r = __shfl(remv, rb, 64);
+                r = ((unsigned long long)(unsigned int)__builtin_amdgcn_readfirstlane((int)(r >> 32)) << 32) |
+                    (unsigned long long)(unsigned int)__builtin_amdgcn_readfirstlane((int)r);
+                unsigned long long km = 0ull;
+                unsigned long long avail = ~r & valid;
+                while (avail) {   // wave-uniform: one iteration per KEPT box of this block
+                    const int i = __ffsll((long long)avail) - 1;
+                    km |= 1ull << i;
+                    const unsigned long long d =
+                        ((unsigned long long)(unsigned int)__builtin_amdgcn_readlane((int)dhi, i) << 32) |
+                        (unsigned long long)(unsigned int)__builtin_amdgcn_readlane((int)dlo, i);
+                    r |= d | (1ull << i);
+                    avail = ~r & valid & ~((2ull << i) - 1ull);
+                }
+                if ((km >> l) & 1ull) keep[nkeep + __popcll(km & lanemask_lt())] = row0 + l;
+                nkeep += __popcll(km);
+                unsigned long long acc = 0ull, m = km;
+                while (m) {
+                    const int i = __ffsll((long long)m) - 1;
+                    m &= m - 1ull;
+                    acc |= s_tile[buf][i][l];
+                }
+                if (l > rb) remv |= acc;
+                if (l == 0) s_stop = (nkeep >= max_keep) ? 1 : 0;   // the caller only wants the first max_keep survivors
             }
-            if ((km >> l) & 1ull) keep[nkeep + __popcll(km & lanemask_lt())] = row0 + l;
-            nkeep += __popcll(km);
-            unsigned long long acc = 0ull, m = km;
-            while (m) {
-                const int i = __ffsll((long long)m) - 1;
-                m &= m - 1ull;
-                acc |= s_tile[buf][i][l];
-            }
-            if (l > rb) remv |= acc;
+            __syncthreads();          // everyone is done reading the buffer block rb+1 goes into
+            if (s_stop) { rb0 = cb; break; }   // block-uniform
+            stash(buf ^ 1, pre[(ph + 1) % 3]);
+            __syncthreads();
         }
-        __syncthreads();          // everyone is done reading buffer buf^1's predecessor
-        stash(buf ^ 1);
-        __syncthreads();
     }
-    if (t == 0) num_keep[f] = nkeep;
+    if (t == 0) num_keep[f] = min(nkeep, max_keep);
 }
 
 // ------------------------------------------------------------------ C ABI
@@ -541,9 +556,9 @@ LIDAR_EXPORT size_t lidar_nms_workspace_bytes(int batch, int n_max) {
 // Batched NMS on already score-sorted boxes.  boxes (batch, n_max, 7); counts (batch) device ints or
 // NULL (= n_max for every frame); keep (batch, n_max) int64 device; num_keep (batch) int device.
 // normal = 0: nms_gpu (iou3d_nms.cpp:90-136), 1: nms_normal_gpu (:139-186).
-LIDAR_EXPORT int lidar_nms_batch(const float *boxes, const int *counts, int batch, int n_max, float thresh, int normal,
-                                 long long *keep, int *num_keep, void *ws, size_t ws_bytes, void *stream) {
-    if (batch <= 0 || n_max < 0 || !num_keep) return LIDAR_ERR_ARG;
+LIDAR_EXPORT int lidar_nms_batch_limited(const float *boxes, const int *counts, int batch, int n_max, float thresh, int normal,
+                                         int max_keep, long long *keep, int *num_keep, void *ws, size_t ws_bytes, void *stream) {
+    if (batch <= 0 || n_max < 0 || !num_keep || max_keep <= 0) return LIDAR_ERR_ARG;
     hipStream_t s = (hipStream_t)stream;
     if (n_max == 0) return hipMemsetAsync(num_keep, 0, sizeof(int) * batch, s) == hipSuccess ? LIDAR_OK : LIDAR_ERR_LAUNCH;
     if (!boxes || !keep || !ws) return LIDAR_ERR_ARG;
@@ -561,10 +576,16 @@ LIDAR_EXPORT int lidar_nms_batch(const float *boxes, const int *counts, int batc
     else
         hipLaunchKernelGGL(nms_mask_kernel<false>, grid, dim3(256), 0, s, boxes, pre, counts, n_max, thresh, mask);
     if (cb <= 64)
-        hipLaunchKernelGGL(nms_greedy_fast_kernel, dim3(batch), dim3(GF_TPB), 0, s, mask, counts, n_max, keep, num_keep);
+        hipLaunchKernelGGL(nms_greedy_fast_kernel, dim3(batch), dim3(GF_TPB), 0, s, mask, counts, n_max, max_keep, keep, num_keep);
     else
-        hipLaunchKernelGGL(nms_greedy_kernel, dim3(batch), dim3(GREEDY_TPB), 0, s, mask, counts, n_max, keep, num_keep);
+        hipLaunchKernelGGL(nms_greedy_kernel, dim3(batch), dim3(GREEDY_TPB), 0, s, mask, counts, n_max, max_keep, keep, num_keep);
     return lidar_check_launch("lidar_nms_batch");
+}
+
+LIDAR_EXPORT int lidar_nms_batch(const float *boxes, const int *counts, int batch, int n_max, float thresh, int normal,
+                                 long long *keep, int *num_keep, void *ws, size_t ws_bytes, void *stream) {
+    return lidar_nms_batch_limited(boxes, counts, batch, n_max, thresh, normal, n_max > 0 ? n_max : 1, keep, num_keep, ws, ws_bytes,
+                                   stream);
 }
 
 // test hook: copy of the suppression mask words (row-major (n_max, cb)) of frame 0 left in ws by

@@ -25,9 +25,10 @@ def boxes_iou_bev_gpu(boxes_a, boxes_b, ans_iou):
     return _pairwise(boxes_a, boxes_b, ans_iou, 1)
 
 
-def nms_batch(boxes, counts, thresh, normal=False):
+def nms_batch(boxes, counts, thresh, normal=False, max_keep=None):
     """Batched device-resident NMS (no host sync).  boxes (B, N, 7) sorted by score desc.
-    -> keep (B, N) int64 positions, num_keep (B,) int32, both on the device."""
+    -> keep (B, N) int64 positions, num_keep (B,) int32, both on the device.  max_keep: only the first max_keep survivors
+    of a frame are needed (NMS_POST_MAXSIZE): the greedy pass stops there, num_keep is clamped."""
     _lib.require_cuda(boxes, counts)
     B, N = boxes.shape[0], boxes.shape[1]
     L = _lib.lib()
@@ -35,8 +36,9 @@ def nms_batch(boxes, counts, thresh, normal=False):
     num = torch.empty((B,), dtype=torch.int32, device=boxes.device)
     wsb = L.lidar_nms_workspace_bytes(B, N)
     ws = workspace.get("nms", wsb, boxes.device)
-    _lib.check(L.lidar_nms_batch(_lib.ptr(boxes), _lib.ptr(counts), B, N, float(thresh), int(normal), _lib.ptr(keep),
-                                 _lib.ptr(num), _lib.ptr(ws), wsb, _lib.stream()), "lidar_nms_batch")
+    mk = max(N, 1) if max_keep is None else max(int(max_keep), 1)
+    _lib.check(L.lidar_nms_batch_limited(_lib.ptr(boxes), _lib.ptr(counts), B, N, float(thresh), int(normal), mk, _lib.ptr(keep),
+                                         _lib.ptr(num), _lib.ptr(ws), wsb, _lib.stream()), "lidar_nms_batch_limited")
     return keep, num
 
 

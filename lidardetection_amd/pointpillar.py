@@ -97,6 +97,7 @@ class PointPillarKITTI(nn.Module):
         self.anchors = generate_anchors(self.pc_range, (self.ny // 2, self.nx // 2), device)
         self._vox_out = self.voxelizer.alloc_outputs(batch_size, device)
         self._folded = None
+        self._canvas = None
         self.fold_bn = bool(fold_bn) and self.channels_last   # folded BN + HIP epilogue (bev_backbone.py)
         self._bev = None
 
@@ -130,8 +131,11 @@ class PointPillarKITTI(nn.Module):
         total = vox["voxel_offsets"][self.B:self.B + 1]
         feat = pillar_ops.pillar_vfe(vox["voxels"], vox["voxel_num_points"], vox["voxel_coords"], w, s, t,
                                      self.voxel_size, self.pc_range, num_voxels_dev=total)
+        if self._canvas is None or self._canvas.device != feat.device:      # persistent 877 MB canvas: no allocator churn per step
+            self._canvas = torch.empty((self.B, feat.shape[1], self.ny, self.nx), dtype=torch.float32, device=feat.device,
+                                       memory_format=torch.channels_last if self.channels_last else torch.contiguous_format)
         return pillar_ops.pillar_scatter(feat, vox["voxel_coords"], self.B, self.nx, self.ny, num_voxels_dev=total,
-                                         channels_last=self.channels_last)
+                                         out=self._canvas, channels_last=self.channels_last)
 
     def backbone_head(self, canvas):
         if self.fold_bn:
@@ -199,8 +203,8 @@ class PointPillarKITTI(nn.Module):
         return self._nms_and_gather(boxes, top_scores, top_idx, labels_all, counts, k)
 
     def _nms_and_gather(self, boxes, top_scores, top_idx, labels_all, counts, k):
-        keep, num = iou3d_nms_cuda.nms_batch(boxes, counts, self.nms_thresh)
         post = min(self.nms_post, k)
+        keep, num = iou3d_nms_cuda.nms_batch(boxes, counts, self.nms_thresh, max_keep=post)   # survivors past `post` are dropped anyway
         sel = keep[:, :post].clamp_(0, k - 1)
         num = torch.clamp(num, max=post)
         valid = torch.arange(post, device=sel.device).unsqueeze(0) < num.unsqueeze(1)
