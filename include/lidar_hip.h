@@ -209,6 +209,13 @@ int lidar_spconv_implicit_gemm_sorted(const float *in_features, const int *nbr, 
 /* weight gradient: grad_weight (K, Cin, Cout) += sum_j in[nbr[j][k]]^T (x) grad_out[j]; zero-filled by the caller */
 int lidar_spconv_wgrad(const float *in_features, const float *grad_out, const int *nbr, int n_out, int K, int Cin, int Cout,
                        float *grad_weight, void *stream);
+/* weight gradient on the matrix cores: same contraction as lidar_spconv_wgrad, grad_weight overwritten (no zero fill),
+ * deterministic (per-chunk partials in `ws`, summed in order); order = mask order of nbr's rows (lidar_spconv_row_masks +
+ * argsort) or NULL; Cin, Cout in {16, 32, 64, 128} (lidar_spconv_wgrad_mfma_supported). */
+int lidar_spconv_wgrad_mfma_supported(int K, int Cin, int Cout);
+size_t lidar_spconv_wgrad_workspace_bytes(int n_out, int K, int Cin, int Cout);
+int lidar_spconv_wgrad_mfma(const float *in_features, const float *grad_out, const int *nbr, const int *order, int n_out, int K,
+                            int Cin, int Cout, float *grad_weight, void *ws, size_t ws_bytes, void *stream);
 /* SparseConvTensor.dense(): (N, C) rows at (N,4) indices -> (B, C, D, H, W), every element written once */
 size_t lidar_sparse_to_dense_workspace_bytes(int batch, int D, int H, int W);
 int lidar_sparse_to_dense(const float *features, const int *indices, int n, int channels, int batch, int D, int H, int W,

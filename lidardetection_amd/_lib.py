@@ -58,6 +58,9 @@ SIGNATURES = {
     "lidar_spconv_sorted_gemm_supported": (i32, [i32, i32, i32]),
     "lidar_spconv_implicit_gemm_sorted": (i32, [vp, vp, vp, vp, i32, i32, i32, i32, vp, vp, vp, i32, vp, vp]),
     "lidar_spconv_wgrad": (i32, [vp, vp, vp, i32, i32, i32, i32, vp, vp]),
+    "lidar_spconv_wgrad_mfma_supported": (i32, [i32, i32, i32]),
+    "lidar_spconv_wgrad_workspace_bytes": (sz, [i32, i32, i32, i32]),
+    "lidar_spconv_wgrad_mfma": (i32, [vp, vp, vp, vp, i32, i32, i32, i32, vp, vp, sz, vp]),
     "lidar_sparse_to_dense_workspace_bytes": (sz, [i32, i32, i32, i32]),
     "lidar_sparse_to_dense": (i32, [vp, vp, i32, i32, i32, i32, i32, i32, vp, vp, sz, vp]),
     "lidar_sparse_to_bev_nhwc": (i32, [vp, vp, i32, i32, i32, i32, i32, i32, vp, vp, sz, vp]),

@@ -190,10 +190,21 @@ class SparseConvFunction(Function):
                 order = cached_mask_order(ctx.orders[0], ctx.orders[2], bwd_table)
             grad_feats = _implicit_gemm(g, bwd_table, wt.transpose(1, 2).contiguous(), None, feats.shape[0], order)
         if ctx.needs_input_grad[1]:
-            grad_w = torch.zeros_like(w)
-            if fwd_table.shape[0] > 0:
-                _lib.check(_lib.lib().lidar_spconv_wgrad(_lib.ptr(feats), _lib.ptr(g), _lib.ptr(fwd_table), fwd_table.shape[0], K, Cin,
-                                                         Cout, _lib.ptr(grad_w), _lib.stream()), "lidar_spconv_wgrad")
+            L, n_out = _lib.lib(), fwd_table.shape[0]
+            if n_out > 0 and L.lidar_spconv_wgrad_mfma_supported(K, Cin, Cout):
+                order = None
+                if ctx.orders is not None and K <= 31:
+                    order = cached_mask_order(ctx.orders[0], ctx.orders[1], fwd_table)[1]
+                grad_w = torch.empty_like(w)
+                wsb = L.lidar_spconv_wgrad_workspace_bytes(n_out, K, Cin, Cout)
+                ws = workspace.get("spconv_wgrad", wsb, g.device)
+                _lib.check(L.lidar_spconv_wgrad_mfma(_lib.ptr(feats), _lib.ptr(g), _lib.ptr(fwd_table), _lib.ptr(order), n_out, K, Cin,
+                                                     Cout, _lib.ptr(grad_w), _lib.ptr(ws), wsb, _lib.stream()), "lidar_spconv_wgrad_mfma")
+            else:
+                grad_w = torch.zeros_like(w)
+                if n_out > 0:
+                    _lib.check(L.lidar_spconv_wgrad(_lib.ptr(feats), _lib.ptr(g), _lib.ptr(fwd_table), n_out, K, Cin, Cout,
+                                                    _lib.ptr(grad_w), _lib.stream()), "lidar_spconv_wgrad")
             grad_w = grad_w.view(ctx.wshape)
         if ctx.has_bias and ctx.needs_input_grad[2]:
             grad_b = g.sum(0)

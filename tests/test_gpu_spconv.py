@@ -239,3 +239,40 @@ def test_dense_bev_nhwc_equals_dense_view(dev, C, D):
     want = ref.view(B, C * D, shape[1], shape[2])
     assert got.shape == want.shape and got.is_contiguous(memory_format=torch.channels_last)
     assert torch.equal(got.cpu(), want)
+
+
+@pytest.mark.parametrize("cin,cout,n_out,p_valid", [(16, 16, 1000, 0.15), (16, 32, 257, 0.4), (32, 64, 901, 0.35),
+                                                    (64, 64, 5000, 0.1), (128, 128, 300, 0.3), (64, 16, 129, 1.0)])
+def test_wgrad_mfma_matches_float64_and_the_scalar_kernel(dev, cin, cout, n_out, p_valid):
+    """weight gradient on the matrix cores (with and without the mask order) vs a float64 gather-matmul and vs the
+    VALU/atomics kernel it replaces; deterministic: two runs give the same bits."""
+    from lidardetection_amd import _lib, workspace
+    from lidardetection_amd.spconv import ops
+    K, n_in = 27, 777
+    g = torch.Generator(device="cpu").manual_seed(cin * 7 + cout + n_out)
+    nbr = torch.randint(0, n_in, (n_out, K), generator=g, dtype=torch.int32)
+    nbr[torch.rand(n_out, K, generator=g) >= p_valid] = -1
+    feats = torch.randn(n_in, cin, generator=g)
+    go = torch.randn(n_out, cout, generator=g)
+    ref = torch.zeros(K, cin, cout, dtype=torch.float64)
+    for k in range(K):
+        m = nbr[:, k] >= 0
+        ref[k] = feats[nbr[m, k].long()].double().t() @ go[m].double()
+    nbr_d, f_d, g_d = nbr.to(dev), feats.to(dev), go.to(dev)
+    L = _lib.lib()
+    assert L.lidar_spconv_wgrad_mfma_supported(K, cin, cout)
+    wsb = L.lidar_spconv_wgrad_workspace_bytes(n_out, K, cin, cout)
+    ws = workspace.get("spconv_wgrad_test", wsb, dev)
+    outs = []
+    for order in (None, ops.mask_order(nbr_d)[1], None):
+        gw = torch.full((K, cin, cout), float("nan"), device=dev)
+        _lib.check(L.lidar_spconv_wgrad_mfma(_lib.ptr(f_d), _lib.ptr(g_d), _lib.ptr(nbr_d), _lib.ptr(order), n_out, K, cin, cout,
+                                             _lib.ptr(gw), _lib.ptr(ws), wsb, _lib.stream()), "lidar_spconv_wgrad_mfma")
+        outs.append(gw)
+        scale = float(ref.abs().max())
+        np.testing.assert_allclose(gw.cpu().double().numpy(), ref.numpy(), rtol=0, atol=2e-5 * max(scale, 1.0))
+    assert torch.equal(outs[0], outs[2])                                   # deterministic
+    old = torch.zeros((K, cin, cout), device=dev)
+    _lib.check(L.lidar_spconv_wgrad(_lib.ptr(f_d), _lib.ptr(g_d), _lib.ptr(nbr_d), n_out, K, cin, cout, _lib.ptr(old), _lib.stream()),
+               "lidar_spconv_wgrad")
+    np.testing.assert_allclose(outs[0].cpu().numpy(), old.cpu().numpy(), rtol=0, atol=2e-4 * max(float(ref.abs().max()), 1.0))
