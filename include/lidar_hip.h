@@ -254,6 +254,12 @@ int lidar_decode_topk(const float *head, int batch, long long locs_per_frame, in
 int lidar_sparse_to_bev_nhwc(const float *features, const int *indices, int n, int channels, int batch, int D, int H, int W,
                              float *out, void *ws, size_t ws_bytes, void *stream);
 
+/* ------------------------------------------------------------------ KITTI-eval rotated BEV IoU (8f rank 4)
+ * rotate_iou_gpu_eval (pcdet/datasets/kitti/kitti_object_eval_python/rotate_iou.py:290-330; numba.cuda in the reference):
+ * boxes (n, 5) / query_boxes (k, 5) as (x, y, w, l, angle) -> iou (n, k); criterion -1: IoU, 0: inter / area(query),
+ * 1: inter / area(box), 2: intersection area. */
+int lidar_rotate_iou_eval(const float *boxes, int n, const float *query_boxes, int k, int criterion, float *iou, void *stream);
+
 /* ------------------------------------------------------------------ CPU entry points (HOST pointers, no GPU touched)
  * Called by the reference from DataLoader workers (augmentation / database creation). */
 /* boxes_iou_bev_cpu (pcdet/ops/iou3d_nms/src/iou3d_cpu.cpp:232-252): out (n_a, n_b) rotated BEV IoU */

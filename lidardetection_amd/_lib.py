@@ -68,6 +68,7 @@ SIGNATURES = {
     "lidar_bias_act_upsample_nhwc": (i32, [vp, vp, i32, i32, i32, i32, i32, i32, vp, i32, i32, vp]),
     "lidar_anchor_scores": (i32, [vp, C.c_longlong, i32, i32, i32, i32, f32, vp, vp, vp]),
     "lidar_decode_topk": (i32, [vp, i32, C.c_longlong, i32, i32, i32, i32, i32, vp, i32, vp, f32, f32, f32, vp, vp]),
+    "lidar_rotate_iou_eval": (i32, [vp, i32, vp, i32, i32, vp, vp]),
     "lidar_boxes_iou_bev_cpu": (i32, [vp, i32, vp, i32, vp]),
     "lidar_points_in_boxes_cpu": (i32, [vp, i32, vp, i32, vp]),
 }

@@ -276,3 +276,12 @@ def three_interpolate_grad_batch(grad_out, idx, w, m):
     gp = np.zeros((b, c, m), np.float32)
     lib().orc_three_interpolate_grad_batch(_ci(b), _ci(c), _ci(n), _ci(m), _p(g), _p(idx), _p(w), _p(gp))
     return gp
+
+
+def rotate_iou_eval(boxes, query_boxes, criterion=-1):
+    """KITTI-eval rotated IoU (rotate_iou.py:290-330), boxes (N,5) / query_boxes (K,5) [x, y, w, l, angle] -> (N,K) f32."""
+    b, q = _f32(boxes), _f32(query_boxes)
+    out = np.zeros((b.shape[0], q.shape[0]), dtype=np.float32)
+    if b.shape[0] and q.shape[0]:
+        lib().orc_rotate_iou_eval(_p(b), _ci(b.shape[0]), _p(q), _ci(q.shape[0]), _ci(criterion), _p(out))
+    return out
