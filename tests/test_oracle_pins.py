@@ -110,3 +110,19 @@ def test_voxel_oracle_properties():
     pu = synth.cloud_uniform(1000)
     v2, c2, n2 = c_oracle.voxelize(pu, vs, rng, 32, 16000)
     assert len(v2) == 16000
+
+
+def test_eval_iou_oracle_known_answers():
+    """oracle/src/eval_iou_oracle.c (restated numba source, parity unpinned): closed-form cases."""
+    from oracle import c_oracle
+    a = np.array([[0, 0, 2, 4, 0]], np.float32)
+    b = np.array([[1, 0, 2, 4, 0], [10, 10, 1, 1, 0.3]], np.float32)
+    np.testing.assert_allclose(c_oracle.rotate_iou_eval(a, b, -1)[0], [4 / 12, 0.0], atol=1e-5)
+    np.testing.assert_allclose(c_oracle.rotate_iou_eval(a, b, 2)[0], [4.0, 0.0], atol=1e-4)
+    np.testing.assert_allclose(c_oracle.rotate_iou_eval(a, b[:1], 0)[0], [0.5], atol=1e-6)
+    sq = np.array([[0, 0, 2, 2, 0]], np.float32)
+    dia = np.array([[0, 0, 2, 2, np.pi / 4]], np.float32)            # square vs the same square turned by 45 deg: an octagon
+    inter = 8 * (np.sqrt(2) - 1)
+    np.testing.assert_allclose(c_oracle.rotate_iou_eval(sq, dia, 2)[0, 0], inter, atol=1e-4)
+    np.testing.assert_allclose(c_oracle.rotate_iou_eval(sq, dia, -1)[0, 0], inter / (8 - inter), atol=1e-5)
+    assert c_oracle.rotate_iou_eval(a[:0], b).shape == (0, 2)
