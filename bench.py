@@ -141,14 +141,17 @@ def main():
     }
     if args.stages and rank == 0:
         def gpu_time(fn, n=20):
-            torch.cuda.synchronize()
-            a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-            a.record()
-            for _ in range(n):
+            """median GPU time of one call (per-call event pairs: a host-side pause between launches is not GPU time)"""
+            for _ in range(2):
                 r = fn()
-            b.record()
             torch.cuda.synchronize()
-            return a.elapsed_time(b) / n, r
+            evs = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(n)]
+            for a, b in evs:
+                a.record()
+                r = fn()
+                b.record()
+            torch.cuda.synchronize()
+            return float(np.median([a.elapsed_time(b) for a, b in evs])), r
         with torch.no_grad():
             tv, vox = gpu_time(lambda: model.voxelize(pts, offs))
             ts, canvas = gpu_time(lambda: model.vfe_scatter(vox))
