@@ -8,6 +8,10 @@ outputs) and are what travels to the GPU box.
   iou3d_ref.npz    <- the reference's own compiled CPU entry points (oracle/_ref, built by
                       oracle/build_ref.py from unmodified sources): boxes_iou_bev_cpu, points_in_boxes_cpu
 
+  bev_head.npz     <- the reference's own BaseBEVBackbone (pcdet/models/backbones_2d/base_bev_backbone.py) forward on a small
+                      configuration with random eval-mode BatchNorm statistics, and its own ResidualCoder.decode_torch
+                      (pcdet/utils/box_coder_utils.py) on random anchors / encodings
+
 Usage:  python tests/golden/make_golden.py
 """
 import os
@@ -116,6 +120,49 @@ def make_iou3d_ref():
     print("iou3d_ref.npz", out.shape, out_n.shape, int(pib.sum()))
 
 
+def make_bev_head():
+    import importlib.util
+
+    def load(name, path):
+        spec = importlib.util.spec_from_file_location(name, path)
+        mod = importlib.util.module_from_spec(spec)
+        spec.loader.exec_module(mod)
+        return mod
+
+    bev = load("_ref_base_bev_backbone", "/root/reference/pcdet/models/backbones_2d/base_bev_backbone.py")
+    coder = load("_ref_box_coder_utils", "/root/reference/pcdet/utils/box_coder_utils.py")
+    cfg = types.SimpleNamespace(LAYER_NUMS=[1, 2], LAYER_STRIDES=[2, 2], NUM_FILTERS=[16, 32], UPSAMPLE_STRIDES=[1, 2],
+                                NUM_UPSAMPLE_FILTERS=[32, 32])
+    cfg.get = lambda k, d=None: getattr(cfg, k, d)
+    torch.manual_seed(3)
+    m = bev.BaseBEVBackbone(cfg, input_channels=16)
+    g = torch.Generator().manual_seed(4)
+    with torch.no_grad():
+        for mod in m.modules():
+            if isinstance(mod, torch.nn.BatchNorm2d):
+                mod.running_mean.copy_(torch.empty(mod.num_features).uniform_(-0.3, 0.3, generator=g))
+                mod.running_var.copy_(torch.empty(mod.num_features).uniform_(0.6, 1.4, generator=g))
+                mod.weight.copy_(torch.empty(mod.num_features).uniform_(0.5, 1.5, generator=g))
+                mod.bias.copy_(torch.empty(mod.num_features).uniform_(-0.3, 0.3, generator=g))
+    m.eval()
+    x = torch.randn(2, 16, 24, 20, generator=g)
+    x[:, :, ::3] = 0
+    with torch.no_grad():
+        y = m({"spatial_features": x})["spatial_features_2d"]
+    sd = {"bev." + k: v.numpy() for k, v in m.state_dict().items()}
+    # ResidualCoder.decode_torch on KITTI-like anchors
+    n = 500
+    r = np.random.default_rng(9)
+    anchors = np.concatenate([r.uniform(0, 70, (n, 1)), r.uniform(-40, 40, (n, 1)), r.uniform(-2, 0, (n, 1)),
+                              r.uniform(0.5, 4.5, (n, 3)), r.choice([0.0, 1.57], (n, 1))], 1).astype(np.float32)
+    enc = (r.standard_normal((n, 7)) * 0.3).astype(np.float32)
+    dec = coder.ResidualCoder().decode_torch(torch.from_numpy(enc), torch.from_numpy(anchors))
+    np.savez_compressed(os.path.join(HERE, "bev_head.npz"), bev_input=x.numpy(), bev_output=y.numpy(),
+                        decode_anchors=anchors, decode_enc=enc, decode_out=dec.numpy(), **sd)
+    print("bev_head.npz", tuple(y.shape), tuple(dec.shape), len(sd))
+
+
 if __name__ == "__main__":
     make_pp_modules()
     make_iou3d_ref()
+    make_bev_head()

@@ -308,3 +308,37 @@ def test_nms_batch_max_keep_is_a_prefix_of_the_full_result(dev):
         assert torch.equal(num, want)
         for f in range(3):
             assert torch.equal(keep[f, :int(want[f])], full_keep[f, :int(want[f])])
+
+
+def test_bev_backbone_and_box_decode_vs_reference_golden(dev, golden_dir):
+    """tests/golden/bev_head.npz was emitted by the REFERENCE's own BaseBEVBackbone and ResidualCoder.decode_torch
+    (tests/golden/make_golden.py).  The folded backbone (BN folded, HIP epilogues, GEMM deblocks writing the concat slice) must
+    reproduce the reference module's output from the reference's own state_dict; lidar_decode_topk must reproduce its decode."""
+    import torch.nn as nn
+    from lidardetection_amd import anchor_post
+    from lidardetection_amd.bev_backbone import FoldedBEVBackbone
+    from lidardetection_amd.pointpillar import make_bev_backbone
+    g = np.load(os.path.join(golden_dir, "bev_head.npz"))
+
+    class Holder(nn.Module):
+        def __init__(self):
+            super().__init__()
+            self.blocks, self.deblocks = make_bev_backbone(cin=16, layer_nums=(1, 2), strides=(2, 2), filters=(16, 32),
+                                                           up_strides=(1, 2), up_filters=(32, 32))
+    h = Holder()
+    sd = {k[4:]: torch.from_numpy(g[k]) for k in g.files if k.startswith("bev.")}
+    h.load_state_dict(sd, strict=True)                      # the reference's parameter names fit this repo's module tree
+    h = h.to(dev).eval().to(memory_format=torch.channels_last)
+    heads = [nn.Conv2d(64, 4, 1).to(dev)]
+    x = torch.from_numpy(g["bev_input"]).to(dev).contiguous(memory_format=torch.channels_last)
+    with torch.no_grad():
+        got = FoldedBEVBackbone(h.blocks, h.deblocks, heads).features(x)
+    want = g["bev_output"]
+    assert tuple(got.shape) == want.shape
+    np.testing.assert_allclose(got.cpu().numpy(), want, rtol=0, atol=1e-4 * max(1.0, float(np.abs(want).max())))
+    # ResidualCoder.decode_torch: one anchor per location, no direction bins
+    enc, anchors = torch.from_numpy(g["decode_enc"]).to(dev), torch.from_numpy(g["decode_anchors"]).to(dev)
+    n = enc.shape[0]
+    boxes = anchor_post.decode_topk(enc.view(1, n, 7).contiguous(), torch.arange(n, device=dev).view(1, n), anchors, 1, box_off=0,
+                                    dir_off=0, num_dir_bins=0, dir_offset=0.0, dir_limit_offset=0.0)
+    np.testing.assert_allclose(boxes[0].cpu().numpy(), g["decode_out"], rtol=2e-6, atol=1e-6)
