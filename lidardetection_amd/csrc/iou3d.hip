@@ -431,8 +431,9 @@ __global__ __launch_bounds__(GREEDY_TPB) void nms_greedy_kernel(const unsigned l
 }
 
 // ------------------------------------------------------------------ greedy keep, N <= 4096 fast path
-// One block per frame.  All 256 threads stream the mask one 64-row block at a time into LDS (double
-// buffered, coalesced, independent of the decisions), wave 0 walks the decision chain on LDS data only:
+// One block per frame.  All 256 threads stream the mask one 64-row block at a time into LDS (two LDS buffers fed from a
+// three-deep register ring, coalesced, independent of the decisions), wave 0 walks the decision chain on LDS data only;
+// the walk stops once max_keep boxes are kept (the caller's NMS_POST_MAXSIZE):
 //   lane c keeps remv word c in a register; the 64x64 diagonal tile is resolved by jumping from kept
 //   box to kept box (ctz over the not-yet-suppressed bits, v_readlane of the row's diagonal word);
 //   the kept rows are then OR-ed into remv from LDS (one conflict-free 512-B row read each).
