@@ -394,14 +394,14 @@ __global__ __launch_bounds__(256) void vx_rows_kernel(const float *__restrict__ 
 
 
 // ================================================================== LDS-binned path (algo 1)
-// No global atomics at all.  A frame's points are hash-partitioned by voxel key into G bins;
-// workgroup (g, f) streams the whole frame (coalesced float4, L2-resident), keeps the points of its
-// bin, and resolves everything that is local to a voxel inside LDS with LDS atomics:
+// No global atomics at all.  A frame's points are hash-partitioned by voxel key into G bins by the key kernel (whose
+// launch also zero-fills the whole padded output, see vxl_key_kernel); workgroup (g, f) of the bin kernel takes its bin's
+// (point, key) pairs and resolves everything that is local to a voxel inside LDS with LDS atomics:
 //   first point, point count, and the ascending list of its first P point indices (the same
 //   order-independent atomicMin insertion chain as the global path, but on LDS).
 // It leaves one 32-bit word per point (0, or for a voxel's first point: count | list position) and
 // the bin's packed index lists.  A one-block-per-frame ballot scan then ranks the first points
-// (= voxel ids in first-appearance order), and the row writer streams the padded rows.
+// (= voxel ids in first-appearance order), and the scatter stage writes the occupied slots, coords and counts.
 #define VXL_S 8192          // LDS table slots per bin
 #define VXL_CAP 6144        // LDS entry / list capacity (points per bin)
 #define VXL_MBITS 14        // pinfo word: m = min(count, P) in the low 14 bits, list position above
@@ -437,10 +437,31 @@ __device__ __forceinline__ bool vx_cell(const VxParams &p, float x, float y, flo
 // atomics).  Outside-the-grid points get their per-point word (0) here and enter no bin.
 #define VXL_GMAX 16
 #define ITEMS_TILES(p) (((p).n_max + 1023) >> 10)
+// Workgroups x < ntiles: one 1024-point tile each (cells, partition by bin).  Workgroups x >= ntiles: zero-fill role — the
+// padded voxel rows are 96 % zeros and none of them depends on the index build, so the whole output buffer is cleared
+// HERE, inside the first launch of the sequence (a plain 136 MB fill runs at 7.6 TB/s on this part, i.e. 19 us, and hides
+// the key stage completely); the row stage then only scatters the occupied slots.  Running the fill beside the later,
+// latency-critical bin / rank launches instead was measured and loses.
+#define VXL_FILL_F4_PER_WG (1024 * 4)      // 64 KiB of zeros per fill workgroup
 template <bool C4>
 __global__ __launch_bounds__(1024) void vxl_key_kernel(const float *__restrict__ points,
-                                                       const int *__restrict__ offsets, VxParams p, VxWs w, int G) {
+                                                       const int *__restrict__ offsets, VxParams p, VxWs w, int G,
+                                                       int ntiles, float *__restrict__ voxels, long long fill_f4_per_frame,
+                                                       long long fill_tail_floats) {
     __shared__ int s_wc[16][VXL_GMAX];   // per wave, per bin counts -> exclusive offsets
+    if ((int)blockIdx.x >= ntiles) {     // ---- zero-fill role (block-uniform)
+        const long long c = (long long)blockIdx.x - ntiles;
+        float4 *dst = reinterpret_cast<float4 *>(voxels) + (long long)blockIdx.y * fill_f4_per_frame;
+        const float4 z = make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const long long i = c * VXL_FILL_F4_PER_WG + k * 1024 + threadIdx.x;
+            if (i < fill_f4_per_frame) dst[i] = z;
+        }
+        if (blockIdx.y == gridDim.y - 1 && c == 0 && (long long)threadIdx.x < fill_tail_floats)   // bytes past the last float4
+            voxels[(long long)gridDim.y * fill_f4_per_frame * 4 + threadIdx.x] = 0.f;
+        return;
+    }
     const int tile = blockIdx.x, f = blockIdx.y, t = threadIdx.x, l = t & 63, wv = t >> 6;
     const int start = offsets[f];
     const int n = min(offsets[f + 1] - start, p.n_max);
@@ -477,11 +498,11 @@ __global__ __launch_bounds__(1024) void vxl_key_kernel(const float *__restrict__
             s_wc[k][t] = acc;
             acc += c;
         }
-        w.qcnt[((size_t)f * gridDim.x + tile) * G + t] = acc;
+        w.qcnt[((size_t)f * ntiles + tile) * G + t] = acc;
     }
     __syncthreads();
     if (bin >= 0)
-        w.queue[(((size_t)f * gridDim.x + tile) * G + bin) * 1024 + s_wc[wv][bin] + myrank] = make_int2(j, (int)key);
+        w.queue[(((size_t)f * ntiles + tile) * G + bin) * 1024 + s_wc[wv][bin] + myrank] = make_int2(j, (int)key);
 }
 
 // K1: workgroup (g, f) = bin g of frame f.
@@ -680,15 +701,19 @@ __global__ __launch_bounds__(1024) void vxl_rank_kernel(const int *__restrict__ 
     if (t == 0) w.nvox[f] = min(s_f[ITEMS * 16], p.max_voxels);
 }
 
+// Row stage of the LDS-binned path: the buffer is already zero (fill role of the first launch), so only the occupied slots,
+// the coords and the counts are written: one thread per voxel row (1.25 points per voxel on average, up to P).
 template <bool C4>
-__global__ __launch_bounds__(256) void vxl_rows_kernel(const float *__restrict__ points,
-                                                       const int *__restrict__ offsets, VxParams p, VxWs w, int G,
-                                                       float *__restrict__ voxels, int *__restrict__ coords,
-                                                       int *__restrict__ num_points, int *__restrict__ voxel_offsets) {
+__global__ __launch_bounds__(256) void vxl_scatter_kernel(const float *__restrict__ points,
+                                                          const int *__restrict__ offsets, VxParams p, VxWs w, int G,
+                                                          float *__restrict__ voxels, int *__restrict__ coords,
+                                                          int *__restrict__ num_points, int *__restrict__ voxel_offsets) {
     const int f = blockIdx.y;
     const int start = offsets[f];
-    // first row of this frame: sum of the earlier frames' voxel counts (lane k holds frame k; batch <= 64
-    // per pass), computed redundantly by every wave: one load latency, no LDS, no barrier
+    const int r = blockIdx.x * 256 + threadIdx.x;
+    // requested before the voxel counts are known (always inside the frame's max_voxels slots): one dependent level fewer
+    const int word = w.voff[(size_t)f * p.max_voxels + min(r, p.max_voxels - 1)];
+    // first row of this frame: sum of the earlier frames' voxel counts (lane k holds frame k; every wave redundantly)
     int base = f * p.max_voxels;
     if (p.compact) {
         int part = 0;
@@ -707,72 +732,40 @@ __global__ __launch_bounds__(256) void vxl_rows_kernel(const float *__restrict__
         voxel_offsets[p.batch] = p.compact ? b : p.batch * p.max_voxels;
     }
     const int nv = w.nvox[f];
-    const int row0 = blockIdx.x * VX_ROWS_PER_BLOCK;
-    if (row0 >= nv) return;
-    const int rows = min(VX_ROWS_PER_BLOCK, nv - row0);
-    const int *vrow = w.voff + (size_t)f * p.max_voxels;
-    const int *stg = w.pfirst + (size_t)f * G * VXL_CAP;
+    if (r >= nv) return;
+    const int cnt = word & VXL_MMASK;
+    const int *lst = w.pfirst + (size_t)f * G * VXL_CAP + (word >> VXL_MBITS);
     const uint32_t nx = p.grid[0], ny = p.grid[1];
+    const size_t row = (size_t)base + r;
+    float x0 = 0.f, y0 = 0.f, z0 = 0.f;
     if (C4) {
-        const int items = rows * p.P;
-        float4 *out4 = reinterpret_cast<float4 *>(voxels) + (size_t)(base + row0) * p.P;
         const float4 *pts4 = reinterpret_cast<const float4 *>(points) + start;
-        constexpr int UN = 8;  // 8 x 256 float4 = 32 KiB per pass: all loads of a pass are issued before its stores
-        for (int it0 = threadIdx.x; it0 < items; it0 += 256 * UN) {
-            int word[UN], slot[UN], rix[UN], pidx[UN];
-            float4 v[UN];
+        float4 *out4 = reinterpret_cast<float4 *>(voxels) + row * p.P;
+        for (int s0 = 0; s0 < cnt; s0 += 4) {              // up to 4 independent gathers in flight
+            int pi[4];
+            float4 v[4];
 #pragma unroll
-            for (int k = 0; k < UN; ++k) {
-                const int it = it0 + 256 * k;
-                const int rr = it / p.P;
-                slot[k] = it - rr * p.P;
-                rix[k] = row0 + rr;
-                word[k] = (it < items) ? vrow[rix[k]] : 0;
-            }
+            for (int k = 0; k < 4; ++k) pi[k] = lst[min(s0 + k, cnt - 1)];
 #pragma unroll
-            for (int k = 0; k < UN; ++k)
-                pidx[k] = (slot[k] < (word[k] & VXL_MMASK)) ? stg[(word[k] >> VXL_MBITS) + slot[k]] : -1;
+            for (int k = 0; k < 4; ++k) v[k] = pts4[pi[k]];
 #pragma unroll
-            for (int k = 0; k < UN; ++k) v[k] = pidx[k] >= 0 ? pts4[pidx[k]] : make_float4(0.f, 0.f, 0.f, 0.f);
-#pragma unroll
-            for (int k = 0; k < UN; ++k) {
-                const int it = it0 + 256 * k;
-                if (it < items) {
-                    if (slot[k] == 0) {  // slot 0 holds the voxel's first point: its cell gives the coords
-                        uint32_t key;
-                        vx_cell(p, v[k].x, v[k].y, v[k].z, key);
-                        reinterpret_cast<int4 *>(coords)[base + rix[k]] =
-                            make_int4(f, (int)(key / (nx * ny)), (int)((key / nx) % ny), (int)(key % nx));
-                        num_points[base + rix[k]] = word[k] & VXL_MMASK;
-                    }
-                    vx_store_nt(out4 + it, v[k]);
-                }
-            }
+            for (int k = 0; k < 4; ++k)
+                if (s0 + k < cnt) out4[s0 + k] = v[k];
+            if (s0 == 0) { x0 = v[0].x; y0 = v[0].y; z0 = v[0].z; }
         }
     } else {
-        const int rowlen = p.P * p.C;
-        const int items = rows * rowlen;
-        float *out = voxels + (size_t)(base + row0) * rowlen;
         const float *pts = points + (size_t)start * p.C;
-        for (int it = threadIdx.x; it < items; it += 256) {
-            const int rr = it / rowlen, e = it - rr * rowlen;
-            const int slot = e / p.C, ch = e - slot * p.C;
-            const int word = vrow[row0 + rr];
-            float v = 0.f;
-            if (slot < (word & VXL_MMASK)) v = pts[(size_t)stg[(word >> VXL_MBITS) + slot] * p.C + ch];
-            out[it] = v;
-        }
-        for (int rr = threadIdx.x; rr < rows; rr += 256) {
-            const int r = row0 + rr;
-            const int word = vrow[r];
-            const float *q = pts + (size_t)stg[word >> VXL_MBITS] * p.C;
-            uint32_t key;
-            vx_cell(p, q[0], q[1], q[2], key);
-            reinterpret_cast<int4 *>(coords)[base + r] =
-                make_int4(f, (int)(key / (nx * ny)), (int)((key / nx) % ny), (int)(key % nx));
-            num_points[base + r] = word & VXL_MMASK;
+        float *out = voxels + row * p.P * p.C;
+        for (int sl = 0; sl < cnt; ++sl) {
+            const float *q = pts + (size_t)lst[sl] * p.C;
+            for (int c = 0; c < p.C; ++c) out[sl * p.C + c] = q[c];
+            if (sl == 0) { x0 = q[0]; y0 = q[1]; z0 = q[2]; }
         }
     }
+    uint32_t key;                                          // slot 0 holds the voxel's first point: its cell gives the coords
+    vx_cell(p, x0, y0, z0, key);
+    reinterpret_cast<int4 *>(coords)[row] = make_int4(f, (int)(key / (nx * ny)), (int)((key / nx) % ny), (int)(key % nx));
+    num_points[row] = cnt;
 }
 
 template <int ITEMS>
@@ -785,9 +778,20 @@ static int vxl_bins(int n_max) { return divup(n_max, VXL_PTS_PER_BIN); }
 static void vxl_run(const float *points, const int *point_offsets, const VxParams &p, const VxWs &w, bool c4,
                     float *voxels, int *coords, int *num_points, int *voxel_offsets, hipStream_t s) {
     const int G = vxl_bins(p.n_max);
-    const dim3 gk(divup(p.n_max, 1024), p.batch);
-    if (c4) hipLaunchKernelGGL(vxl_key_kernel<true>, gk, dim3(1024), 0, s, points, point_offsets, p, w, G);
-    else hipLaunchKernelGGL(vxl_key_kernel<false>, gk, dim3(1024), 0, s, points, point_offsets, p, w, G);
+    const int ntiles = divup(p.n_max, 1024);
+    // zero-fill share of every frame index (positional split of the B * max_voxels rows, whatever the compaction)
+    const long long frame_floats = (long long)p.max_voxels * p.P * p.C;
+    const long long total_floats = frame_floats * p.batch;
+    const bool fill_f4 = (reinterpret_cast<uintptr_t>(voxels) & 15) == 0;
+    // float4 units per frame slice; a slice boundary need not be a row boundary (pure zeros), leftovers go to the tail
+    const long long f4_per_frame = (fill_f4 && total_floats / 4 >= p.batch) ? (total_floats / 4) / p.batch : 0;
+    const long long tail_floats = total_floats - f4_per_frame * 4 * p.batch;      // < 4 * batch + 4 (or everything if unaligned)
+    const int nfill = (int)divup(f4_per_frame, VXL_FILL_F4_PER_WG);
+    const dim3 gk(ntiles + nfill, p.batch);
+    if (c4) hipLaunchKernelGGL(vxl_key_kernel<true>, gk, dim3(1024), 0, s, points, point_offsets, p, w, G, ntiles, voxels, f4_per_frame, tail_floats <= 1024 ? tail_floats : 0);
+    else hipLaunchKernelGGL(vxl_key_kernel<false>, gk, dim3(1024), 0, s, points, point_offsets, p, w, G, ntiles, voxels, f4_per_frame, tail_floats <= 1024 ? tail_floats : 0);
+    if (tail_floats > 1024)   // unaligned output buffer (never the case for torch allocations): plain memset of everything
+        (void)hipMemsetAsync(voxels, 0, (size_t)total_floats * sizeof(float), s);
     const int items = divup(p.n_max, 1024);
     const dim3 gb(G, p.batch);
     if (items <= 4) hipLaunchKernelGGL(vxl_bin_kernel<4>, gb, dim3(1024), 0, s, point_offsets, p, w, G);
@@ -800,9 +804,9 @@ static void vxl_run(const float *points, const int *point_offsets, const VxParam
     else if (items <= 16) vxl_rank_launch<16>(p.batch, s, point_offsets, p, w);
     else if (items <= 24) vxl_rank_launch<24>(p.batch, s, point_offsets, p, w);
     else vxl_rank_launch<32>(p.batch, s, point_offsets, p, w);
-    const dim3 grow(divup(p.max_voxels, VX_ROWS_PER_BLOCK), p.batch);
-    if (c4) hipLaunchKernelGGL(vxl_rows_kernel<true>, grow, dim3(256), 0, s, points, point_offsets, p, w, G, voxels, coords, num_points, voxel_offsets);
-    else hipLaunchKernelGGL(vxl_rows_kernel<false>, grow, dim3(256), 0, s, points, point_offsets, p, w, G, voxels, coords, num_points, voxel_offsets);
+    const dim3 grow(divup(p.max_voxels, 256), p.batch);
+    if (c4) hipLaunchKernelGGL(vxl_scatter_kernel<true>, grow, dim3(256), 0, s, points, point_offsets, p, w, G, voxels, coords, num_points, voxel_offsets);
+    else hipLaunchKernelGGL(vxl_scatter_kernel<false>, grow, dim3(256), 0, s, points, point_offsets, p, w, G, voxels, coords, num_points, voxel_offsets);
 }
 
 // ------------------------------------------------------------------ C ABI
