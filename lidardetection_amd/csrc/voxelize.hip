@@ -51,6 +51,7 @@ struct VxWs {
     int *err;        // [1] sticky error flag (LDS table / entry list overflow)
     int2 *queue;     // [B][tile][G][1024] (point, key): each 1024-point tile partitioned by bin
     int *qcnt;       // [B][tile][G] entries per (tile, bin) segment
+    int *tcnt;       // [B][G][32] first points of bin g per 1024-point tile (the emit stage turns them into voxel ids)
     // ---- global-hash path (algo 2)
     uint32_t *keys;  // [B][H]
     int *first;      // [B][H]
@@ -88,6 +89,7 @@ static size_t vx_carve(void *base, int B, int n_max, int max_voxels, VxWs *w) {
     p = take(65536); if (w) w->err = (int *)p;  // [0] sticky error flag
     p = take((size_t)B * divup(n_max, 1024) * divup(n_max, VXL_PTS_PER_BIN) * 1024 * 8 + 65536); if (w) w->queue = (int2 *)p;  // [B][tile][G][1024]
     p = take((size_t)B * divup(n_max, 1024) * divup(n_max, VXL_PTS_PER_BIN) * 4 + 256); if (w) w->qcnt = (int *)p;             // [B][tile][G]
+    p = take((size_t)B * divup(n_max, VXL_PTS_PER_BIN) * 32 * 4 + 256); if (w) w->tcnt = (int *)p;                               // [B][G][32]
     p = take(B * H * 4); if (w) w->keys = (uint32_t *)p;
     p = take(B * H * 4); if (w) w->first = (int *)p;
     p = take(B * H * 4); if (w) w->cnt = (int *)p;
@@ -465,6 +467,7 @@ __global__ __launch_bounds__(1024) void vxl_key_kernel(const float *__restrict__
     const int tile = blockIdx.x, f = blockIdx.y, t = threadIdx.x, l = t & 63, wv = t >> 6;
     const int start = offsets[f];
     const int n = min(offsets[f + 1] - start, p.n_max);
+    if (tile == 0 && t == 0) w.nvox[f] = 0;        // LDS path: first points of the frame, summed up by the bin workgroups
     const int j = tile * 1024 + t;
     const int jc = min(j, max(n - 1, 0));
     float x = 0.f, y = 0.f, z = 0.f;
@@ -513,9 +516,11 @@ __global__ __launch_bounds__(1024) void vxl_bin_kernel(const int *__restrict__ o
     __shared__ int s_cnt[VXL_S];
     __shared__ int2 s_q[VXL_CAP];       // phase B: (point, key); afterwards x = point | slot << 15, y = list cell
     __shared__ int s_wtot[16];
+    __shared__ int s_tc[32];            // first points of this bin per 1024-point tile
     __shared__ int s_nent, s_total;
     const int g = blockIdx.x, f = blockIdx.y, t = threadIdx.x, l = t & 63, wv = t >> 6;
     const int n = min(offsets[f + 1] - offsets[f], p.n_max);
+    if (t < 32) s_tc[t] = 0;
     // ---- phase B1 (loads): my bin's (point, key) pairs from the ITEMS tile segments written by K0.
     // Counts and the first 256 entries of every segment are requested together (one memory round trip,
     // overlapped with the LDS initialisation below); longer segments are topped up afterwards.
@@ -644,114 +649,105 @@ __global__ __launch_bounds__(1024) void vxl_bin_kernel(const int *__restrict__ o
             if (s_first[slot] == j) word = min(s_cnt[slot], p.P) | ((g * VXL_CAP + (int)s_key[slot]) << VXL_MBITS);
         }
         pinfo[j] = word;
+        // per-tile first-point counts, aggregated per wave: the entries arrive tile by tile, so a wave sees 1-2 tile ids
+        const int tau = j >> 10;
+        unsigned long long rem = __ballot(word != 0);
+        while (rem) {                                  // wave-uniform
+            const int lead = __builtin_ctzll(rem);
+            const int t0 = __shfl(tau, lead, 64);
+            const unsigned long long m = __ballot(word != 0 && tau == t0);
+            if (l == lead) atomicAdd(&s_tc[t0], __popcll(m));
+            rem &= ~m;
+        }
     }
     int *stg = w.pfirst + ((size_t)f * G + g) * VXL_CAP;   // staging lists live in the pfirst/vinfo region
     for (int k = t; k < L; k += 1024) stg[k] = s_q[k].y;
+    __syncthreads();
+    if (t < 32) w.tcnt[((size_t)f * G + g) * 32 + t] = s_tc[t];
+    if (t == 0) {
+        int tot = 0;
+        for (int k = 0; k < 32; ++k) tot += s_tc[k];
+        if (tot) atomicAdd(&w.nvox[f], tot);               // visible to the next launch; no ordering needed inside this one
+    }
 }
 
-// voxel ids = rank of the first points in point order: ballot scan, one block per frame
-template <int ITEMS>
-__global__ __launch_bounds__(1024) void vxl_rank_kernel(const int *__restrict__ offsets, VxParams p, VxWs w) {
-    __shared__ int s_f[ITEMS * 16 + 1];
-    const int f = blockIdx.x, t = threadIdx.x, wv = t >> 6, l = t & 63;
-    const int n = min(offsets[f + 1] - offsets[f], p.n_max);
-    const int *pinfo = w.flagw + (size_t)f * p.n_max;
-    int word[ITEMS], exf[ITEMS];
-#pragma unroll
-    for (int j = 0; j < ITEMS; ++j) {
-        const int i = j * 1024 + t;
-        const int wv_ = pinfo[min(i, max(n - 1, 0))];  // unconditional load (see vxl_bin_kernel)
-        word[j] = (i < n) ? wv_ : 0;
-    }
-#pragma unroll
-    for (int j = 0; j < ITEMS; ++j) {
-        const unsigned long long bal = __ballot(word[j] != 0);
-        exf[j] = __popcll(bal & lanemask_lt());
-        if (l == 0) s_f[j * 16 + wv] = __popcll(bal);
-    }
-    __syncthreads();
-    if (wv == 0) {  // exclusive scan of the ITEMS*16 (row, wave) counts in row-major order
-        constexpr int NE = ITEMS * 16, PER = (NE + 63) / 64;
-        int a[PER];
-        int sa = 0;
-#pragma unroll
-        for (int k = 0; k < PER; ++k) {
-            const int e = l * PER + k;
-            a[k] = e < NE ? s_f[e] : 0;
-            sa += a[k];
-        }
-        int ea = wave_incl_scan(sa) - sa;
-#pragma unroll
-        for (int k = 0; k < PER; ++k) {
-            const int e = l * PER + k;
-            if (e < NE) s_f[e] = ea;
-            ea += a[k];
-        }
-        if (l == 63) s_f[NE] = ea;
-    }
-    __syncthreads();
-    int *vrow = w.voff + (size_t)f * p.max_voxels;
-#pragma unroll
-    for (int j = 0; j < ITEMS; ++j) {
-        if (word[j] != 0) {
-            const int r = s_f[j * 16 + wv] + exf[j];
-            if (r < p.max_voxels) vrow[r] = word[j];
-        }
-    }
-    if (t == 0) w.nvox[f] = min(s_f[ITEMS * 16], p.max_voxels);
-}
-
-// Row stage of the LDS-binned path: the buffer is already zero (fill role of the first launch), so only the occupied slots,
-// the coords and the counts are written: one thread per voxel row (1.25 points per voxel on average, up to P).
+// Emit stage: workgroup (tile, f) owns the 1024 points of its tile.  A first point's voxel id = (first points of the frame in
+// earlier tiles, from the bin kernel's per-tile counts) + (its ballot rank inside the tile) = first-appearance order; the
+// thread then writes that voxel's row itself: occupied slots only (the buffer is already zero), coords from the first
+// point's cell, count.  No separate ranking launch.
 template <bool C4>
-__global__ __launch_bounds__(256) void vxl_scatter_kernel(const float *__restrict__ points,
-                                                          const int *__restrict__ offsets, VxParams p, VxWs w, int G,
-                                                          float *__restrict__ voxels, int *__restrict__ coords,
-                                                          int *__restrict__ num_points, int *__restrict__ voxel_offsets) {
-    const int f = blockIdx.y;
+__global__ __launch_bounds__(1024) void vxl_emit_kernel(const float *__restrict__ points, const int *__restrict__ offsets,
+                                                        VxParams p, VxWs w, int G, float *__restrict__ voxels,
+                                                        int *__restrict__ coords, int *__restrict__ num_points,
+                                                        int *__restrict__ voxel_offsets) {
+    __shared__ int s_part[16], s_wcnt[16];
+    __shared__ int s_base;
+    const int tile = blockIdx.x, f = blockIdx.y, t = threadIdx.x, l = t & 63, wv = t >> 6;
     const int start = offsets[f];
-    const int r = blockIdx.x * 256 + threadIdx.x;
-    // requested before the voxel counts are known (always inside the frame's max_voxels slots): one dependent level fewer
-    const int word = w.voff[(size_t)f * p.max_voxels + min(r, p.max_voxels - 1)];
-    // first row of this frame: sum of the earlier frames' voxel counts (lane k holds frame k; every wave redundantly)
-    int base = f * p.max_voxels;
-    if (p.compact) {
-        int part = 0;
-        for (int k0 = 0; k0 < f; k0 += 64) {
-            const int k = k0 + lane_id();
-            part += (k < f) ? w.nvox[k] : 0;
-        }
-        base = wave_sum(part);
+    const int n = min(offsets[f + 1] - start, p.n_max);
+    const int i = tile * 1024 + t;
+    const int wd = w.flagw[(size_t)f * p.n_max + min(i, max(n - 1, 0))];      // unconditional load, masked below
+    const int word = (i < n) ? wd : 0;
+    // this thread's own point, requested together with its word: for a first point it IS slot 0 of the voxel's row, so the
+    // 80 % of voxels that hold a single point need no dependent load at all
+    float4 me = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (C4 && n > 0) me = reinterpret_cast<const float4 *>(points)[(size_t)start + min(i, n - 1)];   // n: block-uniform
+    // first points of the frame in earlier tiles: sum of tcnt[f][g][tau < tile] over the G bins
+    int v = 0;
+    if (t < G * 32) {
+        const int tau = t & 31;
+        const int c = w.tcnt[(size_t)f * G * 32 + t];
+        v = (tau < tile) ? c : 0;
     }
-    if (blockIdx.x == 0 && f == 0 && threadIdx.x == 0) {  // the batch's offsets table (off the critical path)
+    v = wave_sum(v);
+    if (l == 0) s_part[wv] = v;
+    // rows of the earlier frames (every frame's count is complete: the bin launch has finished)
+    if (wv == 15) {
+        int part = 0;
+        if (p.compact)
+            for (int k0 = 0; k0 < f; k0 += 64) {
+                const int k = k0 + l;
+                part += (k < f) ? min(w.nvox[k], p.max_voxels) : 0;
+            }
+        part = wave_sum(part);
+        if (l == 0) s_base = p.compact ? part : f * p.max_voxels;
+    }
+    if (tile == 0 && f == 0 && t == 0) {              // the batch's offsets table (off the critical path)
         int b = 0;
         for (int k = 0; k < p.batch; ++k) {
             voxel_offsets[k] = p.compact ? b : k * p.max_voxels;
-            b += w.nvox[k];
+            b += min(w.nvox[k], p.max_voxels);
         }
         voxel_offsets[p.batch] = p.compact ? b : p.batch * p.max_voxels;
     }
-    const int nv = w.nvox[f];
-    if (r >= nv) return;
+    const unsigned long long bal = __ballot(word != 0);
+    if (l == 0) s_wcnt[wv] = __popcll(bal);
+    __syncthreads();
+    int r = 0;
+    for (int k = 0; k < (G * 32 + 63) / 64 && k < 16; ++k) r += s_part[k];
+    for (int k = 0; k < wv; ++k) r += s_wcnt[k];
+    r += __popcll(bal & lanemask_lt());
+    if (word == 0 || r >= p.max_voxels) return;       // not a first point / voxel beyond the cap (dropped with its points)
     const int cnt = word & VXL_MMASK;
     const int *lst = w.pfirst + (size_t)f * G * VXL_CAP + (word >> VXL_MBITS);
     const uint32_t nx = p.grid[0], ny = p.grid[1];
-    const size_t row = (size_t)base + r;
+    const size_t row = (size_t)s_base + r;
     float x0 = 0.f, y0 = 0.f, z0 = 0.f;
     if (C4) {
         const float4 *pts4 = reinterpret_cast<const float4 *>(points) + start;
         float4 *out4 = reinterpret_cast<float4 *>(voxels) + row * p.P;
-        for (int s0 = 0; s0 < cnt; s0 += 4) {              // up to 4 independent gathers in flight
+        out4[0] = me;                                  // slot 0 is this very point (the list is ascending, it is the first)
+        x0 = me.x; y0 = me.y; z0 = me.z;
+        for (int s0 = 1; s0 < cnt; s0 += 4) {          // up to 4 independent gathers in flight
             int pi[4];
-            float4 v[4];
+            float4 q[4];
 #pragma unroll
             for (int k = 0; k < 4; ++k) pi[k] = lst[min(s0 + k, cnt - 1)];
 #pragma unroll
-            for (int k = 0; k < 4; ++k) v[k] = pts4[pi[k]];
+            for (int k = 0; k < 4; ++k) q[k] = pts4[pi[k]];
 #pragma unroll
             for (int k = 0; k < 4; ++k)
-                if (s0 + k < cnt) out4[s0 + k] = v[k];
-            if (s0 == 0) { x0 = v[0].x; y0 = v[0].y; z0 = v[0].z; }
+                if (s0 + k < cnt) out4[s0 + k] = q[k];
         }
     } else {
         const float *pts = points + (size_t)start * p.C;
@@ -762,15 +758,10 @@ __global__ __launch_bounds__(256) void vxl_scatter_kernel(const float *__restric
             if (sl == 0) { x0 = q[0]; y0 = q[1]; z0 = q[2]; }
         }
     }
-    uint32_t key;                                          // slot 0 holds the voxel's first point: its cell gives the coords
+    uint32_t key;
     vx_cell(p, x0, y0, z0, key);
     reinterpret_cast<int4 *>(coords)[row] = make_int4(f, (int)(key / (nx * ny)), (int)((key / nx) % ny), (int)(key % nx));
     num_points[row] = cnt;
-}
-
-template <int ITEMS>
-static void vxl_rank_launch(int batch, hipStream_t s, const int *offsets, const VxParams &p, const VxWs &w) {
-    hipLaunchKernelGGL(vxl_rank_kernel<ITEMS>, dim3(batch), dim3(1024), 0, s, offsets, p, w);
 }
 
 static int vxl_bins(int n_max) { return divup(n_max, VXL_PTS_PER_BIN); }
@@ -799,14 +790,9 @@ static void vxl_run(const float *points, const int *point_offsets, const VxParam
     else if (items <= 16) hipLaunchKernelGGL(vxl_bin_kernel<16>, gb, dim3(1024), 0, s, point_offsets, p, w, G);
     else if (items <= 24) hipLaunchKernelGGL(vxl_bin_kernel<24>, gb, dim3(1024), 0, s, point_offsets, p, w, G);
     else hipLaunchKernelGGL(vxl_bin_kernel<32>, gb, dim3(1024), 0, s, point_offsets, p, w, G);
-    if (items <= 4) vxl_rank_launch<4>(p.batch, s, point_offsets, p, w);
-    else if (items <= 8) vxl_rank_launch<8>(p.batch, s, point_offsets, p, w);
-    else if (items <= 16) vxl_rank_launch<16>(p.batch, s, point_offsets, p, w);
-    else if (items <= 24) vxl_rank_launch<24>(p.batch, s, point_offsets, p, w);
-    else vxl_rank_launch<32>(p.batch, s, point_offsets, p, w);
-    const dim3 grow(divup(p.max_voxels, 256), p.batch);
-    if (c4) hipLaunchKernelGGL(vxl_scatter_kernel<true>, grow, dim3(256), 0, s, points, point_offsets, p, w, G, voxels, coords, num_points, voxel_offsets);
-    else hipLaunchKernelGGL(vxl_scatter_kernel<false>, grow, dim3(256), 0, s, points, point_offsets, p, w, G, voxels, coords, num_points, voxel_offsets);
+    const dim3 ge(ntiles, p.batch);
+    if (c4) hipLaunchKernelGGL(vxl_emit_kernel<true>, ge, dim3(1024), 0, s, points, point_offsets, p, w, G, voxels, coords, num_points, voxel_offsets);
+    else hipLaunchKernelGGL(vxl_emit_kernel<false>, ge, dim3(1024), 0, s, points, point_offsets, p, w, G, voxels, coords, num_points, voxel_offsets);
 }
 
 // ------------------------------------------------------------------ C ABI
