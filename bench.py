@@ -102,8 +102,15 @@ def main():
             out = model(pts, offs)
         barrier()
         ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(args.steps)]
+        ev0 = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(args.steps)]
+        for a, b in ev + ev0:       # torch creates the HIP event lazily at the first record(): do that outside the timed region
+            a.record()
+            b.record()
+        barrier()
         t0 = time.perf_counter()
         for k in range(args.steps):
+            ev0[k][0].record()                      # empty bracket: what a HIP event pair costs by itself at this point
+            ev0[k][1].record()
             ev[k][0].record()                       # same stream the kernels are launched on
             vox = model.voxelize(pts, offs)
             ev[k][1].record()
@@ -114,6 +121,7 @@ def main():
     dt = dist_utils.max_over_ranks(dt, dist, device)
 
     vox_ms = float(np.mean([a.elapsed_time(b) for a, b in ev]))
+    ev_overhead_ms = float(np.mean([a.elapsed_time(b) for a, b in ev0]))
     total_rows = int(vox["voxel_offsets"][-1].item())
     npts = int(offs[-1].item())
     P, C = 32, 4
@@ -137,7 +145,10 @@ def main():
                    "frames_per_step": args.batch, "replicas": world},
         "roofline": {"bound": "hbm", "kernel": "lidar_voxelize (vxl_key + zero-fill, vxl_bin, vxl_emit)",
                      "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
-                     "traffic": traffic, "alg_bytes_per_launch": alg_bytes, "ms_per_launch": vox_ms},
+                     "traffic": traffic, "alg_bytes_per_launch": alg_bytes, "ms_per_launch": vox_ms,
+                     # informational: an empty HIP event pair recorded at the same place (dispatch + marker latency that the
+                     # bracket above also contains); `frac` does NOT subtract it
+                     "event_pair_overhead_ms": ev_overhead_ms},
     }
     if args.stages and rank == 0:
         def gpu_time(fn, n=20):
