@@ -458,7 +458,7 @@ __global__ __launch_bounds__(1024) void vxl_key_kernel(const float *__restrict__
 #pragma unroll
         for (int k = 0; k < 4; ++k) {
             const long long i = c * VXL_FILL_F4_PER_WG + k * 1024 + threadIdx.x;
-            if (i < fill_f4_per_frame) dst[i] = z;
+            if (i < fill_f4_per_frame) dst[i] = z;       // plain stores: non-temporal ones measured slower (49.6 vs 43.9 us)
         }
         if (blockIdx.y == gridDim.y - 1 && c == 0 && (long long)threadIdx.x < fill_tail_floats)   // bytes past the last float4
             voxels[(long long)gridDim.y * fill_f4_per_frame * 4 + threadIdx.x] = 0.f;
