@@ -76,6 +76,12 @@ int lidar_mean_vfe(const float *voxels, const void *num_points, int num_voxels, 
  * canvas (batch, channels, ny, nx) f32, every element written exactly once. channels in {32,64,128}.
  * channels_last = 1 writes the same logical tensor with NHWC strides (torch.channels_last), which MIOpen's fp32
  * convolutions consume without layout transposes. */
+/* Resident-canvas variant: ONE persistent channels-last canvas (B, ny, nx, C); a call clears the cells the previous call wrote
+ * (prev_cells / prev_count: caller-owned state, num_voxels ints + 1 int; start with a zero canvas and *prev_count = 0) and
+ * writes the new pillars -- ~2*V*C*4 bytes instead of the whole canvas; the canvas equals a fresh PointPillarScatter output. */
+int lidar_pillar_scatter_update(const float *pillar_features, const void *coords, int coords_are_float, int num_voxels,
+                                const int *num_voxels_dev, int channels, int batch, int nx, int ny, float *canvas,
+                                int *prev_cells, int *prev_count, void *stream);
 size_t lidar_pillar_scatter_workspace_bytes(int batch, int nx, int ny);
 int lidar_pillar_scatter(const float *pillar_features, const void *coords, int coords_are_float, int num_voxels,
                          const int *num_voxels_dev, int channels, int batch, int nx, int ny, int channels_last,

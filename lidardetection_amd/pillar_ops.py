@@ -59,3 +59,27 @@ def pillar_scatter(pillar_features, coords, batch_size, nx, ny, num_voxels_dev=N
                                       _lib.ptr(ws), wsb,
                                       _lib.stream()), "lidar_pillar_scatter")
     return out
+
+
+class ResidentCanvas:
+    """One persistent channels-last BEV canvas (B, C, ny, nx) kept in HBM across calls: update() clears the cells the previous
+    call wrote and writes the new pillars (~2*V*C*4 bytes instead of rewriting the > 90 % zero canvas).  After update() the
+    canvas equals pillar_scatter(..., channels_last=True) of the same pillars."""
+
+    def __init__(self, batch_size, channels, ny, nx, max_pillars, device):
+        self.B, self.C, self.ny, self.nx, self.cap = batch_size, channels, ny, nx, int(max_pillars)
+        self.canvas = torch.zeros((batch_size, channels, ny, nx), dtype=torch.float32, device=device).contiguous(
+            memory_format=torch.channels_last)
+        self.prev_cells = torch.full((max(self.cap, 1),), -1, dtype=torch.int32, device=device)
+        self.prev_count = torch.zeros((1,), dtype=torch.int32, device=device)
+
+    def update(self, pillar_features, coords, num_voxels_dev=None):
+        _lib.require_cuda(pillar_features, coords)
+        V, C = pillar_features.shape
+        if C != self.C or V > self.cap:
+            raise _lib.LidarHipError("ResidentCanvas.update: feature width / pillar count exceeds what the canvas was built for")
+        _lib.check(_lib.lib().lidar_pillar_scatter_update(_lib.ptr(pillar_features), _lib.ptr(coords), int(coords.dtype == torch.float32), V,
+                                                          _lib.ptr(num_voxels_dev), C, self.B, self.nx, self.ny, _lib.ptr(self.canvas),
+                                                          _lib.ptr(self.prev_cells), _lib.ptr(self.prev_count), _lib.stream()),
+                   "lidar_pillar_scatter_update")
+        return self.canvas

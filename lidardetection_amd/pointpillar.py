@@ -131,11 +131,11 @@ class PointPillarKITTI(nn.Module):
         total = vox["voxel_offsets"][self.B:self.B + 1]
         feat = pillar_ops.pillar_vfe(vox["voxels"], vox["voxel_num_points"], vox["voxel_coords"], w, s, t,
                                      self.voxel_size, self.pc_range, num_voxels_dev=total)
-        if self._canvas is None or self._canvas.device != feat.device:      # persistent 877 MB canvas: no allocator churn per step
-            self._canvas = torch.empty((self.B, feat.shape[1], self.ny, self.nx), dtype=torch.float32, device=feat.device,
-                                       memory_format=torch.channels_last if self.channels_last else torch.contiguous_format)
-        return pillar_ops.pillar_scatter(feat, vox["voxel_coords"], self.B, self.nx, self.ny, num_voxels_dev=total,
-                                         out=self._canvas, channels_last=self.channels_last)
+        if self.channels_last:      # resident canvas: clear last step's cells, write this step's (130 MB instead of 877 MB)
+            if self._canvas is None:
+                self._canvas = pillar_ops.ResidentCanvas(self.B, feat.shape[1], self.ny, self.nx, vox["voxels"].shape[0], feat.device)
+            return self._canvas.update(feat, vox["voxel_coords"], num_voxels_dev=total)
+        return pillar_ops.pillar_scatter(feat, vox["voxel_coords"], self.B, self.nx, self.ny, num_voxels_dev=total)
 
     def backbone_head(self, canvas):
         if self.fold_bn:

@@ -342,3 +342,26 @@ def test_bev_backbone_and_box_decode_vs_reference_golden(dev, golden_dir):
     boxes = anchor_post.decode_topk(enc.view(1, n, 7).contiguous(), torch.arange(n, device=dev).view(1, n), anchors, 1, box_off=0,
                                     dir_off=0, num_dir_bins=0, dir_offset=0.0, dir_limit_offset=0.0)
     np.testing.assert_allclose(boxes[0].cpu().numpy(), g["decode_out"], rtol=2e-6, atol=1e-6)
+
+
+def test_resident_canvas_equals_fresh_scatter_over_successive_frames(dev):
+    """ResidentCanvas.update (clear last call's cells, write the new pillars) must leave exactly the canvas a fresh
+    PointPillarScatter produces, call after call, including shrinking / growing pillar sets and an invalid row."""
+    from lidardetection_amd import pillar_ops
+    B, C, ny, nx, cap = 3, 64, 40, 48, 900
+    rc = pillar_ops.ResidentCanvas(B, C, ny, nx, cap, dev)
+    g = torch.Generator(device="cpu").manual_seed(23)
+    for step, n in enumerate((700, 120, 900, 0, 333)):
+        cells = torch.randperm(B * ny * nx, generator=g)[:n]
+        b, rem = cells // (ny * nx), cells % (ny * nx)
+        coords = torch.stack([b, torch.zeros_like(b), rem // nx, rem % nx], 1).int()
+        if n > 5:
+            coords[3, 0] = B + 2                                         # a row outside the batch: ignored by both paths
+        feats = torch.randn(n, C, generator=g)
+        pad = cap - n                                                    # device-side count smaller than the buffer
+        coords_d = torch.cat([coords, torch.full((pad, 4), 7, dtype=torch.int32)], 0).to(dev)
+        feats_d = torch.cat([feats, torch.full((pad, C), 9.0)], 0).to(dev)
+        cnt = torch.tensor([n], dtype=torch.int32, device=dev)
+        got = rc.update(feats_d, coords_d, num_voxels_dev=cnt)
+        want = pillar_ops.pillar_scatter(feats_d, coords_d, B, nx, ny, num_voxels_dev=cnt, channels_last=True)
+        assert torch.equal(got, want), step
