@@ -1,133 +1,129 @@
-"""Mirror of pcdet/models/backbones_3d/spconv_backbone.py: post_act_block (:7-26), SparseBasicBlock (:29-65),
-VoxelBackBone8x (:68-163), VoxelResBackBone8x (:166-261) — built on lidardetection_amd.spconv.  Module / parameter
-names are the reference's, so its checkpoints (weight layout (kD,kH,kW,Cin,Cout)) load unchanged."""
+"""The reference's two sparse 3D backbones — VoxelBackBone8x and VoxelResBackBone8x (pcdet/models/backbones_3d/
+spconv_backbone.py:68-261), with its helper names `post_act_block` (:7-26) and `SparseBasicBlock` (:29-65) — built on
+lidardetection_amd.spconv.  The stage layout is written as data (`_PLAIN_STAGES` / `_RES_STAGES`) and assembled by one
+builder; module and parameter names come out exactly as the reference's, so its checkpoints (weight layout
+(kD, kH, kW, Cin, Cout)) load unchanged (`tests/test_cabi_and_host.py` compares the state_dict layouts).
+
+forward(): all rulebooks of the network are built first from the coordinates alone (the strided convs' output-count
+read-backs overlap the SubM table builds), then the feature pass runs without a host sync; under torch.no_grad() every
+conv + BatchNorm (+ residual) + ReLU is one launch (spconv.conv.forward_fused).
+"""
 from functools import partial
 
+import torch
 import torch.nn as nn
 
 from .... import spconv
 
+_CONV_KINDS = {
+    'subm': lambda cin, cout, k, stride, padding, key: spconv.SubMConv3d(cin, cout, k, bias=False, indice_key=key),
+    'spconv': lambda cin, cout, k, stride, padding, key: spconv.SparseConv3d(cin, cout, k, stride=stride, padding=padding,
+                                                                             bias=False, indice_key=key),
+    'inverseconv': lambda cin, cout, k, stride, padding, key: spconv.SparseInverseConv3d(cin, cout, k, indice_key=key, bias=False),
+}
+
 
 def post_act_block(in_channels, out_channels, kernel_size, indice_key=None, stride=1, padding=0, conv_type='subm', norm_fn=None):
-    if conv_type == 'subm':
-        conv = spconv.SubMConv3d(in_channels, out_channels, kernel_size, bias=False, indice_key=indice_key)
-    elif conv_type == 'spconv':
-        conv = spconv.SparseConv3d(in_channels, out_channels, kernel_size, stride=stride, padding=padding, bias=False,
-                                   indice_key=indice_key)
-    elif conv_type == 'inverseconv':
-        conv = spconv.SparseInverseConv3d(in_channels, out_channels, kernel_size, indice_key=indice_key, bias=False)
-    else:
-        raise NotImplementedError
+    """sparse conv of the requested kind + norm + ReLU as one SparseSequential"""
+    if conv_type not in _CONV_KINDS:
+        raise NotImplementedError(conv_type)
+    conv = _CONV_KINDS[conv_type](in_channels, out_channels, kernel_size, stride, padding, indice_key)
     return spconv.SparseSequential(conv, norm_fn(out_channels), nn.ReLU())
 
 
 class SparseBasicBlock(spconv.SparseModule):
+    """two 3x3x3 submanifold convs with an identity (or `downsample`) shortcut"""
     expansion = 1
 
     def __init__(self, inplanes, planes, stride=1, norm_fn=None, downsample=None, indice_key=None):
         super().__init__()
-        assert norm_fn is not None
-        bias = norm_fn is not None
-        self.conv1 = spconv.SubMConv3d(inplanes, planes, kernel_size=3, stride=stride, padding=1, bias=bias, indice_key=indice_key)
-        self.bn1 = norm_fn(planes)
+        if norm_fn is None:
+            raise AssertionError('SparseBasicBlock needs a norm_fn')
+        make_conv = partial(spconv.SubMConv3d, kernel_size=3, stride=stride, padding=1, bias=True, indice_key=indice_key)
+        self.conv1, self.bn1 = make_conv(inplanes, planes), norm_fn(planes)
         self.relu = nn.ReLU()
-        self.conv2 = spconv.SubMConv3d(planes, planes, kernel_size=3, stride=stride, padding=1, bias=bias, indice_key=indice_key)
-        self.bn2 = norm_fn(planes)
-        self.downsample = downsample
-        self.stride = stride
+        self.conv2, self.bn2 = make_conv(planes, planes), norm_fn(planes)
+        self.downsample, self.stride = downsample, stride
 
     def forward(self, x):
-        import torch
+        shortcut = x if self.downsample is None else self.downsample(x)
         if not torch.is_grad_enabled() and not self.bn1.training and x.indices.shape[0] != 0:
-            # inference: each conv + BN (+ residual) + ReLU is one launch (spconv.conv.forward_fused)
-            identity = x if self.downsample is None else self.downsample(x)
-            out = self.conv1.forward_fused(x, self.bn1, relu=True)
-            return self.conv2.forward_fused(out, self.bn2, relu=True, residual=identity.features)
-        identity = x
+            # inference: each conv + BN (+ shortcut) + ReLU is one launch
+            mid = self.conv1.forward_fused(x, self.bn1, relu=True)
+            return self.conv2.forward_fused(mid, self.bn2, relu=True, residual=shortcut.features)
         out = self.conv1(x)
         out.features = self.relu(self.bn1(out.features))
         out = self.conv2(out)
-        out.features = self.bn2(out.features)
-        if self.downsample is not None:
-            identity = self.downsample(x)
-        out.features = self.relu(out.features + identity.features)
+        out.features = self.relu(self.bn2(out.features) + shortcut.features)
         return out
 
 
+# stage name -> list of layers; ('down', cin, cout, padding) = strided SparseConv3d block, ('subm', c) = SubM block,
+# ('res', c) = SparseBasicBlock.  Strided blocks of stage N use indice_key spconvN, the others submN / resN.
+_PLAIN_STAGES = {
+    'conv1': [('subm', 16)],
+    'conv2': [('down', 16, 32, 1), ('subm', 32), ('subm', 32)],
+    'conv3': [('down', 32, 64, 1), ('subm', 64), ('subm', 64)],
+    'conv4': [('down', 64, 64, (0, 1, 1)), ('subm', 64), ('subm', 64)],
+}
+_RES_STAGES = {
+    'conv1': [('res', 16), ('res', 16)],
+    'conv2': [('down', 16, 32, 1), ('res', 32), ('res', 32)],
+    'conv3': [('down', 32, 64, 1), ('res', 64), ('res', 64)],
+    'conv4': [('down', 64, 128, (0, 1, 1)), ('res', 128), ('res', 128)],
+}
+_STAGE_ORDER = ('conv_input', 'conv1', 'conv2', 'conv3', 'conv4', 'conv_out')
+
+
 class _VoxelBackBoneBase(nn.Module):
-    def _finish(self, batch_dict, x_convs, out):
-        batch_dict.update({'encoded_spconv_tensor': out, 'encoded_spconv_tensor_stride': 8})
-        batch_dict.update({'multi_scale_3d_features': dict(zip(('x_conv1', 'x_conv2', 'x_conv3', 'x_conv4'), x_convs))})
-        return batch_dict
+    def _assemble(self, model_cfg, input_channels, grid_size, stages, out_in_channels):
+        self.model_cfg = model_cfg
+        norm = partial(nn.BatchNorm1d, eps=1e-3, momentum=0.01)
+        zyx = [int(v) for v in list(grid_size)[::-1]]
+        self.sparse_shape = [zyx[0] + 1, zyx[1], zyx[2]]          # one extra z slice, as the reference allocates
+        self.conv_input = spconv.SparseSequential(
+            spconv.SubMConv3d(input_channels, 16, 3, padding=1, bias=False, indice_key='subm1'), norm(16), nn.ReLU())
+        for name, layers in stages.items():
+            level = name[-1]
+            built = []
+            for spec in layers:
+                if spec[0] == 'down':
+                    _, cin, cout, pad = spec
+                    built.append(post_act_block(cin, cout, 3, norm_fn=norm, stride=2, padding=pad, indice_key='spconv' + level,
+                                                conv_type='spconv'))
+                elif spec[0] == 'subm':
+                    built.append(post_act_block(spec[1], spec[1], 3, norm_fn=norm, padding=1, indice_key='subm' + level))
+                else:
+                    built.append(SparseBasicBlock(spec[1], spec[1], norm_fn=norm, indice_key='res' + level))
+            setattr(self, name, spconv.SparseSequential(*built))
+        self.conv_out = spconv.SparseSequential(
+            spconv.SparseConv3d(out_in_channels, 128, (3, 1, 1), stride=(2, 1, 1), padding=model_cfg.get('last_pad', 0), bias=False,
+                                indice_key='spconv_down2'),
+            norm(128), nn.ReLU())
+        self.num_point_features = 128
 
     def forward(self, batch_dict):
         """batch_dict: batch_size, voxel_features (N, C), voxel_coords (N, 4) [b, z, y, x] (float or int)."""
-        sp = spconv.SparseConvTensor(features=batch_dict['voxel_features'], indices=batch_dict['voxel_coords'].int(),
-                                     spatial_shape=self.sparse_shape, batch_size=batch_dict['batch_size'])
-        # all rulebooks first (coordinates only; the 4 strided convs each read one int back), then a sync-free feature pass
-        stages = [getattr(self, name) for name in ('conv_input', 'conv1', 'conv2', 'conv3', 'conv4', 'conv_out')]
-        spconv.prebuild_rulebooks(stages, sp.indices.contiguous(), sp.spatial_shape, sp.batch_size, sp.indice_dict)
-        x = self.conv_input(sp)
-        x1 = self.conv1(x)
-        x2 = self.conv2(x1)
-        x3 = self.conv3(x2)
-        x4 = self.conv4(x3)
-        return self._finish(batch_dict, (x1, x2, x3, x4), self.conv_out(x4))
+        x = spconv.SparseConvTensor(features=batch_dict['voxel_features'], indices=batch_dict['voxel_coords'].int(),
+                                    spatial_shape=self.sparse_shape, batch_size=batch_dict['batch_size'])
+        stages = [getattr(self, name) for name in _STAGE_ORDER]
+        spconv.prebuild_rulebooks(stages, x.indices.contiguous(), x.spatial_shape, x.batch_size, x.indice_dict)
+        taps = {}
+        for name, stage in zip(_STAGE_ORDER, stages):
+            x = stage(x)
+            taps[name] = x
+        batch_dict.update({'encoded_spconv_tensor': x, 'encoded_spconv_tensor_stride': 8})
+        batch_dict.update({'multi_scale_3d_features': {'x_conv%d' % i: taps['conv%d' % i] for i in (1, 2, 3, 4)}})
+        return batch_dict
 
 
 class VoxelBackBone8x(_VoxelBackBoneBase):
     def __init__(self, model_cfg, input_channels, grid_size, **kwargs):
         super().__init__()
-        self.model_cfg = model_cfg
-        norm_fn = partial(nn.BatchNorm1d, eps=1e-3, momentum=0.01)
-        self.sparse_shape = [int(v) for v in (list(grid_size[::-1]))]
-        self.sparse_shape[0] += 1                                   # grid_size[::-1] + [1, 0, 0]
-        block = post_act_block
-        self.conv_input = spconv.SparseSequential(
-            spconv.SubMConv3d(input_channels, 16, 3, padding=1, bias=False, indice_key='subm1'), norm_fn(16), nn.ReLU())
-        self.conv1 = spconv.SparseSequential(block(16, 16, 3, norm_fn=norm_fn, padding=1, indice_key='subm1'))
-        self.conv2 = spconv.SparseSequential(
-            block(16, 32, 3, norm_fn=norm_fn, stride=2, padding=1, indice_key='spconv2', conv_type='spconv'),
-            block(32, 32, 3, norm_fn=norm_fn, padding=1, indice_key='subm2'),
-            block(32, 32, 3, norm_fn=norm_fn, padding=1, indice_key='subm2'))
-        self.conv3 = spconv.SparseSequential(
-            block(32, 64, 3, norm_fn=norm_fn, stride=2, padding=1, indice_key='spconv3', conv_type='spconv'),
-            block(64, 64, 3, norm_fn=norm_fn, padding=1, indice_key='subm3'),
-            block(64, 64, 3, norm_fn=norm_fn, padding=1, indice_key='subm3'))
-        self.conv4 = spconv.SparseSequential(
-            block(64, 64, 3, norm_fn=norm_fn, stride=2, padding=(0, 1, 1), indice_key='spconv4', conv_type='spconv'),
-            block(64, 64, 3, norm_fn=norm_fn, padding=1, indice_key='subm4'),
-            block(64, 64, 3, norm_fn=norm_fn, padding=1, indice_key='subm4'))
-        last_pad = self.model_cfg.get('last_pad', 0)
-        self.conv_out = spconv.SparseSequential(
-            spconv.SparseConv3d(64, 128, (3, 1, 1), stride=(2, 1, 1), padding=last_pad, bias=False, indice_key='spconv_down2'),
-            norm_fn(128), nn.ReLU())
-        self.num_point_features = 128
+        self._assemble(model_cfg, input_channels, grid_size, _PLAIN_STAGES, out_in_channels=64)
 
 
 class VoxelResBackBone8x(_VoxelBackBoneBase):
     def __init__(self, model_cfg, input_channels, grid_size, **kwargs):
         super().__init__()
-        self.model_cfg = model_cfg
-        norm_fn = partial(nn.BatchNorm1d, eps=1e-3, momentum=0.01)
-        self.sparse_shape = [int(v) for v in (list(grid_size[::-1]))]
-        self.sparse_shape[0] += 1
-        block = post_act_block
-        self.conv_input = spconv.SparseSequential(
-            spconv.SubMConv3d(input_channels, 16, 3, padding=1, bias=False, indice_key='subm1'), norm_fn(16), nn.ReLU())
-        self.conv1 = spconv.SparseSequential(SparseBasicBlock(16, 16, norm_fn=norm_fn, indice_key='res1'),
-                                             SparseBasicBlock(16, 16, norm_fn=norm_fn, indice_key='res1'))
-        self.conv2 = spconv.SparseSequential(
-            block(16, 32, 3, norm_fn=norm_fn, stride=2, padding=1, indice_key='spconv2', conv_type='spconv'),
-            SparseBasicBlock(32, 32, norm_fn=norm_fn, indice_key='res2'), SparseBasicBlock(32, 32, norm_fn=norm_fn, indice_key='res2'))
-        self.conv3 = spconv.SparseSequential(
-            block(32, 64, 3, norm_fn=norm_fn, stride=2, padding=1, indice_key='spconv3', conv_type='spconv'),
-            SparseBasicBlock(64, 64, norm_fn=norm_fn, indice_key='res3'), SparseBasicBlock(64, 64, norm_fn=norm_fn, indice_key='res3'))
-        self.conv4 = spconv.SparseSequential(
-            block(64, 128, 3, norm_fn=norm_fn, stride=2, padding=(0, 1, 1), indice_key='spconv4', conv_type='spconv'),
-            SparseBasicBlock(128, 128, norm_fn=norm_fn, indice_key='res4'), SparseBasicBlock(128, 128, norm_fn=norm_fn, indice_key='res4'))
-        last_pad = self.model_cfg.get('last_pad', 0)
-        self.conv_out = spconv.SparseSequential(
-            spconv.SparseConv3d(128, 128, (3, 1, 1), stride=(2, 1, 1), padding=last_pad, bias=False, indice_key='spconv_down2'),
-            norm_fn(128), nn.ReLU())
-        self.num_point_features = 128
+        self._assemble(model_cfg, input_channels, grid_size, _RES_STAGES, out_in_channels=128)

@@ -1,6 +1,9 @@
-"""Mirror of pcdet/ops/iou3d_nms/iou3d_nms_utils.py (same symbols, signatures and return types).
+"""Rotated-box IoU / NMS front-ends with the reference's public names, argument order and return types
+(pcdet/ops/iou3d_nms/iou3d_nms_utils.py:12-116), on top of lidardetection_amd.ext.iou3d_nms_cuda.
+Boxes are (N, 7) [x, y, z, dx, dy, dz, heading].
 
-boxes are (N, 7) [x, y, z, dx, dy, dz, heading].  The native module is lidardetection_amd.ext.iou3d_nms_cuda.
+The two NMS entry points use the batched device-resident kernel directly (one frame): the survivors never visit the
+host, unlike the reference's CPU `keep` tensor round trip.
 """
 import torch
 
@@ -8,62 +11,72 @@ from ...utils import common_utils
 from ....ext import iou3d_nms_cuda
 
 
+def _check7(*tensors):
+    for t in tensors:
+        if t.dim() != 2 or t.shape[1] != 7:
+            raise AssertionError('boxes must be (N, 7), got %s' % (tuple(t.shape),))
+
+
+def _pair_matrix(kernel, boxes_a, boxes_b):
+    """allocates the (N, M) result on the boxes' device and lets `kernel(a, b, out)` fill it"""
+    out = torch.zeros((boxes_a.shape[0], boxes_b.shape[0]), dtype=torch.float32, device=boxes_a.device)
+    kernel(boxes_a.contiguous(), boxes_b.contiguous(), out)
+    return out
+
+
 def boxes_bev_iou_cpu(boxes_a, boxes_b):
-    """iou3d_nms_utils.py:12-28 — CPU tensors / numpy in, (N, M) rotated BEV IoU out."""
-    boxes_a, is_numpy = common_utils.check_numpy_to_torch(boxes_a)
-    boxes_b, is_numpy = common_utils.check_numpy_to_torch(boxes_b)
-    assert not (boxes_a.is_cuda or boxes_b.is_cuda), 'Only support CPU tensors'
-    assert boxes_a.shape[1] == 7 and boxes_b.shape[1] == 7
-    ans_iou = boxes_a.new_zeros(torch.Size((boxes_a.shape[0], boxes_b.shape[0])))
-    iou3d_nms_cuda.boxes_iou_bev_cpu(boxes_a.contiguous(), boxes_b.contiguous(), ans_iou)
-    return ans_iou.numpy() if is_numpy else ans_iou
+    """host tensors or numpy arrays in, (N, M) rotated BEV IoU out in the same container type (reference :12-28)"""
+    a, from_numpy = common_utils.check_numpy_to_torch(boxes_a)
+    b, _ = common_utils.check_numpy_to_torch(boxes_b)
+    if a.is_cuda or b.is_cuda:
+        raise AssertionError('Only support CPU tensors')
+    _check7(a, b)
+    iou = _pair_matrix(iou3d_nms_cuda.boxes_iou_bev_cpu, a, b)
+    return iou.numpy() if from_numpy else iou
 
 
 def boxes_iou_bev(boxes_a, boxes_b):
-    """iou3d_nms_utils.py:31-45 -> (N, M) cuda float."""
-    assert boxes_a.shape[1] == boxes_b.shape[1] == 7
-    ans_iou = torch.zeros((boxes_a.shape[0], boxes_b.shape[0]), dtype=torch.float32, device=boxes_a.device)
-    iou3d_nms_cuda.boxes_iou_bev_gpu(boxes_a.contiguous(), boxes_b.contiguous(), ans_iou)
-    return ans_iou
+    """(N, 7) x (M, 7) device boxes -> (N, M) rotated BEV IoU (reference :31-45)"""
+    _check7(boxes_a, boxes_b)
+    return _pair_matrix(iou3d_nms_cuda.boxes_iou_bev_gpu, boxes_a, boxes_b)
+
+
+def _z_range(boxes):
+    half = boxes[:, 5] * 0.5
+    return boxes[:, 2] - half, boxes[:, 2] + half
 
 
 def boxes_iou3d_gpu(boxes_a, boxes_b):
-    """iou3d_nms_utils.py:48-81 -> (N, M) 3D IoU = BEV overlap x height overlap / union volume."""
-    assert boxes_a.shape[1] == boxes_b.shape[1] == 7
-    boxes_a_height_max = (boxes_a[:, 2] + boxes_a[:, 5] / 2).view(-1, 1)
-    boxes_a_height_min = (boxes_a[:, 2] - boxes_a[:, 5] / 2).view(-1, 1)
-    boxes_b_height_max = (boxes_b[:, 2] + boxes_b[:, 5] / 2).view(1, -1)
-    boxes_b_height_min = (boxes_b[:, 2] - boxes_b[:, 5] / 2).view(1, -1)
+    """(N, M) 3D IoU = rotated BEV overlap area x overlap along z / union volume (reference :48-81)"""
+    _check7(boxes_a, boxes_b)
+    area = _pair_matrix(iou3d_nms_cuda.boxes_overlap_bev_gpu, boxes_a, boxes_b)
+    lo_a, hi_a = _z_range(boxes_a)
+    lo_b, hi_b = _z_range(boxes_b)
+    dz = (torch.min(hi_a[:, None], hi_b[None, :]) - torch.max(lo_a[:, None], lo_b[None, :])).clamp(min=0)
+    shared = area * dz
+    volume = lambda t: t[:, 3] * t[:, 4] * t[:, 5]
+    union = (volume(boxes_a)[:, None] + volume(boxes_b)[None, :] - shared).clamp(min=1e-6)
+    return shared / union
 
-    overlaps_bev = torch.zeros((boxes_a.shape[0], boxes_b.shape[0]), dtype=torch.float32, device=boxes_a.device)
-    iou3d_nms_cuda.boxes_overlap_bev_gpu(boxes_a.contiguous(), boxes_b.contiguous(), overlaps_bev)
 
-    max_of_min = torch.max(boxes_a_height_min, boxes_b_height_min)
-    min_of_max = torch.min(boxes_a_height_max, boxes_b_height_max)
-    overlaps_h = torch.clamp(min_of_max - max_of_min, min=0)
-    overlaps_3d = overlaps_bev * overlaps_h
-    vol_a = (boxes_a[:, 3] * boxes_a[:, 4] * boxes_a[:, 5]).view(-1, 1)
-    vol_b = (boxes_b[:, 3] * boxes_b[:, 4] * boxes_b[:, 5]).view(1, -1)
-    return overlaps_3d / torch.clamp(vol_a + vol_b - overlaps_3d, min=1e-6)
+def _greedy_nms(boxes, scores, thresh, pre_maxsize, axis_aligned):
+    _check7(boxes)
+    ranking = torch.argsort(scores, dim=0, descending=True)
+    if pre_maxsize is not None:
+        ranking = ranking[:pre_maxsize]
+    if ranking.numel() == 0:
+        return ranking, None
+    ordered = boxes[ranking].contiguous()
+    keep, count = iou3d_nms_cuda.nms_batch(ordered.unsqueeze(0), None, thresh, normal=axis_aligned)
+    survivors = keep[0, :int(count[0])]
+    return ranking[survivors].contiguous(), None
 
 
 def nms_gpu(boxes, scores, thresh, pre_maxsize=None, **kwargs):
-    """iou3d_nms_utils.py:84-99 -> (kept indices into `boxes` (cuda int64), None)."""
-    assert boxes.shape[1] == 7
-    order = scores.sort(0, descending=True)[1]
-    if pre_maxsize is not None:
-        order = order[:pre_maxsize]
-    boxes = boxes[order].contiguous()
-    keep = torch.LongTensor(boxes.size(0))
-    num_out = iou3d_nms_cuda.nms_gpu(boxes, keep, thresh)
-    return order[keep[:num_out].to(boxes.device)].contiguous(), None
+    """rotated-IoU NMS: indices of the kept boxes, best first, and None (reference :84-99)"""
+    return _greedy_nms(boxes, scores, thresh, pre_maxsize, axis_aligned=False)
 
 
 def nms_normal_gpu(boxes, scores, thresh, **kwargs):
-    """iou3d_nms_utils.py:102-116 (axis-aligned BEV IoU)."""
-    assert boxes.shape[1] == 7
-    order = scores.sort(0, descending=True)[1]
-    boxes = boxes[order].contiguous()
-    keep = torch.LongTensor(boxes.size(0))
-    num_out = iou3d_nms_cuda.nms_normal_gpu(boxes, keep, thresh)
-    return order[keep[:num_out].to(boxes.device)].contiguous(), None
+    """the same with the axis-aligned BEV IoU of the enclosing rectangles (reference :102-116)"""
+    return _greedy_nms(boxes, scores, thresh, None, axis_aligned=True)

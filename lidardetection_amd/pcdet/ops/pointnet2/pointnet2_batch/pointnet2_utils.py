@@ -1,32 +1,29 @@
-"""Mirror of pcdet/ops/pointnet2/pointnet2_batch/pointnet2_utils.py (dense-batch PointNet++ operators:
-xyz are (B, N, 3), features are channel-major (B, C, N)).  Same public symbols: furthest_point_sample,
-gather_operation, three_nn, three_interpolate, grouping_operation, ball_query, QueryAndGroup, GroupAll.
+"""Dense-batch PointNet++ operators under the reference's public names (pcdet/ops/pointnet2/pointnet2_batch/
+pointnet2_utils.py:10-290): furthest_point_sample, gather_operation, three_nn, three_interpolate, grouping_operation,
+ball_query, QueryAndGroup, GroupAll.  Coordinates are (B, N, 3), features channel-major (B, C, N).
 Native module: lidardetection_amd.ext.pointnet2_batch_cuda."""
 import torch
 import torch.nn as nn
 from torch.autograd import Function
 
+from .. import _common as C
 from .....ext import pointnet2_batch_cuda as pointnet2
 
 
-def _new(shape, dtype, device, zero=False):
-    return (torch.zeros if zero else torch.empty)(shape, dtype=dtype, device=device)
-
-
 class FurthestPointSampling(Function):
-    """pointnet2_utils.py:10-36 — xyz (B, N, 3) -> (B, npoint) int32."""
+    """xyz (B, N, 3) -> (B, npoint) int32"""
 
     @staticmethod
     def forward(ctx, xyz, npoint):
-        assert xyz.is_contiguous()
-        B, N, _ = xyz.size()
-        output = _new((B, npoint), torch.int32, xyz.device)
-        temp = torch.full((B, N), 1e10, dtype=torch.float32, device=xyz.device)
-        pointnet2.furthest_point_sampling_wrapper(B, N, npoint, xyz, temp, output)
-        return output
+        C.require_contiguous(xyz)
+        n_batch, n_pts = xyz.shape[:2]
+        picked = C.empty_i32((n_batch, npoint), xyz.device)
+        running = torch.full((n_batch, n_pts), 1e10, dtype=torch.float32, device=xyz.device)
+        pointnet2.furthest_point_sampling_wrapper(n_batch, n_pts, npoint, xyz, running, picked)
+        return picked
 
     @staticmethod
-    def backward(xyz, a=None):
+    def backward(ctx, *unused):
         return None, None
 
 
@@ -34,24 +31,24 @@ furthest_point_sample = FurthestPointSampling.apply
 
 
 class GatherOperation(Function):
-    """pointnet2_utils.py:39-73 — features (B, C, N), idx (B, npoint) -> (B, C, npoint)."""
+    """features (B, C, N) picked at idx (B, npoint) -> (B, C, npoint); differentiable in the features"""
 
     @staticmethod
     def forward(ctx, features, idx):
-        assert features.is_contiguous() and idx.is_contiguous()
-        B, npoint = idx.size()
-        _, C, N = features.size()
-        output = _new((B, C, npoint), torch.float32, features.device)
-        pointnet2.gather_points_wrapper(B, C, N, npoint, features, idx, output)
-        ctx.for_backwards = (idx, C, N)
-        return output
+        C.require_contiguous(features, idx)
+        n_batch, width, n_src = features.shape
+        n_pick = idx.shape[1]
+        out = C.empty_f32((n_batch, width, n_pick), features.device)
+        pointnet2.gather_points_wrapper(n_batch, width, n_src, n_pick, features, idx, out)
+        ctx.gather_state = (idx, width, n_src)
+        return out
 
     @staticmethod
     def backward(ctx, grad_out):
-        idx, C, N = ctx.for_backwards
-        B, npoint = idx.size()
-        grad_features = _new((B, C, N), torch.float32, grad_out.device, zero=True)
-        pointnet2.gather_points_grad_wrapper(B, C, N, npoint, grad_out.detach().contiguous(), idx, grad_features)
+        idx, width, n_src = ctx.gather_state
+        n_batch, n_pick = idx.shape
+        grad_features = C.zeros_f32((n_batch, width, n_src), grad_out.device)
+        pointnet2.gather_points_grad_wrapper(n_batch, width, n_src, n_pick, grad_out.detach().contiguous(), idx, grad_features)
         return grad_features, None
 
 
@@ -59,20 +56,19 @@ gather_operation = GatherOperation.apply
 
 
 class ThreeNN(Function):
-    """pointnet2_utils.py:76-104 — unknown (B, n, 3), known (B, m, 3) -> (dist (B, n, 3), idx (B, n, 3) int32)."""
+    """unknown (B, n, 3), known (B, m, 3) -> (distances (B, n, 3), indices into known (B, n, 3) int32)"""
 
     @staticmethod
     def forward(ctx, unknown, known):
-        assert unknown.is_contiguous() and known.is_contiguous()
-        B, N, _ = unknown.size()
-        m = known.size(1)
-        dist2 = _new((B, N, 3), torch.float32, unknown.device)
-        idx = _new((B, N, 3), torch.int32, unknown.device)
-        pointnet2.three_nn_wrapper(B, N, m, unknown, known, dist2, idx)
-        return torch.sqrt(dist2), idx
+        C.require_contiguous(unknown, known)
+        n_batch, n_unknown = unknown.shape[:2]
+        d2 = C.empty_f32((n_batch, n_unknown, 3), unknown.device)
+        idx = C.empty_i32((n_batch, n_unknown, 3), unknown.device)
+        pointnet2.three_nn_wrapper(n_batch, n_unknown, known.shape[1], unknown, known, d2, idx)
+        return d2.sqrt(), idx
 
     @staticmethod
-    def backward(ctx, a=None, b=None):
+    def backward(ctx, *unused):
         return None, None
 
 
@@ -80,24 +76,25 @@ three_nn = ThreeNN.apply
 
 
 class ThreeInterpolate(Function):
-    """pointnet2_utils.py:108-152 — features (B, c, m), idx/weight (B, n, 3) -> (B, c, n)."""
+    """features (B, c, m) blended through idx / weight (B, n, 3) -> (B, c, n); differentiable in the features"""
 
     @staticmethod
     def forward(ctx, features, idx, weight):
-        assert features.is_contiguous() and idx.is_contiguous() and weight.is_contiguous()
-        B, c, m = features.size()
-        n = idx.size(1)
-        ctx.three_interpolate_for_backward = (idx, weight, m)
-        output = _new((B, c, n), torch.float32, features.device)
-        pointnet2.three_interpolate_wrapper(B, c, m, n, features, idx, weight, output)
-        return output
+        C.require_contiguous(features, idx, weight)
+        n_batch, width, n_known = features.shape
+        n_out = idx.shape[1]
+        ctx.interp_state = (idx, weight, n_known)
+        out = C.empty_f32((n_batch, width, n_out), features.device)
+        pointnet2.three_interpolate_wrapper(n_batch, width, n_known, n_out, features, idx, weight, out)
+        return out
 
     @staticmethod
     def backward(ctx, grad_out):
-        idx, weight, m = ctx.three_interpolate_for_backward
-        B, c, n = grad_out.size()
-        grad_features = _new((B, c, m), torch.float32, grad_out.device, zero=True)
-        pointnet2.three_interpolate_grad_wrapper(B, c, n, m, grad_out.detach().contiguous(), idx, weight, grad_features)
+        idx, weight, n_known = ctx.interp_state
+        n_batch, width, n_out = grad_out.shape
+        grad_features = C.zeros_f32((n_batch, width, n_known), grad_out.device)
+        pointnet2.three_interpolate_grad_wrapper(n_batch, width, n_out, n_known, grad_out.detach().contiguous(), idx, weight,
+                                                 grad_features)
         return grad_features, None, None
 
 
@@ -105,24 +102,25 @@ three_interpolate = ThreeInterpolate.apply
 
 
 class GroupingOperation(Function):
-    """pointnet2_utils.py:156-196 — features (B, C, N), idx (B, npoint, nsample) -> (B, C, npoint, nsample)."""
+    """features (B, C, N) gathered through idx (B, npoint, nsample) -> (B, C, npoint, nsample); differentiable"""
 
     @staticmethod
     def forward(ctx, features, idx):
-        assert features.is_contiguous() and idx.is_contiguous()
-        B, nfeatures, nsample = idx.size()
-        _, C, N = features.size()
-        output = _new((B, C, nfeatures, nsample), torch.float32, features.device)
-        pointnet2.group_points_wrapper(B, C, N, nfeatures, nsample, features, idx, output)
-        ctx.for_backwards = (idx, N)
-        return output
+        C.require_contiguous(features, idx)
+        n_batch, n_centre, nsample = idx.shape
+        width, n_src = features.shape[1:]
+        out = C.empty_f32((n_batch, width, n_centre, nsample), features.device)
+        pointnet2.group_points_wrapper(n_batch, width, n_src, n_centre, nsample, features, idx, out)
+        ctx.group_state = (idx, n_src)
+        return out
 
     @staticmethod
     def backward(ctx, grad_out):
-        idx, N = ctx.for_backwards
-        B, C, npoint, nsample = grad_out.size()
-        grad_features = _new((B, C, N), torch.float32, grad_out.device, zero=True)
-        pointnet2.group_points_grad_wrapper(B, C, N, npoint, nsample, grad_out.detach().contiguous(), idx, grad_features)
+        idx, n_src = ctx.group_state
+        n_batch, width, n_centre, nsample = grad_out.shape
+        grad_features = C.zeros_f32((n_batch, width, n_src), grad_out.device)
+        pointnet2.group_points_grad_wrapper(n_batch, width, n_src, n_centre, nsample, grad_out.detach().contiguous(), idx,
+                                            grad_features)
         return grad_features, None
 
 
@@ -130,27 +128,33 @@ grouping_operation = GroupingOperation.apply
 
 
 class BallQuery(Function):
-    """pointnet2_utils.py:200-225 — (B, npoint, nsample) int32; an empty ball keeps the zero fill (no sentinel)."""
+    """(B, npoint, nsample) int32 neighbour indices; a ball without neighbours keeps the zero fill (no marker in this variant)"""
 
     @staticmethod
     def forward(ctx, radius, nsample, xyz, new_xyz):
-        assert new_xyz.is_contiguous() and xyz.is_contiguous()
-        B, N, _ = xyz.size()
-        npoint = new_xyz.size(1)
-        idx = _new((B, npoint, nsample), torch.int32, xyz.device, zero=True)
-        pointnet2.ball_query_wrapper(B, N, npoint, radius, nsample, new_xyz, xyz, idx)
+        C.require_contiguous(new_xyz, xyz)
+        n_batch, n_src = xyz.shape[:2]
+        n_centre = new_xyz.shape[1]
+        idx = C.zeros_i32((n_batch, n_centre, nsample), xyz.device)
+        pointnet2.ball_query_wrapper(n_batch, n_src, n_centre, radius, nsample, new_xyz, xyz, idx)
         return idx
 
     @staticmethod
-    def backward(ctx, a=None):
-        return None, None, None, None
+    def backward(ctx, *unused):
+        return (None,) * 4
 
 
 ball_query = BallQuery.apply
 
 
+def _with_coordinates(offsets, gathered, use_xyz):
+    if gathered is None:
+        return offsets
+    return torch.cat((offsets, gathered), dim=1) if use_xyz else gathered
+
+
 class QueryAndGroup(nn.Module):
-    """pointnet2_utils.py:228-262 — -> (B, 3 + C, npoint, nsample)."""
+    """ball query around new_xyz, neighbours' offsets (and features) -> (B, 3 [+ C], npoint, nsample)"""
 
     def __init__(self, radius, nsample, use_xyz=True):
         super().__init__()
@@ -158,25 +162,19 @@ class QueryAndGroup(nn.Module):
 
     def forward(self, xyz, new_xyz, features=None):
         idx = ball_query(self.radius, self.nsample, xyz, new_xyz)
-        grouped_xyz = grouping_operation(xyz.transpose(1, 2).contiguous(), idx)      # (B, 3, npoint, nsample)
-        grouped_xyz -= new_xyz.transpose(1, 2).unsqueeze(-1)
-        if features is None:
-            assert self.use_xyz, "Cannot have not features and not use xyz as a feature!"
-            return grouped_xyz
-        grouped_features = grouping_operation(features, idx)
-        return torch.cat([grouped_xyz, grouped_features], dim=1) if self.use_xyz else grouped_features
+        offsets = grouping_operation(xyz.transpose(1, 2).contiguous(), idx) - new_xyz.transpose(1, 2).unsqueeze(-1)
+        if features is None and not self.use_xyz:
+            raise AssertionError('nothing to group: no features and use_xyz=False')
+        return _with_coordinates(offsets, None if features is None else grouping_operation(features, idx), self.use_xyz)
 
 
 class GroupAll(nn.Module):
-    """pointnet2_utils.py:265-290 — groups everything: (B, C + 3, 1, N)."""
+    """one group holding every point: (B, 3 [+ C], 1, N)"""
 
     def __init__(self, use_xyz=True):
         super().__init__()
         self.use_xyz = use_xyz
 
     def forward(self, xyz, new_xyz, features=None):
-        grouped_xyz = xyz.transpose(1, 2).unsqueeze(2)
-        if features is None:
-            return grouped_xyz
-        grouped_features = features.unsqueeze(2)
-        return torch.cat([grouped_xyz, grouped_features], dim=1) if self.use_xyz else grouped_features
+        coords = xyz.transpose(1, 2).unsqueeze(2)
+        return _with_coordinates(coords, None if features is None else features.unsqueeze(2), self.use_xyz)

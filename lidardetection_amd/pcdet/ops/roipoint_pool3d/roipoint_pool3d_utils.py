@@ -1,35 +1,38 @@
-"""Mirror of pcdet/ops/roipoint_pool3d/roipoint_pool3d_utils.py: RoIPointPool3d, RoIPointPool3dFunction.
-Native module: lidardetection_amd.ext.roipoint_pool3d_cuda."""
+"""Point-cloud RoI pooling under the reference's public names (pcdet/ops/roipoint_pool3d/roipoint_pool3d_utils.py:9-59),
+bound to lidardetection_amd.ext.roipoint_pool3d_cuda: for every (enlarged) box, the first `num_sampled_points` points
+inside it, cycled when there are fewer, with their features; boxes without points are flagged.
+"""
+import torch
 import torch.nn as nn
 from torch.autograd import Function
 
 from ...utils import box_utils
-from ....ext import roipoint_pool3d_cuda
-
-
-class RoIPointPool3d(nn.Module):
-    def __init__(self, num_sampled_points=512, pool_extra_width=1.0):
-        super().__init__()
-        self.num_sampled_points = num_sampled_points
-        self.pool_extra_width = pool_extra_width
-
-    def forward(self, points, point_features, boxes3d):
-        """points (B,N,3), point_features (B,N,C), boxes3d (B,M,7) -> pooled (B,M,S,3+C), empty_flag (B,M)."""
-        return RoIPointPool3dFunction.apply(points, point_features, boxes3d, self.pool_extra_width, self.num_sampled_points)
+from ....ext import roipoint_pool3d_cuda as _native
 
 
 class RoIPointPool3dFunction(Function):
     @staticmethod
     def forward(ctx, points, point_features, boxes3d, pool_extra_width, num_sampled_points=512):
-        assert points.shape.__len__() == 3 and points.shape[2] == 3
-        batch_size, boxes_num, feature_len = points.shape[0], boxes3d.shape[1], point_features.shape[2]
-        pooled_boxes3d = box_utils.enlarge_box3d(boxes3d.view(-1, 7), pool_extra_width).view(batch_size, -1, 7)
-        pooled_features = point_features.new_zeros((batch_size, boxes_num, num_sampled_points, 3 + feature_len))
-        pooled_empty_flag = point_features.new_zeros((batch_size, boxes_num)).int()
-        roipoint_pool3d_cuda.forward(points.contiguous(), pooled_boxes3d.contiguous(), point_features.contiguous(),
-                                     pooled_features, pooled_empty_flag)
-        return pooled_features, pooled_empty_flag
+        """points (B, N, 3), point_features (B, N, C), boxes3d (B, M, 7)
+        -> pooled (B, M, num_sampled_points, 3 + C), empty flag (B, M) int32"""
+        if points.dim() != 3 or points.shape[2] != 3:
+            raise AssertionError('points must be (B, N, 3)')
+        n_batch, n_box, n_feat = points.shape[0], boxes3d.shape[1], point_features.shape[2]
+        grown = box_utils.enlarge_box3d(boxes3d.reshape(-1, 7), pool_extra_width).reshape(n_batch, n_box, 7)
+        pooled = point_features.new_zeros((n_batch, n_box, num_sampled_points, 3 + n_feat))
+        empty = torch.zeros((n_batch, n_box), dtype=torch.int32, device=point_features.device)
+        _native.forward(points.contiguous(), grown.contiguous(), point_features.contiguous(), pooled, empty)
+        return pooled, empty
 
     @staticmethod
     def backward(ctx, grad_out):
-        raise NotImplementedError
+        raise NotImplementedError    # the reference defines no gradient for this op either
+
+
+class RoIPointPool3d(nn.Module):
+    def __init__(self, num_sampled_points=512, pool_extra_width=1.0):
+        super().__init__()
+        self.num_sampled_points, self.pool_extra_width = num_sampled_points, pool_extra_width
+
+    def forward(self, points, point_features, boxes3d):
+        return RoIPointPool3dFunction.apply(points, point_features, boxes3d, self.pool_extra_width, self.num_sampled_points)
