@@ -64,6 +64,8 @@ struct VxWs {
     uint32_t *vcell; // [B][max_voxels]
     int *tile_sums;  // [B][ntiles][2]
     int *nvox;       // [B]
+    int *fillst;     // [2] LDS path, compact mode: [0] rows the NEXT call should pre-clear (last total + 25 % + 1024),
+                     //     [1] the value this call's fill role used (copied by the bin launch; read by the emit launch)
 };
 
 
@@ -101,6 +103,7 @@ static size_t vx_carve(void *base, int B, int n_max, int max_voxels, VxWs *w) {
     p = take((size_t)B * max_voxels * 4); if (w) w->vcell = (uint32_t *)p;
     p = take((size_t)B * ntiles * 2 * 4); if (w) w->tile_sums = (int *)p;
     p = take((size_t)B * 4); if (w) w->nvox = (int *)p;
+    p = take(256); if (w) w->fillst = (int *)p;
     return off;
 }
 
@@ -118,7 +121,10 @@ __global__ void vx_ws_init_kernel(VxWs w, long long nh, long long nl, long long 
         w.list[k] = VX_INF;
         w.pslot[k] = -1;
     }
-    if (i == 0) *w.err = 0;
+    if (i == 0) {
+        *w.err = 0;
+        w.fillst[0] = w.fillst[1] = 0x7fffffff;     // no history yet: clear the whole buffer
+    }
 }
 
 // ------------------------------------------------------------------ K1: hash insert
@@ -454,11 +460,18 @@ __global__ __launch_bounds__(1024) void vxl_key_kernel(const float *__restrict__
     if ((int)blockIdx.x >= ntiles) {     // ---- zero-fill role (block-uniform)
         const long long c = (long long)blockIdx.x - ntiles;
         float4 *dst = reinterpret_cast<float4 *>(voxels) + (long long)blockIdx.y * fill_f4_per_frame;
+        // compact layout: only the rows a call can plausibly produce are cleared here — the previous call's total + 25 % (kept
+        // in the workspace, no host involvement); rows beyond that are written whole by their emit thread (rare)
+        const long long lim_rows = p.compact ? (long long)w.fillst[0] : 0x7fffffffll;
+        const long long lim_f4 = (lim_rows >= 0x7fffffffll) ? (1ll << 62) : (lim_rows * p.P * p.C + 3) / 4;
+        const long long g0 = (long long)blockIdx.y * fill_f4_per_frame + c * VXL_FILL_F4_PER_WG;
+        if (g0 >= lim_f4) return;
         const float4 z = make_float4(0.f, 0.f, 0.f, 0.f);
 #pragma unroll
         for (int k = 0; k < 4; ++k) {
             const long long i = c * VXL_FILL_F4_PER_WG + k * 1024 + threadIdx.x;
-            if (i < fill_f4_per_frame) dst[i] = z;       // plain stores: non-temporal ones measured slower (49.6 vs 43.9 us)
+            if (i < fill_f4_per_frame && g0 + k * 1024 + threadIdx.x < lim_f4)
+                dst[i] = z;                              // plain stores: non-temporal ones measured slower (49.6 vs 43.9 us)
         }
         if (blockIdx.y == gridDim.y - 1 && c == 0 && (long long)threadIdx.x < fill_tail_floats)   // bytes past the last float4
             voxels[(long long)gridDim.y * fill_f4_per_frame * 4 + threadIdx.x] = 0.f;
@@ -521,6 +534,7 @@ __global__ __launch_bounds__(1024) void vxl_bin_kernel(const int *__restrict__ o
     const int g = blockIdx.x, f = blockIdx.y, t = threadIdx.x, l = t & 63, wv = t >> 6;
     const int n = min(offsets[f + 1] - offsets[f], p.n_max);
     if (t < 32) s_tc[t] = 0;
+    if (g == 0 && f == 0 && t == 0) w.fillst[1] = w.fillst[0];   // what the fill role of THIS call used; the emit launch reads it
     // ---- phase B1 (loads): my bin's (point, key) pairs from the ITEMS tile segments written by K0.
     // Counts and the first 256 entries of every segment are requested together (one memory round trip,
     // overlapped with the LDS initialisation below); longer segments are topped up afterwards.
@@ -719,7 +733,11 @@ __global__ __launch_bounds__(1024) void vxl_emit_kernel(const float *__restrict_
             b += min(w.nvox[k], p.max_voxels);
         }
         voxel_offsets[p.batch] = p.compact ? b : p.batch * p.max_voxels;
+        // rows the next call's fill role should clear up front (nobody reads fillst[0] during this launch)
+        const long long next = (long long)b + b / 4 + 1024;
+        w.fillst[0] = p.compact ? (int)min(next, (long long)p.batch * p.max_voxels) : 0x7fffffff;
     }
+    const long long cleared_rows = p.compact ? (long long)w.fillst[1] : 0x7fffffffll;
     const unsigned long long bal = __ballot(word != 0);
     if (l == 0) s_wcnt[wv] = __popcll(bal);
     __syncthreads();
@@ -737,6 +755,8 @@ __global__ __launch_bounds__(1024) void vxl_emit_kernel(const float *__restrict_
         const float4 *pts4 = reinterpret_cast<const float4 *>(points) + start;
         float4 *out4 = reinterpret_cast<float4 *>(voxels) + row * p.P;
         out4[0] = me;                                  // slot 0 is this very point (the list is ascending, it is the first)
+        if ((long long)row >= cleared_rows)            // beyond what the fill role cleared: this thread owns the whole row
+            for (int sl = cnt; sl < p.P; ++sl) out4[sl] = make_float4(0.f, 0.f, 0.f, 0.f);
         x0 = me.x; y0 = me.y; z0 = me.z;
         for (int s0 = 1; s0 < cnt; s0 += 4) {          // up to 4 independent gathers in flight
             int pi[4];
@@ -757,6 +777,8 @@ __global__ __launch_bounds__(1024) void vxl_emit_kernel(const float *__restrict_
             for (int c = 0; c < p.C; ++c) out[sl * p.C + c] = q[c];
             if (sl == 0) { x0 = q[0]; y0 = q[1]; z0 = q[2]; }
         }
+        if ((long long)row >= cleared_rows)
+            for (int e = cnt * p.C; e < p.P * p.C; ++e) out[e] = 0.f;
     }
     uint32_t key;
     vx_cell(p, x0, y0, z0, key);

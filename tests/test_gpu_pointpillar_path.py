@@ -365,3 +365,30 @@ def test_resident_canvas_equals_fresh_scatter_over_successive_frames(dev):
         got = rc.update(feats_d, coords_d, num_voxels_dev=cnt)
         want = pillar_ops.pillar_scatter(feats_d, coords_d, B, nx, ny, num_voxels_dev=cnt, channels_last=True)
         assert torch.equal(got, want), step
+
+
+def test_voxelize_adaptive_fill_over_successive_calls(dev):
+    """The LDS-binned path pre-clears only as many rows as the previous call produced (+25 %); rows beyond that are written whole
+    by their emit thread.  Alternate sparse and dense batches through ONE voxeliser whose output buffer is poisoned with NaN
+    before every call: every row a call reports must be exact (zero padding included)."""
+    P, maxv = 32, 16000
+    vz = BatchVoxelizer(synth.PP_VOXEL, synth.PP_RANGE, P, maxv, 4)
+    sparse = [synth.cloud_ring(2000 + f) for f in range(3)]
+    dense = [synth.cloud_uniform(1000 + f) for f in range(3)]
+    tiny = [synth.cloud_uniform(1100 + f)[:500] for f in range(3)]
+    for step, frames in enumerate((sparse, dense, sparse, tiny, dense, dense)):
+        sizes = [len(f) for f in frames]
+        pts = torch.from_numpy(np.concatenate(frames)).to(dev)
+        offs = torch.tensor(np.concatenate([[0], np.cumsum(sizes)]), dtype=torch.int32, device=dev)
+        out = vz.alloc_outputs(len(frames), dev)
+        out["voxels"].fill_(float("nan"))
+        o = vz(pts, offs, 20000, compact=True, out=out)                   # same n_max every call: same workspace
+        offsets = o["voxel_offsets"].cpu().numpy()
+        for f, pf in enumerate(frames):
+            vo, co, nu = c_oracle.voxelize(pf, synth.PP_VOXEL, synth.PP_RANGE, P, maxv)
+            a, b = int(offsets[f]), int(offsets[f + 1])
+            assert b - a == len(vo), (step, f)
+            assert np.array_equal(o["voxels"][a:b].cpu().numpy(), vo), (step, f)
+            assert np.array_equal(o["voxel_num_points"][a:b].cpu().numpy(), nu)
+            assert np.array_equal(o["voxel_coords"][a:b, 1:].cpu().numpy(), co)
+        assert vz.error_flag(len(frames), 20000, dev) == 0
