@@ -493,8 +493,10 @@ __global__ __launch_bounds__(256) void sc_implicit_gemm_pipe_kernel(const float 
         const unsigned rest = (k + 1 < 32) ? (wg_mask >> (k + 1)) : 0u;
         return rest ? k + 1 + __builtin_ctz(rest) : K;
     };
-    auto fetch = [&](int k) {
-        const int src = (myrow < n_out) ? nbr[(size_t)trow * K + k] : -1;
+    // table entries are requested one offset ahead of the gathers that use them (two ahead of the MFMAs), so no wave waits
+    // for a table load with nothing else in flight
+    auto load_src = [&](int k) { return (myrow < n_out && k < K) ? nbr[(size_t)trow * K + k] : -1; };
+    auto fetch = [&](int k, const int src) {
         any_next = row_mask ? ((wave_mask >> k) & 1u) != 0u : __ballot(src >= 0) != 0ull;
 #pragma unroll
         for (int u = 0; u < NG; ++u) {
@@ -511,7 +513,11 @@ __global__ __launch_bounds__(256) void sc_implicit_gemm_pipe_kernel(const float 
         }
     };
     int k = next_k(-1);
-    if (k < K) fetch(k);
+    int src_ahead = load_src(k);
+    if (k < K) {
+        fetch(k, src_ahead);
+        src_ahead = load_src(next_k(k));
+    }
     for (; k < K;) {
         const int kn = next_k(k);
         const bool any = any_next;
@@ -534,7 +540,10 @@ __global__ __launch_bounds__(256) void sc_implicit_gemm_pipe_kernel(const float 
             }
         }
         __syncthreads();
-        if (kn < K) fetch(kn);                            // in flight while the MFMAs below run
+        if (kn < K) {                                     // in flight while the MFMAs below run
+            fetch(kn, src_ahead);
+            src_ahead = load_src(next_k(kn));
+        }
         if (any) {
 #pragma unroll 4
             for (int c0 = 0; c0 < Cin; c0 += 2) {
@@ -548,19 +557,37 @@ __global__ __launch_bounds__(256) void sc_implicit_gemm_pipe_kernel(const float 
         }
         k = kn;
     }
+    const int last = n_out - 1;                           // n_out >= 1 (checked by the launcher)
+    // fused epilogue: (+ bias) (+ residual) (ReLU); sorted tables scatter rows.  Output row indices and residual values are
+    // requested eight rows at a time before any is used (clamped, unconditional loads: no wait per element).
 #pragma unroll
-    for (int q = 0; q < NT; ++q) {
-        const int col = q * 32 + (l & 31);
-        if (col < Cout) {
-            const float bv = bias ? bias[col] : 0.f;
+    for (int h = 0; h < 2; ++h) {
+        int orow[8];
 #pragma unroll
-            for (int r = 0; r < 16; ++r) {
+        for (int j = 0; j < 8; ++j) {
+            const int r = h * 8 + j;
+            const int row = min(row0 + (r & 3) + 8 * (r >> 2) + 4 * (l >> 5), last);
+            orow[j] = out_row ? out_row[row] : row;
+        }
+#pragma unroll
+        for (int q = 0; q < NT; ++q) {
+            const int col = q * 32 + (l & 31);
+            const int cc = min(col, Cout - 1);
+            const float bv = bias ? bias[cc] : 0.f;
+            float res[8];
+#pragma unroll
+            for (int j = 0; j < 8; ++j) res[j] = 0.f;
+            if (residual) {
+#pragma unroll
+                for (int j = 0; j < 8; ++j) res[j] = residual[(size_t)orow[j] * Cout + cc];
+            }
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                const int r = h * 8 + j;
                 const int row = row0 + (r & 3) + 8 * (r >> 2) + 4 * (l >> 5);
-                if (row < n_out) {              // fused epilogue: (+ bias) (+ residual) (ReLU); sorted tables scatter rows
-                    const size_t orow = out_row ? (size_t)out_row[row] : (size_t)row;
-                    float v = acc[q][r] + bv;
-                    if (residual) v += residual[orow * Cout + col];
-                    out[orow * Cout + col] = relu ? fmaxf(v, 0.f) : v;
+                if (row < n_out && col < Cout) {
+                    const float v = acc[q][r] + bv + res[j];
+                    out[(size_t)orow[j] * Cout + col] = relu ? fmaxf(v, 0.f) : v;
                 }
             }
         }
