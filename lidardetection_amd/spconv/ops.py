@@ -126,9 +126,15 @@ def mask_order(nbr):
     workgroup (include/lidar_hip.h: lidar_spconv_implicit_gemm_sorted)."""
     n_out, K = nbr.shape
     masks = torch.empty(n_out, dtype=torch.int32, device=nbr.device)
+    order = torch.empty(n_out, dtype=torch.int32, device=nbr.device)
     if n_out:
-        _lib.check(_lib.lib().lidar_spconv_row_masks(_lib.ptr(nbr), n_out, K, _lib.ptr(masks), _lib.stream()), "lidar_spconv_row_masks")
-    return masks, torch.argsort(masks).int()
+        L = _lib.lib()
+        _lib.check(L.lidar_spconv_row_masks(_lib.ptr(nbr), n_out, K, _lib.ptr(masks), _lib.stream()), "lidar_spconv_row_masks")
+        wsb = int(L.lidar_spconv_mask_order_workspace_bytes(n_out, K))
+        ws = torch.empty(wsb, dtype=torch.uint8, device=nbr.device)
+        _lib.check(L.lidar_spconv_mask_order(_lib.ptr(masks), n_out, K, _lib.ptr(order), _lib.ptr(ws), wsb, _lib.stream()),
+                   "lidar_spconv_mask_order")
+    return masks, order
 
 
 def indice_conv_fused(feats, nbr, weight_kcc, bias, residual=None, relu=False, order=None):

@@ -276,3 +276,22 @@ def test_wgrad_mfma_matches_float64_and_the_scalar_kernel(dev, cin, cout, n_out,
     _lib.check(L.lidar_spconv_wgrad(_lib.ptr(f_d), _lib.ptr(g_d), _lib.ptr(nbr_d), n_out, K, cin, cout, _lib.ptr(old), _lib.stream()),
                "lidar_spconv_wgrad")
     np.testing.assert_allclose(outs[0].cpu().numpy(), old.cpu().numpy(), rtol=0, atol=2e-4 * max(float(ref.abs().max()), 1.0))
+
+
+def test_mask_order_is_a_sorting_permutation(dev):
+    """lidar_spconv_mask_order (rocPRIM onesweep over the K significant bits): a permutation that puts the row masks in
+    ascending order; sizes around rocPRIM's internal algorithm switches and a K = 32 table with the sign bit in use."""
+    from lidardetection_amd.spconv import ops
+    g = torch.Generator().manual_seed(5)
+    for n, K in ((1, 27), (63, 27), (5000, 27), (150001, 27), (300000, 8), (4097, 32)):
+        nbr = torch.where(torch.rand((n, K), generator=g) < 0.35, torch.randint(0, max(n, 1), (n, K), generator=g), -1).int().to(dev)
+        masks, order = ops.mask_order(nbr)
+        want = torch.zeros(n, dtype=torch.int64)
+        for k in range(K):
+            want |= (nbr[:, k].cpu() >= 0).long() << k
+        assert torch.equal(masks.cpu().long() & 0xFFFFFFFF, want)
+        o = order.cpu().long()
+        assert torch.equal(torch.sort(o).values, torch.arange(n))
+        assert torch.equal(want[o], torch.sort(want).values)
+    m0, o0 = ops.mask_order(torch.empty((0, 27), dtype=torch.int32, device=dev))
+    assert m0.numel() == 0 and o0.numel() == 0
