@@ -107,11 +107,16 @@ class _VoxelBackBoneBase(nn.Module):
         x = spconv.SparseConvTensor(features=batch_dict['voxel_features'], indices=batch_dict['voxel_coords'].int(),
                                     spatial_shape=self.sparse_shape, batch_size=batch_dict['batch_size'])
         stages = [getattr(self, name) for name in _STAGE_ORDER]
-        spconv.prebuild_rulebooks(stages, x.indices.contiguous(), x.spatial_shape, x.batch_size, x.indice_dict)
-        taps = {}
-        for name, stage in zip(_STAGE_ORDER, stages):
-            x = stage(x)
-            taps[name] = x
+        if not torch.is_grad_enabled() and x.features.is_cuda and x.indices.shape[0] > 0:
+            # inference: the next stage's rulebooks are built on a second stream under this stage's GEMMs
+            taps = dict(zip(_STAGE_ORDER, spconv.run_stages_pipelined(stages, x)))
+            x = taps[_STAGE_ORDER[-1]]
+        else:
+            spconv.prebuild_rulebooks(stages, x.indices.contiguous(), x.spatial_shape, x.batch_size, x.indice_dict)
+            taps = {}
+            for name, stage in zip(_STAGE_ORDER, stages):
+                x = stage(x)
+                taps[name] = x
         batch_dict.update({'encoded_spconv_tensor': x, 'encoded_spconv_tensor_stride': 8})
         batch_dict.update({'multi_scale_3d_features': {'x_conv%d' % i: taps['conv%d' % i] for i in (1, 2, 3, 4)}})
         return batch_dict

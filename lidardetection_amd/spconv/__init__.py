@@ -11,9 +11,9 @@ spconv itself is absent from /root/reference and from this image: parity is pinn
 torch.nn.functional.conv3d and a brute-force rulebook (tests/test_gpu_spconv.py), i.e. "parity unpinned" w.r.t. upstream.
 """
 from .conv import SparseConv3d, SparseConvolution, SparseInverseConv3d, SubMConv3d
-from .modules import SparseModule, SparseSequential, prebuild_rulebooks
+from .modules import SparseModule, SparseSequential, prebuild_rulebooks, run_stages_pipelined
 from .tensor import SparseConvTensor
 from . import ops, utils
 
 __all__ = ["SparseConvTensor", "SparseModule", "SparseSequential", "SparseConvolution", "SubMConv3d", "SparseConv3d",
-           "SparseInverseConv3d", "prebuild_rulebooks", "ops", "utils"]
+           "SparseInverseConv3d", "prebuild_rulebooks", "run_stages_pipelined", "ops", "utils"]

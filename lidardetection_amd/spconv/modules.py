@@ -112,14 +112,14 @@ def _sparse_convs(module):
                 yield from _sparse_convs(child)
 
 
-def prebuild_rulebooks(module, indices, spatial_shape, batch_size, indice_dict):
+def prebuild_rulebooks(module, indices, spatial_shape, batch_size, indice_dict, pending=None):
     """Builds every rulebook of `module` (a module or a list of modules run back to back) from the coordinates alone and
     returns the (indices, spatial_shape) leaving it.
     Dense layers (BatchNorm1d, ReLU) are skipped.  Scheduling: a strided conv's rulebook needs one host read-back (the
     number of output sites); when a SubM layer is about to build a table for the level that strided conv consumes, the
     strided conv's output-site search is enqueued FIRST, so the SubM table build runs while the host waits for the count."""
     convs = list(_sparse_convs(module))
-    pending = {}
+    pending = dict(pending or {})               # {id(conv): state of an output-site search begun by the caller}
     if indices.dtype != torch.int32:
         indices = indices.int()
     indices = indices.contiguous()
@@ -133,3 +133,66 @@ def prebuild_rulebooks(module, indices, spatial_shape, batch_size, indice_dict):
                 break
         indices, spatial_shape = conv.build_rulebook(indices, spatial_shape, batch_size, indice_dict, pending.pop(id(conv), None))
     return indices, spatial_shape
+
+
+_RULEBOOK_STREAMS = {}
+
+
+def _begin_first_strided(module, indices, spatial_shape, batch_size, indice_dict):
+    """starts the output-site search of `module`'s first table-building convolution when that is a strided one"""
+    for conv in _sparse_convs(module):
+        if conv.conv1x1:
+            continue
+        if conv.subm or conv.inverse or not conv.needs_new_rulebook(indice_dict) or indices.shape[0] == 0:
+            return None
+        return {id(conv): conv.begin_rulebook(indices, spatial_shape, batch_size)}
+    return None
+
+
+def _hand_tables_to(stream, indice_dict):
+    """tables are allocated on the rulebook stream and read on the feature stream: tell the caching allocator"""
+    for datas in indice_dict.values():
+        for key in ("nbr", "nbr_t", "in_indices", "out_indices"):
+            t = datas.get(key)
+            if torch.is_tensor(t) and t.is_cuda:
+                t.record_stream(stream)
+
+
+def run_stages_pipelined(stages, x):
+    """Inference over a list of stages (modules run back to back): -> the output of every stage.
+    The rulebooks depend on coordinates alone, so stage s+1's tables are built on a second stream WHILE stage s's GEMMs run:
+    the host starts the next stage's output-site search, enqueues this stage's feature launches, and only then blocks on the
+    search's count read-back — the hash builds, table fills and mask orders hide under the matrix work instead of preceding
+    it (prebuild_rulebooks alone serialises ~1.3 ms of table building in front of a SECOND backbone's 2.1 ms of GEMMs)."""
+    dev = x.features.device
+    feat = torch.cuda.current_stream(dev)
+    rb = _RULEBOOK_STREAMS.get(dev)
+    if rb is None:
+        rb = _RULEBOOK_STREAMS[dev] = torch.cuda.Stream(dev)
+    indices = x.indices if x.indices.dtype == torch.int32 else x.indices.int()
+    indices = indices.contiguous()
+    x.indices = indices
+    rb.wait_stream(feat)                         # the coordinates are produced on the feature stream
+    indices.record_stream(rb)
+    bs, idict = x.batch_size, x.indice_dict
+    with torch.cuda.stream(rb):
+        nxt = prebuild_rulebooks(stages[0], indices, x.spatial_shape, bs, idict)
+        ready = torch.cuda.Event()
+        ready.record(rb)
+    _hand_tables_to(feat, idict)
+    outs = []
+    for s, stage in enumerate(stages):
+        pend = None
+        if s + 1 < len(stages):
+            with torch.cuda.stream(rb):
+                pend = _begin_first_strided(stages[s + 1], nxt[0], nxt[1], bs, idict)
+        feat.wait_event(ready)
+        x = stage(x)
+        outs.append(x)
+        if s + 1 < len(stages):
+            with torch.cuda.stream(rb):
+                nxt = prebuild_rulebooks(stages[s + 1], nxt[0], nxt[1], bs, idict, pend)
+                ready = torch.cuda.Event()
+                ready.record(rb)
+            _hand_tables_to(feat, idict)
+    return outs

@@ -95,7 +95,10 @@ def cached_mask_order(datas, key, table):
     if st is None:
         st = datas[key] = list(mask_order(table)) + [None]
     if st[2] is not None:
-        torch.cuda.current_stream(table.device).wait_event(st[2])
+        cur = torch.cuda.current_stream(table.device)
+        cur.wait_event(st[2])
+        st[0].record_stream(cur)                # computed on the side stream, read on this one
+        st[1].record_stream(cur)
         st[2] = None
     return st[0], st[1]
 
