@@ -7,7 +7,7 @@ import numpy as np
 import pytest
 import torch
 
-from lidardetection_amd import synth
+from lidardetection_amd import pillar_ops, synth
 from lidardetection_amd.pcdet.models.backbones_2d import map_to_bev
 from lidardetection_amd.pcdet.models.backbones_3d import spconv_backbone, vfe
 from lidardetection_amd.pcdet.models.model_utils import model_nms_utils
@@ -180,3 +180,31 @@ def test_second_kitti_pipeline_runs_and_matches_unfused_paths(dev):
     for x, y, z in zip(fused, plain, full):
         assert torch.equal(x, y) and torch.equal(x, z)
     assert int(fused[3].min()) >= 0 and torch.isfinite(fused[0]).all()
+
+
+def test_pipelined_stage_runner_equals_prebuilt_pass(dev):
+    """spconv.run_stages_pipelined (rulebooks of stage s+1 on a second stream under stage s's GEMMs) vs building every
+    rulebook first and running the stages one after another: same tables, same sums — bit-identical taps, repeatedly
+    (the second and third pass reuse the streams and catch a missing cross-stream dependency)."""
+    from lidardetection_amd import spconv, synth
+    from lidardetection_amd.voxelizer import BatchVoxelizer
+    frames = [synth.cloud_ring(2000 + f) for f in range(3)]
+    o = BatchVoxelizer(synth.SEC_VOXEL, synth.SEC_RANGE, 5, 16000).voxelize_frames(frames, device=dev)
+    feats = pillar_ops.mean_vfe(o["voxels"], o["voxel_num_points"])
+    torch.manual_seed(11)
+    m = spconv_backbone.VoxelBackBone8x(AttrDict(), 4, [1408, 1600, 40]).to(dev).eval()
+    stages = [getattr(m, n) for n in ("conv_input", "conv1", "conv2", "conv3", "conv4", "conv_out")]
+    with torch.no_grad():
+        x = spconv.SparseConvTensor(feats, o["voxel_coords"].int(), m.sparse_shape, 3)
+        spconv.prebuild_rulebooks(stages, x.indices.contiguous(), x.spatial_shape, x.batch_size, x.indice_dict)
+        want = []
+        for st in stages:
+            x = st(x)
+            want.append(x)
+        for _ in range(3):
+            x = spconv.SparseConvTensor(feats, o["voxel_coords"].int(), m.sparse_shape, 3)
+            got = spconv.run_stages_pipelined(stages, x)
+            assert len(got) == len(want)
+            for a, b in zip(got, want):
+                assert a.spatial_shape == b.spatial_shape and torch.equal(a.indices, b.indices)
+                assert torch.equal(a.features, b.features)
