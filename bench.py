@@ -85,6 +85,13 @@ def main():
     args = ap.parse_args()
 
     rank, local, world = dist_utils.env_world()
+    if world > 1 and "MIOPEN_USER_DB_PATH" not in os.environ:
+        # every rank runs MIOpen's find pass during warm-up and records the result in the user database: one directory per
+        # rank keeps N processes from queueing on the same SQLite file (the find results themselves are per process anyway)
+        import tempfile
+        db = os.path.join(tempfile.gettempdir(), f"lidar_miopen_udb_{os.getuid()}_rank{local}")
+        os.makedirs(db, exist_ok=True)
+        os.environ["MIOPEN_USER_DB_PATH"] = db
     torch.cuda.set_device(local)
     dist = dist_utils.init_from_env("nccl")          # RCCL on ROCm; None for a single process
     device = torch.device("cuda", local)
