@@ -594,6 +594,96 @@ __global__ __launch_bounds__(256) void sc_implicit_gemm_pipe_kernel(const float 
     }
 }
 
+// Input layer (Cin == 4: x, y, z, intensity means; K * 4 <= 128): all K offsets in ONE stage.  The per-offset kernels above
+// spend two barriers per offset on 2 MFMA steps of work here; this one gathers the wave's 32 x (K * 4) tile and the whole
+// (K * 4, Cout) weight once, then runs the K * 2 MFMA steps back to back.  Same operand pairs in the same order as the
+// per-offset kernels (skipped offsets contribute exact zeros), so the sums are the same.
+template <int NT>
+__global__ __launch_bounds__(256) void sc_input_layer_gemm_kernel(const float *__restrict__ in, const int *__restrict__ nbr, int n_out,
+                                                                  int K, int Cout, const float *__restrict__ Wt,
+                                                                  const float *__restrict__ bias, const float *__restrict__ residual,
+                                                                  int relu, float *__restrict__ out) {
+    constexpr int CW = NT * 32, MAXG = 14;                // MAXG * 64 >= 32 rows * 27 offsets
+    const int KC = K * 4, KCp = KC + 1;
+    extern __shared__ float s_mem[];
+    float *s_w = s_mem;                                   // [KC][CW]
+    float *s_a = s_mem + (size_t)KC * CW;                 // [4 waves][32][KCp]
+    const int t = threadIdx.x, l = t & 63, wv = t >> 6;
+    const int row0 = blockIdx.x * IG_ROWS + wv * 32;
+    const int last = n_out - 1;
+    float *A = s_a + (size_t)wv * 32 * KCp;
+    // the wave's 32 x K table entries are contiguous: coalesced, all requested before the first gather
+    const int npairs = 32 * K;
+    int src[MAXG];
+    const long long tbase = (long long)row0 * K, tend = (long long)n_out * K;
+#pragma unroll
+    for (int u = 0; u < MAXG; ++u) {
+        const long long e = tbase + u * 64 + l;
+        src[u] = nbr[e < tend ? e : tend - 1];
+    }
+    float4 g[MAXG];
+#pragma unroll
+    for (int u = 0; u < MAXG; ++u) g[u] = reinterpret_cast<const float4 *>(in)[max(src[u], 0)];
+    for (int e = t; e < KC * CW; e += 256) {
+        const int ci = e / CW, co = e - ci * CW;
+        s_w[e] = co < Cout ? Wt[(size_t)ci * Cout + co] : 0.f;
+    }
+#pragma unroll
+    for (int u = 0; u < MAXG; ++u) {
+        const int p = u * 64 + l;
+        if (p < npairs) {
+            const int r = p / K, k = p - r * K;
+            const bool ok = src[u] >= 0 && tbase + p < tend;
+            float *dst = A + r * KCp + k * 4;
+            dst[0] = ok ? g[u].x : 0.f; dst[1] = ok ? g[u].y : 0.f; dst[2] = ok ? g[u].z : 0.f; dst[3] = ok ? g[u].w : 0.f;
+        }
+    }
+    __syncthreads();
+    f32x16 acc[NT];
+#pragma unroll
+    for (int q = 0; q < NT; ++q)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[q][r] = 0.f;
+    const int ar = l & 31, ak = l >> 5;
+#pragma unroll 4
+    for (int c0 = 0; c0 < KC; c0 += 2) {
+        const float a = A[ar * KCp + c0 + ak];
+#pragma unroll
+        for (int q = 0; q < NT; ++q) {
+            const float b = s_w[(c0 + ak) * CW + q * 32 + ar];
+            acc[q] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, acc[q], 0, 0, 0);
+        }
+    }
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+#pragma unroll
+        for (int q = 0; q < NT; ++q) {
+            const int col = q * 32 + (l & 31);
+            const int cc = min(col, Cout - 1);
+            const float bv = bias ? bias[cc] : 0.f;
+            float res[8];
+#pragma unroll
+            for (int j = 0; j < 8; ++j) res[j] = 0.f;
+            if (residual) {
+#pragma unroll
+                for (int j = 0; j < 8; ++j) {
+                    const int r = h * 8 + j;
+                    res[j] = residual[(size_t)min(row0 + (r & 3) + 8 * (r >> 2) + 4 * (l >> 5), last) * Cout + cc];
+                }
+            }
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                const int r = h * 8 + j;
+                const int row = row0 + (r & 3) + 8 * (r >> 2) + 4 * (l >> 5);
+                if (row < n_out && col < Cout) {
+                    const float v = acc[q][r] + bv + res[j];
+                    out[(size_t)row * Cout + col] = relu ? fmaxf(v, 0.f) : v;
+                }
+            }
+        }
+    }
+}
+
 // indice_conv forward / dgrad (with the transposed table and W^T) — spconv.functional indice_conv (Appendix A.3) —
 // with the inference epilogue of the reference's conv/BatchNorm1d/ReLU triplets (spconv_backbone.py:20-26) and of
 // SparseBasicBlock (spconv_backbone.py:49-63): out = act(gemm + bias + residual).
@@ -618,6 +708,12 @@ static int sc_gemm_launch(const float *in_features, const int *nbr, int n_out, i
         return lidar_check_launch("lidar_spconv_implicit_gemm(pipe)");
     }
 #undef IGP
+    if (Cin == 4 && K * 32 <= 14 * 64 && nt <= 2) {       // the network's input layer: one stage for all offsets
+        const size_t lds_in = ((size_t)K * 4 * nt * 32 + (size_t)4 * 32 * (K * 4 + 1)) * sizeof(float);
+        if (nt == 1) hipLaunchKernelGGL(sc_input_layer_gemm_kernel<1>, grid, dim3(256), lds_in, s, in_features, nbr, n_out, K, Cout, weight, bias, residual, relu, out_features);
+        else hipLaunchKernelGGL(sc_input_layer_gemm_kernel<2>, grid, dim3(256), lds_in, s, in_features, nbr, n_out, K, Cout, weight, bias, residual, relu, out_features);
+        return lidar_check_launch("lidar_spconv_implicit_gemm(input layer)");
+    }
 #define IG_CASE(NT) hipLaunchKernelGGL(sc_implicit_gemm_kernel<NT>, grid, dim3(256), lds, s, in_features, nbr, n_out, K, Cin, Cout, weight, bias, residual, relu, out_features)
     switch (nt) {
         case 1: IG_CASE(1); break;

@@ -295,3 +295,30 @@ def test_mask_order_is_a_sorting_permutation(dev):
         assert torch.equal(want[o], torch.sort(want).values)
     m0, o0 = ops.mask_order(torch.empty((0, 27), dtype=torch.int32, device=dev))
     assert m0.numel() == 0 and o0.numel() == 0
+
+
+@pytest.mark.parametrize("cout,n_out,K,p_valid", [(16, 1000, 27, 0.15), (16, 129, 27, 1.0), (32, 4097, 27, 0.3), (48, 300, 27, 0.4),
+                                                  (16, 1, 27, 1.0), (16, 500, 8, 0.5), (64, 260, 1, 1.0)])
+def test_input_layer_gemm(dev, cout, n_out, K, p_valid):
+    """Cin == 4 (the networks' input layer): the single-stage kernel (all K offsets gathered once) against float64, with and
+    without bias / residual / ReLU, ragged row counts, K = 27 / 8 / 1 tables and a row without neighbours."""
+    from lidardetection_amd.spconv import ops
+    n_in = 555
+    g = torch.Generator(device="cpu").manual_seed(cout * 7 + n_out + K)
+    nbr = torch.randint(0, n_in, (n_out, K), generator=g, dtype=torch.int32)
+    nbr[torch.rand(n_out, K, generator=g) >= p_valid] = -1
+    nbr[n_out // 2] = -1
+    feats = torch.randn(n_in, 4, generator=g)
+    w = torch.randn(K, 4, cout, generator=g) * 0.3
+    b = torch.randn(cout, generator=g)
+    res = torch.randn(n_out, cout, generator=g)
+    ref = torch.zeros(n_out, cout, dtype=torch.float64)
+    for k in range(K):
+        m = nbr[:, k] >= 0
+        ref[m] += feats[nbr[m, k].long()].double() @ w[k].double()
+    nbr_d, f_d, w_d, b_d, r_d = (x.to(dev) for x in (nbr, feats, w, b, res))
+    plain = ops.indice_conv_fused(f_d, nbr_d, w_d, None, None, False, None)
+    np.testing.assert_allclose(plain.cpu().double().numpy(), ref.numpy(), rtol=0, atol=1e-4)
+    full = ops.indice_conv_fused(f_d, nbr_d, w_d, b_d, r_d, True, None)
+    np.testing.assert_allclose(full.cpu().double().numpy(), torch.relu(ref + b.double() + res.double()).numpy(), rtol=0, atol=1e-4)
+    assert torch.equal(full, ops.indice_conv_fused(f_d, nbr_d, w_d, b_d, r_d, True, None))      # deterministic
