@@ -107,8 +107,10 @@ class _VoxelBackBoneBase(nn.Module):
         x = spconv.SparseConvTensor(features=batch_dict['voxel_features'], indices=batch_dict['voxel_coords'].int(),
                                     spatial_shape=self.sparse_shape, batch_size=batch_dict['batch_size'])
         stages = [getattr(self, name) for name in _STAGE_ORDER]
-        if not torch.is_grad_enabled() and x.features.is_cuda and x.indices.shape[0] > 0:
-            # inference: the next stage's rulebooks are built on a second stream under this stage's GEMMs
+        if not torch.is_grad_enabled() and not self.training and x.features.is_cuda and x.indices.shape[0] > 0:
+            # inference (eval mode: one fused launch per layer, the host is far ahead of the GPU): the next stage's rulebooks
+            # are built on a second stream under this stage's GEMMs.  With train-mode BatchNorm under no_grad the feature pass
+            # is launch-bound and the interleaving delays the rulebook chain (6.4 vs 5.5 ms), so that case keeps the prebuilt pass.
             taps = dict(zip(_STAGE_ORDER, spconv.run_stages_pipelined(stages, x)))
             x = taps[_STAGE_ORDER[-1]]
         else:

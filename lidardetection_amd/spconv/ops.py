@@ -123,6 +123,9 @@ def sorted_gemm_supported(K, Cin, Cout):
     return K <= 31 and bool(_lib.lib().lidar_spconv_sorted_gemm_supported(K, Cin, Cout))
 
 
+_ORDER_VIA_TORCH = __import__("os").environ.get("LIDAR_MASK_ORDER_TORCH", "0") == "1"
+
+
 def mask_order(nbr):
     """(n_out, K <= 31) neighbour table -> (row offset bit masks, the row order that sorts them).  Visiting rows in that
     order puts equal masks into the same MFMA tiles, so tiles stop multiplying padding rows and whole offsets drop out per
@@ -133,6 +136,8 @@ def mask_order(nbr):
     if n_out:
         L = _lib.lib()
         _lib.check(L.lidar_spconv_row_masks(_lib.ptr(nbr), n_out, K, _lib.ptr(masks), _lib.stream()), "lidar_spconv_row_masks")
+        if _ORDER_VIA_TORCH:                    # A/B knob (LIDAR_MASK_ORDER_TORCH=1): torch.argsort instead of the C-ABI sort
+            return masks, torch.argsort(masks).int()
         wsb = int(L.lidar_spconv_mask_order_workspace_bytes(n_out, K))
         ws = torch.empty(wsb, dtype=torch.uint8, device=nbr.device)
         _lib.check(L.lidar_spconv_mask_order(_lib.ptr(masks), n_out, K, _lib.ptr(order), _lib.ptr(ws), wsb, _lib.stream()),
