@@ -15,6 +15,8 @@ Prints ONE JSON line on rank 0 (contract in the task statement) with two extra o
 import argparse
 import json
 import os
+import socket
+import subprocess
 import sys
 import time
 
@@ -25,7 +27,6 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 from lidardetection_amd import dist_utils, synth  # noqa: E402
-from lidardetection_amd.pointpillar import PointPillarKITTI  # noqa: E402
 
 HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
 
@@ -73,6 +74,44 @@ def cpu_baseline(frames, model, nframes):
                       f"PFN/scatter/backbone/head ({torch.get_num_threads()} threads), {dt:.1f} s"}
 
 
+def launch_ranks(n, argv):
+    """`python bench.py --gpus N` without a torch.distributed launcher: start N fresh rank processes, one per GPU, with
+    RANK / LOCAL_RANK / WORLD_SIZE / MASTER_* set (what tools/scripts/dist_train.sh:7 + pcdet/utils/common_utils.py:170-184
+    do for the reference).  The parent never touches the GPU; it only waits and forwards the worst exit code."""
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    procs = []
+    for r in range(n):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), MASTER_ADDR="127.0.0.1",
+                   MASTER_PORT=str(port), LIDAR_BENCH_CHILD="1")
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__), *argv], env=env))
+    rc = 0
+    for p in procs:
+        rc = max(rc, abs(p.wait()))
+    return rc
+
+
+def dry_run(args, rank, world):
+    """--dry-run: the N-rank plumbing alone on CPU / gloo (launcher, rendezvous, barrier, max-over-ranks clock, the single
+    JSON line) — no kernel is launched and nothing is measured."""
+    dist = dist_utils.init_from_env("gloo")
+    frames_of_rank = dist_utils.shard_indices(args.batch * world, rank, world)
+    dist_utils.barrier(dist)
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        time.sleep(1e-3)
+    dist_utils.barrier(dist)
+    dt = dist_utils.max_over_ranks(time.perf_counter() - t0, dist)
+    if rank == 0:
+        print(json.dumps({"metric": "frames/sec (fwd+NMS) PointPillar-KITTI", "value": None, "unit": "frames/s", "n_gpus": world,
+                          "steps": args.steps, "warmup": args.warmup, "ms_per_step": dt / args.steps * 1e3, "dry_run": True,
+                          "frames_per_rank": len(frames_of_rank), "scaling": "weak"}))
+    if dist is not None:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -80,11 +119,22 @@ def main():
     ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--batch", type=int, default=16)
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--cpu-frames", type=int, default=2)
+    ap.add_argument("--cpu-frames", type=int, default=8)
+    ap.add_argument("--no-extra", action="store_true", help="skip the SECOND / sparse-GEMM / NMS / PFN side measurements")
+    ap.add_argument("--dry-run", action="store_true", help="N-rank plumbing only, CPU / gloo, no kernels (tests)")
     ap.add_argument("--stages", action="store_true", help="also print per-stage GPU times (stderr)")
     args = ap.parse_args()
 
+    if "WORLD_SIZE" not in os.environ and args.gpus > 1:
+        sys.exit(launch_ranks(args.gpus, sys.argv[1:]))       # before anything touches the GPU
     rank, local, world = dist_utils.env_world()
+    if world != args.gpus:
+        print(f"bench.py: --gpus {args.gpus} but WORLD_SIZE={world}: launch one rank per GPU "
+              f"(torch.distributed.run --nproc-per-node {args.gpus}, or no launcher at all)", file=sys.stderr)
+        sys.exit(2)
+    if args.dry_run:
+        return dry_run(args, rank, world)
+    from lidardetection_amd.pointpillar import PointPillarKITTI
     if world > 1 and "MIOPEN_USER_DB_PATH" not in os.environ:
         # every rank runs MIOpen's find pass during warm-up and records the result in the user database: one directory per
         # rank keeps N processes from queueing on the same SQLite file (the find results themselves are per process anyway)

@@ -50,3 +50,31 @@ def test_two_rank_gloo_sharding_and_clock():
 def test_single_process_is_identity():
     assert dist_utils.shard_indices(5, 0, 1) == [0, 1, 2, 3, 4]
     assert dist_utils.max_over_ranks(3.5) == 3.5
+
+
+def _run_bench(extra_args, env=None):
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    e = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT")}
+    e.update(env or {})
+    return subprocess.run([sys.executable, os.path.join(root, "bench.py"), *extra_args], env=e, capture_output=True, text=True,
+                          timeout=300)
+
+
+def test_bench_launches_its_own_ranks():
+    """`python bench.py --gpus 2` (no torch.distributed launcher) must start two ranks and print ONE line with n_gpus 2
+    (reference launch: tools/scripts/dist_train.sh:7, pcdet/utils/common_utils.py:170-184).  --dry-run = gloo, no kernels."""
+    import json
+    r = _run_bench(["--gpus", "2", "--steps", "3", "--warmup", "1", "--dry-run"])
+    assert r.returncode == 0, r.stderr
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1
+    rec = json.loads(lines[0])
+    assert rec["n_gpus"] == 2 and rec["steps"] == 3 and rec["dry_run"] is True and rec["frames_per_rank"] == 16
+
+
+def test_bench_refuses_a_world_size_mismatch():
+    r = _run_bench(["--gpus", "4", "--dry-run"], env={"WORLD_SIZE": "1", "RANK": "0", "LOCAL_RANK": "0"})
+    assert r.returncode != 0 and "WORLD_SIZE=1" in r.stderr
+    assert not [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
