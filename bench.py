@@ -202,7 +202,7 @@ def main():
                                "stock-torch (MIOpen) fp32 2D backbone/head convolutions, channels_last, BN folded + HIP bias/ReLU epilogue; cloud_uniform 20k pts/frame, 16k pillars/frame "
                                "(max_voxels cap), NMS pre 4096 / post 500 / thr 0.01",
                    "frames_per_step": args.batch, "replicas": world},
-        "roofline": {"bound": "hbm", "kernel": "lidar_voxelize (vxl_key + zero-fill, vxl_bin, vxl_emit)",
+        "roofline": {"bound": "hbm", "kernel": "lidar_voxelize (vxl_keybin = key + bin + zero-fill roles in one launch, vxl_emit)",
                      "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
                      "traffic": traffic, "alg_bytes_per_launch": alg_bytes, "ms_per_launch": vox_ms,
                      # informational: an empty HIP event pair recorded at the same place (dispatch + marker latency that the

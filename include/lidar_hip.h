@@ -37,9 +37,12 @@ extern "C" {
  *   range6/voxel_size3/grid3  HOST arrays: [x0,y0,z0,x1,y1,z1], [vx,vy,vz], [nx,ny,nz]
  *   compact       1: frame f's rows start at sum_{g<f} V_g (the collate_batch layout)
  *                 0: frame f's rows start at f*max_voxels
- *   algo          0: auto; 1: LDS-binned hashing (n_max <= 32768; no global atomics on the critical
- *                 path; a hash-bin overflow — only reachable with adversarial inputs — sets the sticky
- *                 flag read by lidar_voxelize_error_flag); 2: global hash table (any n_max)
+ *   algo          0: auto (3 when it applies, else 2); 1: LDS-binned hashing, 3 launches (key + zero-fill, bin, emit);
+ *                 3: LDS-binned, 2 launches (fused key + bin + zero-fill, emit; a bin with more than 6144 points —
+ *                 zero-padded clouds — is handled exactly by a streaming variant); 1 and 3 need n_max <= 32768 and
+ *                 have no global atomics on the data path; more distinct voxels / list cells in ONE hash bin than its
+ *                 LDS holds (adversarial input only) sets the sticky flag read by lidar_voxelize_error_flag / mirrored
+ *                 to the host by lidar_voxelize_set_error_mirror; 2: global hash table (any n_max)
  *   voxels        (batch*max_voxels, max_points, C) f32; rows [0, total) fully written (zero padded)
  *   coords        (batch*max_voxels, 4) i32 [b, z, y, x]
  *   num_points    (batch*max_voxels) i32
@@ -51,7 +54,11 @@ int lidar_voxelize(const float *points, const int *point_offsets, int batch, int
                    const float *range6, const float *voxel_size3, const int *grid3, int max_points,
                    int max_voxels, int compact, int algo, float *voxels, int *coords, int *num_points,
                    int *voxel_offsets, void *ws, size_t ws_bytes, void *stream);
-/* host-synchronous read of the sticky overflow flag of algo 1 (0 = fine); not for use inside captures */
+/* optional: a device-visible HOST int (pinned + mapped memory) that receives the same error bits, so the caller can poll
+ * the flag without a copy or a synchronisation (nullptr unregisters).  Cleared by the caller. */
+int lidar_voxelize_set_error_mirror(void *ws, size_t ws_bytes, int batch, int n_max, int max_voxels, int *host_flag,
+                                    void *stream);
+/* host-synchronous read of the sticky overflow flag of algo 1 / 3 (0 = fine); not for use inside captures */
 int lidar_voxelize_error_flag(void *ws, size_t ws_bytes, int batch, int n_max, int max_voxels);
 
 /* ------------------------------------------------------------------ PillarVFE (one PFN layer, eval)

@@ -52,10 +52,27 @@ def bias_act_upsample_(y2d, bias, batch, h, w, s, out, out_offset=0, relu=True):
     return out
 
 
-def _fold(weight, bn, out_dim):
-    """scale the conv weight along its output-channel dim by gamma/sqrt(var+eps); return (weight, shift)."""
+def collect_params(*modules):
+    """every parameter and buffer of `modules` (collected once: the module tree does not change)"""
+    out = []
+    for m in modules:
+        out += list(m.parameters()) + list(m.buffers())
+    return out
+
+
+def params_key(tensors):
+    """identity + version of the source tensors: changes whenever load_state_dict(), .to(), an optimizer step or a
+    BatchNorm statistics update touches one of them (same idea as SparseConvolution._folded)"""
+    return tuple((t.data_ptr(), t._version) for t in tensors)
+
+
+def _fold(weight, bn, out_dim, conv_bias=None):
+    """scale the conv weight along its output-channel dim by gamma/sqrt(var+eps); return (weight, shift).
+    A convolution bias (the reference uses bias=False) is folded as bias*scale + shift."""
     scale = bn.weight.detach() / torch.sqrt(bn.running_var + bn.eps)
     shift = bn.bias.detach() - bn.running_mean * scale
+    if conv_bias is not None:
+        shift = shift + conv_bias.detach() * scale
     shape = [1] * weight.dim()
     shape[out_dim] = -1
     return (weight.detach() * scale.view(shape)), shift.contiguous()
@@ -65,6 +82,8 @@ class FoldedBEVBackbone:
     """Built from the (eval-mode) reference-shaped modules; call with the channels-last canvas."""
 
     def __init__(self, blocks, deblocks, heads):
+        self.sources = collect_params(blocks, deblocks, *heads)
+        self.source_key = params_key(self.sources)                  # owners rebuild when this no longer matches
         self.stages = []
         for blk, de in zip(blocks, deblocks):
             convs, mods, i = [], list(blk), 0
@@ -74,12 +93,12 @@ class FoldedBEVBackbone:
                     pad, i = int(mods[i].padding[0]), i + 1
                 conv, bn = mods[i], mods[i + 1]
                 assert isinstance(conv, nn.Conv2d) and isinstance(bn, nn.BatchNorm2d) and isinstance(mods[i + 2], nn.ReLU)
-                w, b = _fold(conv.weight, bn, 0)
+                w, b = _fold(conv.weight, bn, 0, conv.bias)
                 convs.append((w.contiguous(memory_format=torch.channels_last), b, conv.stride, conv.padding[0] + pad))
                 i += 3
             up, bn = de[0], de[1]
             if isinstance(up, nn.ConvTranspose2d):
-                w, b = _fold(up.weight, bn, 1)
+                w, b = _fold(up.weight, bn, 1, up.bias)
                 if tuple(up.kernel_size) == tuple(up.stride) and up.stride[0] == up.stride[1] and \
                         tuple(up.padding) == (0, 0) and tuple(up.output_padding) == (0, 0):
                     # kernel == stride: every input pixel owns its own s x s output patch -> a plain GEMM
@@ -87,14 +106,15 @@ class FoldedBEVBackbone:
                 else:
                     upc = ("deconv", w.contiguous(memory_format=torch.channels_last), b, up.stride)
             else:   # stride < 1 in the reference config: a strided Conv2d (base_bev_backbone.py:60-69)
-                w, b = _fold(up.weight, bn, 0)
+                w, b = _fold(up.weight, bn, 0, up.bias)
                 upc = ("conv", w.contiguous(memory_format=torch.channels_last), b, up.stride)
             self.stages.append((convs, upc))
         self.up_channels = [s[1][2].numel() for s in self.stages]
         for h in heads:
             assert tuple(h.kernel_size) == (1, 1) and tuple(h.stride) == (1, 1)
         self.head_wt = torch.cat([h.weight.detach().flatten(1) for h in heads], 0).t().contiguous()   # (C_in, sum C_head)
-        self.head_b = torch.cat([h.bias.detach() for h in heads], 0).contiguous()
+        self.head_b = torch.cat([h.bias.detach() if h.bias is not None else h.weight.new_zeros(h.weight.shape[0]) for h in heads],
+                                0).contiguous()
         self.head_split = [h.weight.shape[0] for h in heads]
         self._cat = None
 
@@ -128,6 +148,9 @@ class FoldedBEVBackbone:
                 bias_act_(y, ub, out=cat, out_offset=off)
             off += ub.numel()
         return cat
+
+    def stale(self):
+        return params_key(self.sources) != self.source_key
 
     def merged(self, canvas):
         """-> the merged head output (B, H, W, sum C_head), channels [cls | box | dir] as the heads were given."""

@@ -304,29 +304,21 @@ __global__ __launch_bounds__(256) void nms_mask_kernel(const float *__restrict__
                 if (hit && j >= start && j < col_size) cand |= 1ull << j;
             }
         }
-        const int myc = __popcll(cand);
-        const int incl = wave_incl_scan(myc);
-        const int total = __shfl(incl, 63, 64);
+        const int total_all = wave_sum(__popcll(cand));
         W.word[l] = 0ull;
-        if (total > NMS_PAIR_CAP) {
-            // pathological tile (most of its 4096 pairs nearly coincide): per-lane sequential evaluation
-            while (cand) {
-                const int j = __ffsll((long long)cand) - 1;
-                cand &= cand - 1ull;
-                bool hitp = false;
-                for (int half = 0; half < 2; ++half) {   // the scratch holds 32 lanes at a time
-                    if ((l >> 5) == half) {
-                        const float sov = box_overlap_pre<32>(A, s_pre[j], W.S, l & 31);
-                        hitp = iou_from_overlap(A.area, s_pre[j].area, sov) > thresh;
-                    }
-                }
-                if (hitp) word |= 1ull << j;
-            }
-        } else {
+        // The pair list holds NMS_PAIR_CAP entries.  A tile with more candidates (most of its 4096 pairs nearly coincide:
+        // a row of parked cars, a few objects with thousands of proposals each) goes through the SAME three steps in four
+        // rounds of 16 rows (16 x 64 pairs always fit) — no per-lane special path, no lanes sharing a scratch column.
+        const int ngrp = (total_all > NMS_PAIR_CAP) ? 4 : 1;           // wave-uniform
+        for (int grp = 0; grp < ngrp; ++grp) {
+            unsigned long long cnd = (ngrp == 1 || (l >> 4) == grp) ? cand : 0ull;
+            const int myc = __popcll(cnd);
+            const int incl = wave_incl_scan(myc);
+            const int total = __shfl(incl, 63, 64);
             int pos = incl - myc;
-            while (cand) {
-                const int j = __ffsll((long long)cand) - 1;
-                cand &= cand - 1ull;
+            while (cnd) {
+                const int j = __ffsll((long long)cnd) - 1;
+                cnd &= cnd - 1ull;
                 W.pairs[pos++] = (unsigned short)((l << 6) | j);
             }
             __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
@@ -362,10 +354,10 @@ __global__ __launch_bounds__(256) void nms_mask_kernel(const float *__restrict__
                 }
             }
             __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-            __builtin_amdgcn_wave_barrier();
+            __builtin_amdgcn_wave_barrier();       // also: the next round re-uses the pair list
             __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-            word = W.word[l];
         }
+        word = W.word[l];
     }
     if (rvalid) mask[(size_t)row * cb_total + cbk] = word;
 }

@@ -18,6 +18,7 @@
 //   vx_rows   : writes every padded voxel row exactly once with 16-B/lane stores (zeros included),
 //               coords + counts, and restores the workspace (hash table, lists) to its clean state
 #include "common.h"
+#include <stdlib.h>
 
 #define VX_EMPTY 0xFFFFFFFFu
 #define VX_INF 0x7FFFFFFF
@@ -38,6 +39,7 @@ struct VxParams {
     float lo[3];
     float vs[3];
     float rvs[3];  // fl(1 / vs): only used to skip the IEEE division when the quotient is far from an integer
+    float eabs[3]; // fused launch: absolute form of the same margin, (grid + 2) * 4.8e-7 (valid for every in-grid quotient)
     int grid[3];  // nx, ny, nz
     int C, P, max_voxels, batch, n_max, compact;
     int H, hshift, ntiles;
@@ -66,7 +68,19 @@ struct VxWs {
     int *nvox;       // [B]
     int *fillst;     // [2] LDS path, compact mode: [0] rows the NEXT call should pre-clear (last total + 25 % + 1024),
                      //     [1] the value this call's fill role used (copied by the bin launch; read by the emit launch)
+    int *bvox;       // [B][VXL_GMAX] fused launch: first points (= voxels) found by bin g of frame f (plain stores, no zeroing)
+    int **mirror;    // [1] optional device-visible HOST address (pinned, mapped) that also receives the error bits, so the
+                     //     host can poll the flag without a copy or a sync (lidar_voxelize_set_error_mirror); null = none
 };
+
+// error bits: 1 = LDS table full, 2 = bin entry / list capacity exceeded.  Only ever reached on degenerate input, so the
+// extra pointer load and the system-scope atomic cost nothing on the normal path.
+__device__ __noinline__ void vx_raise_at(int *err, int **mirror, int bits) {
+    atomicOr(err, bits);
+    int *m = *mirror;
+    if (m) __hip_atomic_fetch_or(m, bits, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+}
+__device__ __forceinline__ void vx_raise(const VxWs &w, int bits) { vx_raise_at(w.err, w.mirror, bits); }
 
 
 static int vx_hash_capacity(int n_max) {
@@ -104,6 +118,8 @@ static size_t vx_carve(void *base, int B, int n_max, int max_voxels, VxWs *w) {
     p = take((size_t)B * ntiles * 2 * 4); if (w) w->tile_sums = (int *)p;
     p = take((size_t)B * 4); if (w) w->nvox = (int *)p;
     p = take(256); if (w) w->fillst = (int *)p;
+    p = take((size_t)B * 16 * 4 + 256); if (w) w->bvox = (int *)p;
+    p = take(256); if (w) w->mirror = (int **)p;
     return off;
 }
 
@@ -123,6 +139,7 @@ __global__ void vx_ws_init_kernel(VxWs w, long long nh, long long nl, long long 
     }
     if (i == 0) {
         *w.err = 0;
+        *w.mirror = nullptr;
         w.fillst[0] = w.fillst[1] = 0x7fffffff;     // no history yet: clear the whole buffer
     }
 }
@@ -440,6 +457,39 @@ __device__ __forceinline__ bool vx_cell(const VxParams &p, float x, float y, flo
     return inside;
 }
 
+// x / y cell only (z is not looked at): pillar index cy * nx + cx, false when outside in x or y
+__device__ __forceinline__ bool vx_pillar(const VxParams &p, float x, float y, uint32_t &pillar) {
+    const float fx = vx_floor_div(x - p.lo[0], p.vs[0], p.rvs[0]);
+    const float fy = vx_floor_div(y - p.lo[1], p.vs[1], p.rvs[1]);
+    const bool inside = (fx >= 0.f) & (fx < (float)p.grid[0]) & (fy >= 0.f) & (fy < (float)p.grid[1]);
+    pillar = inside ? (uint32_t)fy * (uint32_t)p.grid[0] + (uint32_t)fx : 0u;
+    return inside;
+}
+
+// Branch-free first look at one coordinate (phase A of the fused launch evaluates x and y of EVERY point of a frame in
+// each of its bin workgroups, so instructions count): c = floor(d * fl(1/vs)), ok = 0 <= c < n, and risky = "an integer
+// lies within the rounding margin of the quotient (or it is NaN / inf): the exact IEEE division must decide" — the same
+// criterion as vx_floor_div with the margin in absolute form (eabs >= |q| * 4.8e-7 for every quotient inside the grid; a
+// quotient far outside the grid is outside whatever its last bit).  Risky coordinates (~0.1 %) are re-evaluated with
+// vx_pillar afterwards.
+__device__ __forceinline__ void vx_cell_fast(float d, float rvs, float eabs, int n, int &c, bool &ok, bool &risky) {
+    const float q = d * rvs;
+    const float fl = floorf(q);
+    const float fr = q - fl;                                     // in [0, 1], exact
+    risky = !(fabsf(fr - 0.5f) <= 0.5f - eabs);                   // true for NaN as well
+    c = (int)__builtin_amdgcn_fmed3f(fl, -1.0f, (float)n);        // clamped: the conversion is always defined
+    ok = (unsigned)c < (unsigned)n;
+}
+
+// full cell: key as vx_cell, plus the pillar index the fused launch bins by
+__device__ __forceinline__ bool vx_cell_pillar(const VxParams &p, float x, float y, float z, uint32_t &key, uint32_t &pillar) {
+    const bool in_xy = vx_pillar(p, x, y, pillar);
+    const float fz = vx_floor_div(z - p.lo[2], p.vs[2], p.rvs[2]);
+    const bool inside = in_xy & (fz >= 0.f) & (fz < (float)p.grid[2]);
+    key = inside ? (uint32_t)fz * (uint32_t)p.grid[1] * (uint32_t)p.grid[0] + pillar : 0u;
+    return inside;
+}
+
 // K0: one workgroup per 1024-point tile: voxel key per point, bin = hash(key) % G, and an in-block
 // partition of the tile's (point, key) pairs by bin (wave ballots + a 16 x G LDS count table; no
 // atomics).  Outside-the-grid points get their per-point word (0) here and enter no bin.
@@ -562,13 +612,13 @@ __global__ __launch_bounds__(1024) void vxl_bin_kernel(const int *__restrict__ o
             const int c = (u < nt) ? cnt_u[u] : 0;
             if (t < min(c, 256)) {
                 if (base + t < VXL_CAP) s_q[base + t] = ent[u];
-                else atomicOr(w.err, 2);
+                else vx_raise(w, 2);
             }
             if (c > 256) {  // block-uniform, rare: a tile that sends more than a quarter of its points to one bin
                 const int2 *seg = w.queue + (((size_t)f * ITEMS_TILES(p) + u) * G + g) * 1024;
                 if (t >= 256 && t < c) {
                     if (base + t < VXL_CAP) s_q[base + t] = seg[t];
-                    else atomicOr(w.err, 2);
+                    else vx_raise(w, 2);
                 }
             }
             base += c;
@@ -597,7 +647,7 @@ __global__ __launch_bounds__(1024) void vxl_bin_kernel(const int *__restrict__ o
             atomicAdd(&s_cnt[slot], 1);
             s_q[e].x = j | (slot << 15);
         } else {
-            atomicOr(w.err, 1);
+            vx_raise(w, 1);
             s_q[e].x = j | (int)0x80000000;
         }
     }
@@ -689,11 +739,23 @@ __global__ __launch_bounds__(1024) void vxl_bin_kernel(const int *__restrict__ o
 // earlier tiles, from the bin kernel's per-tile counts) + (its ballot rank inside the tile) = first-appearance order; the
 // thread then writes that voxel's row itself: occupied slots only (the buffer is already zero), coords from the first
 // point's cell, count.  No separate ranking launch.
+// rows (= voxels kept) of frame k: the 3-launch path sums them with atomics (nvox), the fused launch leaves one count per bin
+__device__ __forceinline__ int vxl_frame_rows(const VxParams &p, const VxWs &w, int G, int k, int fused) {
+    int c;
+    if (fused) {
+        c = 0;
+        for (int g = 0; g < G; ++g) c += w.bvox[k * VXL_GMAX + g];
+    } else {
+        c = w.nvox[k];
+    }
+    return min(c, p.max_voxels);
+}
+
 template <bool C4>
 __global__ __launch_bounds__(1024) void vxl_emit_kernel(const float *__restrict__ points, const int *__restrict__ offsets,
                                                         VxParams p, VxWs w, int G, float *__restrict__ voxels,
                                                         int *__restrict__ coords, int *__restrict__ num_points,
-                                                        int *__restrict__ voxel_offsets) {
+                                                        int *__restrict__ voxel_offsets, int fused) {
     __shared__ int s_part[16], s_wcnt[16];
     __shared__ int s_base;
     const int tile = blockIdx.x, f = blockIdx.y, t = threadIdx.x, l = t & 63, wv = t >> 6;
@@ -721,21 +783,26 @@ __global__ __launch_bounds__(1024) void vxl_emit_kernel(const float *__restrict_
         if (p.compact)
             for (int k0 = 0; k0 < f; k0 += 64) {
                 const int k = k0 + l;
-                part += (k < f) ? min(w.nvox[k], p.max_voxels) : 0;
+                part += (k < f) ? vxl_frame_rows(p, w, G, k, fused) : 0;
             }
         part = wave_sum(part);
         if (l == 0) s_base = p.compact ? part : f * p.max_voxels;
     }
-    if (tile == 0 && f == 0 && t == 0) {              // the batch's offsets table (off the critical path)
-        int b = 0;
-        for (int k = 0; k < p.batch; ++k) {
-            voxel_offsets[k] = p.compact ? b : k * p.max_voxels;
-            b += min(w.nvox[k], p.max_voxels);
+    if (tile == 0 && f == 0 && wv == 14) {            // the batch's offsets table (off the critical path)
+        int carry = 0;
+        for (int k0 = 0; k0 < p.batch; k0 += 64) {
+            const int k = k0 + l;
+            const int c = (k < p.batch) ? vxl_frame_rows(p, w, G, k, fused) : 0;
+            const int inc = wave_incl_scan(c);
+            if (k < p.batch) voxel_offsets[k] = p.compact ? carry + inc - c : k * p.max_voxels;
+            carry += __shfl(inc, 63, 64);
         }
-        voxel_offsets[p.batch] = p.compact ? b : p.batch * p.max_voxels;
-        // rows the next call's fill role should clear up front (nobody reads fillst[0] during this launch)
-        const long long next = (long long)b + b / 4 + 1024;
-        w.fillst[0] = p.compact ? (int)min(next, (long long)p.batch * p.max_voxels) : 0x7fffffff;
+        if (l == 0) {
+            voxel_offsets[p.batch] = p.compact ? carry : p.batch * p.max_voxels;
+            // rows the next call's fill role should clear up front (nobody reads fillst[0] during this launch)
+            const long long next = (long long)carry + carry / 4 + 1024;
+            w.fillst[0] = p.compact ? (int)min(next, (long long)p.batch * p.max_voxels) : 0x7fffffff;
+        }
     }
     const long long cleared_rows = p.compact ? (long long)w.fillst[1] : 0x7fffffffll;
     const unsigned long long bal = __ballot(word != 0);
@@ -786,7 +853,416 @@ __global__ __launch_bounds__(1024) void vxl_emit_kernel(const float *__restrict_
     num_points[row] = cnt;
 }
 
+
+// ================================================================== fused key + bin launch (algo 3)
+// One launch instead of two, and no (point, key) queue in HBM (8 MB written + read per 16 frames): workgroup (g, f) reads
+// ALL points of frame f itself (320 KB, L2 / Infinity-Cache hits for 7 of the 8 bins), evaluates their cells and keeps
+// the ones whose key hashes to bin g, appended to the LDS entry list with one wave-aggregated LDS atomic per 64 points.
+// Phases B2..E are those of vxl_bin_kernel.  Every workgroup of the launch reserves the bin role's 144 KB of LDS, so the
+// launch is sized to ONE resident workgroup per CU: ids [0, nbinwg) are bin roles, the rest fill roles that clear the
+// padded output with grid-stride stores while the bin roles run their LDS phases (bin roles join in when they are done).
+// Degenerate input (thousands of points in one voxel, e.g. zero-padded clouds, where (0,0,0) lies inside the KITTI range):
+// when a bin receives more than VXL_CAP entries the workgroup switches to a streaming variant without an entry list —
+// pass 1 builds the table (first / count per voxel) straight from the points, pass 2 re-reads them for the insertion
+// chains and the per-point words — which is exact for any multiplicity; only more than ~VXL_S distinct voxels or more
+// than VXL_CAP list cells in ONE bin still raise the error flag.
+#define VXL_RISK_CAP 512     // parked points per bin workgroup (expected ~20 per frame); more -> the streaming variant
+#define VXL_A_U 20          // points per thread requested together in phase A (one round trip for a 20 k-point frame)
+struct VxlShared {
+    uint32_t *key;
+    int *first, *cnt;
+    int2 *q;
+    int *wtot, *tc, *nent, *total;
+};
+
+__device__ __forceinline__ void vxl_fill_chunks(float4 *__restrict__ dst, long long c0, long long cstep, long long cend,
+                                                long long lim_f4, int t) {
+    const float4 z = make_float4(0.f, 0.f, 0.f, 0.f);
+    for (long long c = c0; c < cend; c += cstep) {
+        const long long b = c * VXL_FILL_F4_PER_WG + t;
+#pragma unroll
+        for (int k = 0; k < 4; ++k)
+            if (b + k * 1024 < lim_f4) dst[b + k * 1024] = z;
+    }
+}
+
+template <bool C4>
+__device__ __forceinline__ void vxl_load_xyz(const float *__restrict__ points, size_t idx, int C, float &x, float &y, float &z) {
+    if (C4) {
+        const float4 v = reinterpret_cast<const float4 *>(points)[idx];
+        x = v.x; y = v.y; z = v.z;
+    } else {
+        const float *q = points + idx * C;
+        x = q[0]; y = q[1]; z = q[2];
+    }
+}
+
+__device__ __forceinline__ int vxl_bin_of(uint32_t key, int G) {
+    const uint32_t h2 = (key * 0x85EBCA6Bu) >> 16;
+    return (int)((h2 * (uint32_t)G) >> 16);
+}
+
+// the fused launch's bin of a pillar: full-rate 24-bit multiplies only (v_mul_lo_u32 is quarter rate)
+__device__ __forceinline__ int vxl_bin_of24(uint32_t pillar, int G) {
+    const uint32_t h = __umul24(pillar, 0x5BCA6Bu) ^ (pillar >> 9);
+    return (int)(__umul24((h >> 8) & 0xFFFFu, (uint32_t)G) >> 16);
+}
+
+// LDS table insert: slot of `key` (claimed if new), or -1 when the table is full
+__device__ __forceinline__ int vxl_table_insert(uint32_t *s_key, uint32_t key) {
+    uint32_t h = (key * 2654435761u) >> (32 - 13);  // log2(VXL_S) == 13
+    for (int probe = 0; probe < VXL_S; ++probe) {
+        const uint32_t old = atomicCAS(&s_key[h], VX_EMPTY, key);
+        if (old == VX_EMPTY || old == key) return (int)h;
+        h = (h + 1u) & (VXL_S - 1);
+    }
+    return -1;
+}
+
+// exclusive scan of m = min(count, P) over the table slots -> list offsets (into sh.key, whose keys are no longer needed by
+// the caller when `keep_keys` is false; the streaming variant passes a separate array); returns the total list length
+__device__ __forceinline__ int vxl_list_offsets(const VxlShared &sh, int P, int t, uint32_t *off_out) {
+    const int l = t & 63, wv = t >> 6;
+    int mloc[8];
+    int run = 0;
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {
+        mloc[k] = min(sh.cnt[t * 8 + k], P);
+        run += mloc[k];
+    }
+    const int inc = wave_incl_scan(run);
+    if (l == 63) sh.wtot[wv] = inc;
+    __syncthreads();
+    if (t == 0) {
+        int acc = 0;
+        for (int k = 0; k < 16; ++k) {
+            const int v = sh.wtot[k];
+            sh.wtot[k] = acc;
+            acc += v;
+        }
+        *sh.total = acc;
+    }
+    __syncthreads();
+    int off = sh.wtot[wv] + inc - run;
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {
+        off_out[t * 8 + k] = (uint32_t)off;
+        off += mloc[k];
+    }
+    return *sh.total;
+}
+
+// order-independent insertion of point j into the ascending list of its voxel's m smallest point indices
+__device__ __forceinline__ void vxl_chain_insert(int *cell0, int stride_ints, int m, int j) {
+    int x = j;
+    for (int s = 0; s < m; ++s) {
+        const int old = atomicMin(cell0 + (size_t)s * stride_ints, x);
+        if (old == VX_INF) break;
+        x = max(old, x);
+    }
+}
+
+template <bool C4>
+__device__ __forceinline__ void vxl_bin_streaming(const float *__restrict__ points, const VxParams &p, const VxWs &w, int G,
+                                               int g, int f, int start, int n, const VxlShared &sh) {
+    const int t = threadIdx.x, l = t & 63;
+    uint32_t *s_off = reinterpret_cast<uint32_t *>(sh.q);            // [VXL_S] list offset per slot
+    int *s_list = reinterpret_cast<int *>(sh.q) + VXL_S;             // [VXL_CAP - VXL_S / 2 ... ] list cells
+    const int LCAP = 2 * VXL_CAP - VXL_S;                            // ints left in the entry region (4096)
+    const int nt = (n + 1023) >> 10;
+    __syncthreads();                                                 // phase A's entry list is dropped: its LDS is re-used
+    // ---- pass 1: first point and count per voxel, straight from the points
+    for (int u = 0; u < nt; ++u) {
+        const int j = u * 1024 + t;
+        float x, y, z;
+        vxl_load_xyz<C4>(points, (size_t)start + min(j, n - 1), p.C, x, y, z);
+        uint32_t key, pil;
+        const bool mine = vx_cell_pillar(p, x, y, z, key, pil) && j < n && vxl_bin_of24(pil, G) == g;
+        if (mine) {
+            const int slot = vxl_table_insert(sh.key, key);
+            if (slot >= 0) {
+                atomicMin(&sh.first[slot], j);
+                atomicAdd(&sh.cnt[slot], 1);
+            } else {
+                vx_raise(w, 1);
+            }
+        }
+    }
+    __syncthreads();
+    const int total = vxl_list_offsets(sh, p.P, t, s_off);
+    if (total > min(LCAP, VXL_CAP) && t == 0) vx_raise(w, 2);
+    const int L = min(total, min(LCAP, VXL_CAP));
+    for (int k = t; k < L; k += 1024) s_list[k] = VX_INF;
+    __syncthreads();
+    // ---- pass 2: insertion chains, per-point words, per-tile first-point counts
+    int *pinfo = w.flagw + (size_t)f * p.n_max;
+    for (int u = 0; u < nt; ++u) {
+        const int j = u * 1024 + t;
+        float x, y, z;
+        vxl_load_xyz<C4>(points, (size_t)start + min(j, n - 1), p.C, x, y, z);
+        uint32_t key, pil;
+        const bool in_xy = vx_pillar(p, x, y, pil) && j < n && vxl_bin_of24(pil, G) == g;     // z-outside points of my pillars
+        const bool mine = vx_cell_pillar(p, x, y, z, key, pil) && in_xy;                       // get their word (0) from me too
+        int word = 0;
+        if (mine) {
+            uint32_t h = (key * 2654435761u) >> (32 - 13);
+            int slot = -1;
+            for (int probe = 0; probe < VXL_S; ++probe) {
+                const uint32_t k2 = sh.key[h];
+                if (k2 == key) { slot = (int)h; break; }
+                if (k2 == VX_EMPTY) break;
+                h = (h + 1u) & (VXL_S - 1);
+            }
+            if (slot >= 0) {
+                const int m = min(sh.cnt[slot], p.P), off = (int)s_off[slot];
+                if (off + m <= L) {
+                    if (sh.cnt[slot] == 1) s_list[off] = j;
+                    else vxl_chain_insert(s_list + off, 1, m, j);
+                    if (sh.first[slot] == j) word = m | ((g * VXL_CAP + off) << VXL_MBITS);
+                }
+            }
+        }
+        if (in_xy) pinfo[j] = word;
+        const unsigned long long bal = __ballot(word != 0);
+        if (l == 0 && bal) atomicAdd(&sh.tc[u], __popcll(bal));
+    }
+    __syncthreads();
+    int *stg = w.pfirst + ((size_t)f * G + g) * VXL_CAP;
+    for (int k = t; k < L; k += 1024) stg[k] = s_list[k];
+}
+
+template <bool C4>
+__global__ __launch_bounds__(1024) void vxl_keybin_kernel(const float *__restrict__ points, const int *__restrict__ offsets,
+                                                          VxParams p, VxWs w, int G, int nbinwg, int nfillwg,
+                                                          float *__restrict__ voxels, long long total_f4,
+                                                          long long tail_floats, int help16) {
+    __shared__ uint32_t s_key[VXL_S];   // keys; after phase C: list offset of the slot
+    __shared__ int s_first[VXL_S];
+    __shared__ int s_cnt[VXL_S];
+    __shared__ int2 s_q[VXL_CAP];       // (point, key); afterwards x = point | slot << 15, y = list cell
+    __shared__ int s_wtot[16];
+    __shared__ int s_tc[32];
+    __shared__ int s_nent, s_total, s_nrisk;
+    __shared__ float4 s_risk[VXL_RISK_CAP];   // points whose cell the exact division must decide: (x, y, z, index)
+    const int id = blockIdx.x, t = threadIdx.x, l = t & 63;
+    // ---- fill geometry (all roles): chunks of 64 KiB; the last help16/16 of them belong to the bin roles
+    const long long lim_rows = p.compact ? (long long)w.fillst[0] : 0x7fffffffll;
+    const long long lim_f4 = (lim_rows >= 0x7fffffffll) ? total_f4 : min(total_f4, (lim_rows * p.P * p.C + 3) / 4);
+    const long long nchunks = (lim_f4 + VXL_FILL_F4_PER_WG - 1) / VXL_FILL_F4_PER_WG;
+    const long long nhelp = nchunks * help16 / 16, nmain = nchunks - nhelp;
+    float4 *dst = reinterpret_cast<float4 *>(voxels);
+    if (id >= nbinwg) {                  // ---- fill role (block-uniform)
+        vxl_fill_chunks(dst, id - nbinwg, nfillwg, nmain, lim_f4, t);
+        if (id == nbinwg && (long long)t < tail_floats) voxels[total_f4 * 4 + t] = 0.f;     // bytes past the last float4
+        return;
+    }
+    // ---- bin role: id -> (g, f) with the G bins of a frame on ONE XCD (workgroup i runs on XCD i % 8): they share the
+    // frame's points through that XCD's L2
+    const int q8 = id >> 3;
+    const int f = (id & 7) + 8 * (q8 / G), g = q8 % G;
+    VxlShared sh;
+    sh.key = s_key; sh.first = s_first; sh.cnt = s_cnt; sh.q = s_q;
+    sh.wtot = s_wtot; sh.tc = s_tc; sh.nent = &s_nent; sh.total = &s_total;
+#ifdef VXL_STAMPS   // -DVXL_STAMPS: shader-clock stamps of bin role 0's phases into the error page (tools/vx_phase_probe.py)
+#define VXL_STAMP(k) do { if (id == 0 && t == 0) w.err[16 + (k)] = (int)clock64(); } while (0)
+#else
+#define VXL_STAMP(k) do { } while (0)
+#endif
+    VXL_STAMP(0);
+    if (f < p.batch) {
+        const int start = offsets[f];
+        const int n = min(offsets[f + 1] - start, p.n_max);
+        const int nt = (n + 1023) >> 10;
+        if (id == 0 && t == 0) w.fillst[1] = w.fillst[0];   // what the fill roles of THIS call use; the emit launch reads it
+        for (int k = t; k < VXL_S / 4; k += 1024) {
+            reinterpret_cast<uint4 *>(s_key)[k] = make_uint4(VX_EMPTY, VX_EMPTY, VX_EMPTY, VX_EMPTY);
+            reinterpret_cast<int4 *>(s_first)[k] = make_int4(VX_INF, VX_INF, VX_INF, VX_INF);
+            reinterpret_cast<int4 *>(s_cnt)[k] = make_int4(0, 0, 0, 0);
+        }
+        if (t < 32) s_tc[t] = 0;
+        if (t == 0) s_nent = s_nrisk = 0;
+        __syncthreads();
+        VXL_STAMP(1);
+        // ---- phase A: cells of ALL points of the frame — the 8-fold redundant part of the fused design and VALU-bound, so
+        // kept lean: branch-free fast cells (vx_cell_fast, 24-bit multiplies), ONE rarely taken wave-level branch per point
+        // for the exact re-evaluation of risky coordinates (the operands are still in registers: no reload) and one for
+        // points outside the grid.  Bins are by pillar, so a voxel's points meet in one bin.  A wave owns a contiguous run
+        // of points (its entries come out ascending, which keeps the later per-entry stores of a wave close together); one
+        // LDS atomic per wave for the whole frame.
+        int *pinfo = w.flagw + (size_t)f * p.n_max;
+        const int wv = t >> 6;
+        const int wbase = wv * nt * 64;     // first point of this wave's run; point (u, l) = wbase + u * 64 + l
+        const uint32_t nxy = (uint32_t)p.grid[0] * (uint32_t)p.grid[1];
+        uint32_t bits = 0;                  // bit (u - u0): that point goes to my bin
+        for (int u0 = 0; u0 < nt; u0 += VXL_A_U) {
+            float x[VXL_A_U], y[VXL_A_U], z[VXL_A_U];
+            uint32_t key[VXL_A_U];
+#pragma unroll
+            for (int u = 0; u < VXL_A_U; ++u) {
+                const int j = wbase + (u0 + u) * 64 + l;
+                vxl_load_xyz<C4>(points, (size_t)start + min(j, n - 1), p.C, x[u], y[u], z[u]);
+            }
+            bits = 0;
+            int wtotal = 0;                 // wave-uniform: entries of this wave in this round
+#pragma unroll
+            for (int u = 0; u < VXL_A_U; ++u) {
+                const int j = wbase + (u0 + u) * 64 + l;
+                int cx, cy, cz;
+                bool okx, oky, okz, rx, ry, rz;
+                vx_cell_fast(x[u] - p.lo[0], p.rvs[0], p.eabs[0], p.grid[0], cx, okx, rx);
+                vx_cell_fast(y[u] - p.lo[1], p.rvs[1], p.eabs[1], p.grid[1], cy, oky, ry);
+                vx_cell_fast(z[u] - p.lo[2], p.rvs[2], p.eabs[2], p.grid[2], cz, okz, rz);
+                const bool valid = (j < n) & (u0 + u < nt);
+                const bool risky = (rx | ry | rz) & valid;
+                const bool inside = okx & oky & okz;
+                const uint32_t pil = __umul24((uint32_t)cy, (uint32_t)p.grid[0]) + (uint32_t)cx;   // grids up to 2^24 cells per layer
+                key[u] = (uint32_t)cz * nxy + pil;
+                if (__builtin_expect(__ballot(risky) != 0ull, 0)) {       // wave-uniform, ~1 in 20 wave-iterations
+                    if (risky) {                                           // parked with its coordinates: settled after the barrier
+                        const int k = atomicAdd(&s_nrisk, 1);
+                        if (k < VXL_RISK_CAP) s_risk[k] = make_float4(x[u], y[u], z[u], __int_as_float(j));
+                    }
+                }
+                if (__builtin_expect(__ballot(!inside & valid & !risky) != 0ull, 0)) {            // wave-uniform, rare
+                    if (g == 0 && !inside && valid && !risky) pinfo[j] = 0;                       // a word of 0, written once
+                }
+                const bool mine = inside && valid && !risky && vxl_bin_of24(pil, G) == g;
+                bits |= (uint32_t)mine << u;
+                wtotal += __popcll(__ballot(mine));
+            }
+            int base = 0;
+            if (l == 0 && wtotal) base = atomicAdd(&s_nent, wtotal);
+            base = __shfl(base, 0, 64);
+#pragma unroll
+            for (int u = 0; u < VXL_A_U; ++u) {
+                const bool mine = (bits >> u) & 1u;
+                const unsigned long long bal = __ballot(mine);
+                const int pos = base + __popcll(bal & lanemask_lt());
+                if (mine && pos < VXL_CAP) s_q[pos] = make_int2(wbase + (u0 + u) * 64 + l, (int)key[u]);
+                base += __popcll(bal);
+            }
+        }
+        __syncthreads();
+        // the parked points (~0.1 %): the reference's expression with the IEEE division, once per workgroup
+        if (t < min(s_nrisk, VXL_RISK_CAP)) {
+            const float4 v = s_risk[t];
+            const int j = __float_as_int(v.w);
+            uint32_t key2, pil2;
+            if (vx_cell_pillar(p, v.x, v.y, v.z, key2, pil2)) {
+                if (vxl_bin_of24(pil2, G) == g) {
+                    const int pos = atomicAdd(&s_nent, 1);
+                    if (pos < VXL_CAP) s_q[pos] = make_int2(j, (int)key2);
+                }
+            } else if (g == 0) {
+                pinfo[j] = 0;
+            }
+        }
+        __syncthreads();
+        VXL_STAMP(2);
+        if (__builtin_expect(s_nent > VXL_CAP || s_nrisk > VXL_RISK_CAP, 0)) {   // block-uniform, degenerate input only
+            vxl_bin_streaming<C4>(points, p, w, G, g, f, start, n, sh);
+        } else {
+            const int ne = s_nent;
+            // ---- phase B2: dense insertion into the LDS hash table (first point, count per voxel)
+            for (int e = t; e < ne; e += 1024) {
+                const int2 q = s_q[e];
+                const int slot = vxl_table_insert(s_key, (uint32_t)q.y);
+                int en = q.x | (int)0x80000000;                       // table full: dead entry, word 0
+                if (slot >= 0) {
+                    atomicMin(&s_first[slot], q.x);
+                    atomicAdd(&s_cnt[slot], 1);
+                    en = q.x | (slot << 15);
+                } else {
+                    vx_raise(w, 1);
+                }
+                s_q[e].x = en;
+            }
+            __syncthreads();
+            VXL_STAMP(3);
+            // ---- phase C: list offsets (the keys are not needed any more: offsets overwrite them)
+            const int total = vxl_list_offsets(sh, p.P, t, s_key);
+            const int L = min(total, VXL_CAP);       // total <= ne <= VXL_CAP
+            for (int k = t; k < L; k += 1024) s_q[k].y = VX_INF;
+            __syncthreads();
+            VXL_STAMP(4);
+            // ---- phase D: ordered lists in LDS
+            for (int e = t; e < ne; e += 1024) {
+                const int en = s_q[e].x;
+                if (en < 0) continue;
+                const int j = en & 0x7FFF, slot = (en >> 15) & 0x1FFF;
+                const int c = s_cnt[slot];
+                int2 *Lp = s_q + s_key[slot];
+                if (c == 1) Lp[0].y = j;
+                else vxl_chain_insert(&Lp[0].y, 2, min(c, p.P), j);
+            }
+            __syncthreads();
+            VXL_STAMP(5);
+            // ---- phase E: per-point word + this bin's packed lists
+            for (int e = t; e < ne; e += 1024) {
+                const int en = s_q[e].x;
+                const int j = en & 0x7FFF;
+                int word = 0;
+                if (en >= 0) {
+                    const int slot = (en >> 15) & 0x1FFF;
+                    if (s_first[slot] == j) word = min(s_cnt[slot], p.P) | ((g * VXL_CAP + (int)s_key[slot]) << VXL_MBITS);
+                }
+                pinfo[j] = word;
+                const int tau = j >> 10;
+                unsigned long long rem = __ballot(word != 0);
+                while (rem) {                                  // wave-uniform; a wave sees few distinct tile ids
+                    const int lead = __builtin_ctzll(rem);
+                    const int t0 = __shfl(tau, lead, 64);
+                    const unsigned long long m = __ballot(word != 0 && tau == t0);
+                    if (l == lead) atomicAdd(&s_tc[t0], __popcll(m));
+                    rem &= ~m;
+                }
+            }
+            int *stg = w.pfirst + ((size_t)f * G + g) * VXL_CAP;
+            for (int k = t; k < L; k += 1024) stg[k] = s_q[k].y;
+        }
+        __syncthreads();
+        VXL_STAMP(6);
+        if (t < 32) w.tcnt[((size_t)f * G + g) * 32 + t] = s_tc[t];
+        if (t == 0) {
+            int tot = 0;
+            for (int k = 0; k < 32; ++k) tot += s_tc[k];
+            w.bvox[f * VXL_GMAX + g] = tot;                    // read by the emit launch
+        }
+    }
+    VXL_STAMP(7);
+    // ---- done with the index build: help with the tail of the fill
+    vxl_fill_chunks(dst, nmain + id, nbinwg, nchunks, lim_f4, t);
+}
+
 static int vxl_bins(int n_max) { return divup(n_max, VXL_PTS_PER_BIN); }
+
+static int vxl_env_int(const char *name, int dflt) {
+    const char *e = getenv(name);
+    return e ? atoi(e) : dflt;
+}
+
+// fused key + bin + fill launch, then emit: 2 launches
+static void vxl_run_fused(const float *points, const int *point_offsets, const VxParams &p, const VxWs &w, bool c4,
+                          float *voxels, int *coords, int *num_points, int *voxel_offsets, hipStream_t s) {
+    // share (in 1/16) of the fill left to the bin roles once they are done: 0 measured best (33.9 / 34.7 / 35.4 / 36.4 us
+    // for 1 / 2 / 3 / 4 sixteenths) — the bin roles are the longer pole of the launch
+    const int help16 = 0;
+    const int G = vxl_bins(p.n_max);
+    const int ntiles = divup(p.n_max, 1024);
+    const long long total_floats = (long long)p.max_voxels * p.P * p.C * p.batch;
+    const bool fill_f4 = (reinterpret_cast<uintptr_t>(voxels) & 15) == 0;
+    const long long total_f4 = fill_f4 ? total_floats / 4 : 0;
+    const long long tail_floats = total_floats - total_f4 * 4;
+    const int nbinwg = 8 * G * divup(p.batch, 8);
+    const int nfillwg = nbinwg < 192 ? 256 - nbinwg : 64;              // one resident workgroup per CU (LDS-bound)
+    if (tail_floats > 1024) (void)hipMemsetAsync(voxels, 0, (size_t)total_floats * sizeof(float), s);   // unaligned buffer
+    const long long tf = tail_floats <= 1024 ? tail_floats : 0;
+    if (c4) hipLaunchKernelGGL(vxl_keybin_kernel<true>, dim3(nbinwg + nfillwg), dim3(1024), 0, s, points, point_offsets, p, w, G, nbinwg, nfillwg, voxels, total_f4, tf, help16);
+    else hipLaunchKernelGGL(vxl_keybin_kernel<false>, dim3(nbinwg + nfillwg), dim3(1024), 0, s, points, point_offsets, p, w, G, nbinwg, nfillwg, voxels, total_f4, tf, help16);
+    const dim3 ge(ntiles, p.batch);
+    if (c4) hipLaunchKernelGGL(vxl_emit_kernel<true>, ge, dim3(1024), 0, s, points, point_offsets, p, w, G, voxels, coords, num_points, voxel_offsets, 1);
+    else hipLaunchKernelGGL(vxl_emit_kernel<false>, ge, dim3(1024), 0, s, points, point_offsets, p, w, G, voxels, coords, num_points, voxel_offsets, 1);
+}
 
 static void vxl_run(const float *points, const int *point_offsets, const VxParams &p, const VxWs &w, bool c4,
                     float *voxels, int *coords, int *num_points, int *voxel_offsets, hipStream_t s) {
@@ -813,8 +1289,8 @@ static void vxl_run(const float *points, const int *point_offsets, const VxParam
     else if (items <= 24) hipLaunchKernelGGL(vxl_bin_kernel<24>, gb, dim3(1024), 0, s, point_offsets, p, w, G);
     else hipLaunchKernelGGL(vxl_bin_kernel<32>, gb, dim3(1024), 0, s, point_offsets, p, w, G);
     const dim3 ge(ntiles, p.batch);
-    if (c4) hipLaunchKernelGGL(vxl_emit_kernel<true>, ge, dim3(1024), 0, s, points, point_offsets, p, w, G, voxels, coords, num_points, voxel_offsets);
-    else hipLaunchKernelGGL(vxl_emit_kernel<false>, ge, dim3(1024), 0, s, points, point_offsets, p, w, G, voxels, coords, num_points, voxel_offsets);
+    if (c4) hipLaunchKernelGGL(vxl_emit_kernel<true>, ge, dim3(1024), 0, s, points, point_offsets, p, w, G, voxels, coords, num_points, voxel_offsets, 0);
+    else hipLaunchKernelGGL(vxl_emit_kernel<false>, ge, dim3(1024), 0, s, points, point_offsets, p, w, G, voxels, coords, num_points, voxel_offsets, 0);
 }
 
 // ------------------------------------------------------------------ C ABI
@@ -832,6 +1308,19 @@ LIDAR_EXPORT int lidar_voxelize_workspace_init(void *ws, size_t ws_bytes, int ba
     const long long nh = (long long)batch * vx_hash_capacity(n_max), nl = (long long)batch * n_max;
     hipLaunchKernelGGL(vx_ws_init_kernel, dim3(1024), dim3(256), 0, (hipStream_t)stream, w, nh, nl, 0LL);
     return lidar_check_launch("vx_ws_init");
+}
+
+// Registers a device-visible host address (pinned + mapped, e.g. a pinned torch tensor's data_ptr) that receives the
+// error bits as well: the host can then poll the flag at no cost (no copy, no synchronisation).  nullptr unregisters.
+__global__ void vx_set_mirror_kernel(VxWs w, int *host_flag) { *w.mirror = host_flag; }
+
+LIDAR_EXPORT int lidar_voxelize_set_error_mirror(void *ws, size_t ws_bytes, int batch, int n_max, int max_voxels,
+                                                 int *host_flag, void *stream) {
+    VxWs w;
+    if (n_max <= 0) n_max = 1;
+    if (!ws || vx_carve(ws, batch, n_max, max_voxels, &w) > ws_bytes) return LIDAR_ERR_WORKSPACE;
+    hipLaunchKernelGGL(vx_set_mirror_kernel, dim3(1), dim3(1), 0, (hipStream_t)stream, w, host_flag);
+    return lidar_check_launch("vx_set_mirror");
 }
 
 // sticky overflow flag of the LDS-binned path (0 = fine).  Host-synchronous: call outside captures.
@@ -858,6 +1347,7 @@ LIDAR_EXPORT int lidar_voxelize(const float *points, const int *point_offsets, i
         p.lo[j] = range6[j];
         p.vs[j] = voxel_size3[j];
         p.rvs[j] = 1.0f / voxel_size3[j];
+        p.eabs[j] = fminf(((float)grid3[j] + 2.0f) * 4.9e-7f, 0.5f);
         p.grid[j] = grid3[j];
     }
     p.C = num_features;
@@ -876,10 +1366,17 @@ LIDAR_EXPORT int lidar_voxelize(const float *points, const int *point_offsets, i
     hipStream_t s = (hipStream_t)stream;
     const bool c4 = (num_features == 4) && ((reinterpret_cast<uintptr_t>(points) & 15) == 0) &&
                     ((reinterpret_cast<uintptr_t>(voxels) & 15) == 0);
-    // algo 0 = auto, 1 = LDS-binned (n_max <= 32768, max_points < 65536), 2 = global hash table
+    // algo 0 = auto, 1 = LDS-binned 3 launches, 3 = LDS-binned fused 2 launches (both: n_max <= 32768, max_points < 16384),
+    // 2 = global hash table (any size)
     const bool lds_ok = (n_max <= VXL_MAX_ITEMS * 1024) && (max_points <= VXL_MMASK);
-    if (algo == 1 && !lds_ok) return LIDAR_ERR_ARG;
-    if (algo == 1 || (algo == 0 && lds_ok)) {
+    if ((algo == 1 || algo == 3) && !lds_ok) return LIDAR_ERR_ARG;
+    static const int auto_algo = vxl_env_int("LIDAR_VXL_ALGO", 3);
+    if (algo == 0 && lds_ok) algo = (auto_algo == 1) ? 1 : 3;
+    if (algo == 3) {
+        vxl_run_fused(points, point_offsets, p, w, c4, voxels, coords, num_points, voxel_offsets, s);
+        return lidar_check_launch("lidar_voxelize(fused)");
+    }
+    if (algo == 1) {
         vxl_run(points, point_offsets, p, w, c4, voxels, coords, num_points, voxel_offsets, s);
         return lidar_check_launch("lidar_voxelize(lds)");
     }

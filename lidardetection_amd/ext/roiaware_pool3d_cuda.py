@@ -39,6 +39,9 @@ def points_in_boxes_cpu(boxes, pts, pts_indices):
     """roiaware_pool3d.cpp:143-168 — CPU tensors: boxes (N,7), pts (P,3), pts_indices (N,P) int32 0/1."""
     if boxes.is_cuda or pts.is_cuda or pts_indices.is_cuda:
         raise _lib.LidarHipError("points_in_boxes_cpu takes CPU tensors")
-    _lib.check(_lib.lib().lidar_points_in_boxes_cpu(_p(boxes.contiguous()), boxes.shape[0], _p(pts.contiguous()), pts.shape[0],
+    if not pts_indices.is_contiguous():
+        raise _lib.LidarHipError("points_in_boxes_cpu: pts_indices must be contiguous (it is written in place)")
+    boxes_c, pts_c = boxes.contiguous(), pts.contiguous()      # bound to locals: they must outlive the call
+    _lib.check(_lib.lib().lidar_points_in_boxes_cpu(_p(boxes_c), boxes_c.shape[0], _p(pts_c), pts_c.shape[0],
                                                     _p(pts_indices)), "lidar_points_in_boxes_cpu")
     return 1

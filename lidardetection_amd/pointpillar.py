@@ -22,7 +22,7 @@ import torch
 import torch.nn as nn
 
 from . import anchor_post, pillar_ops, synth
-from .bev_backbone import FoldedBEVBackbone
+from .bev_backbone import FoldedBEVBackbone, collect_params, params_key
 from .ext import iou3d_nms_cuda
 from .voxelizer import BatchVoxelizer, grid_size_of
 
@@ -116,11 +116,20 @@ class PointPillarKITTI(nn.Module):
         return self
 
     def _pfn_folded(self):
-        if self._folded is None:
+        """folded PFN weights, rebuilt whenever a source parameter / BN statistic changed (load_state_dict, training step)"""
+        if getattr(self, "_pfn_srcs", None) is None:
+            self._pfn_srcs = collect_params(self.pfn_linear, self.pfn_norm)
+        key = params_key(self._pfn_srcs)
+        if self._folded is None or self._folded[0] != key:
             n = self.pfn_norm
             s, t = pillar_ops.fold_bn(n.weight.detach(), n.bias.detach(), n.running_mean, n.running_var, n.eps)
-            self._folded = (self.pfn_linear.weight.detach().contiguous(), s, t)
-        return self._folded
+            self._folded = (key, (self.pfn_linear.weight.detach().contiguous(), s, t))
+        return self._folded[1]
+
+    def _bev_folded(self):
+        if self._bev is None or self._bev.stale():
+            self._bev = FoldedBEVBackbone(self.blocks, self.deblocks, [self.conv_cls, self.conv_box, self.conv_dir_cls])
+        return self._bev
 
     # ---- stages (kept separate so bench.py can time them) ------------------------------------
     def voxelize(self, points, point_offsets):
@@ -139,9 +148,7 @@ class PointPillarKITTI(nn.Module):
 
     def backbone_head(self, canvas):
         if self.fold_bn:
-            if self._bev is None:
-                self._bev = FoldedBEVBackbone(self.blocks, self.deblocks, [self.conv_cls, self.conv_box, self.conv_dir_cls])
-            return (self._bev.merged(canvas),)          # (B, H, W, 18 + 42 + 12): consumed in place by post_process
+            return (self._bev_folded().merged(canvas),)  # (B, H, W, 18 + 42 + 12): consumed in place by post_process
         return self.backbone_head_stock(canvas)
 
     def split_heads(self, head):

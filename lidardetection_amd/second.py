@@ -55,9 +55,7 @@ class SECONDKitti(PointPillarKITTI):
         return bd["encoded_spconv_tensor"].dense_bev()          # (B, 128 * 2, 200, 176), channels-last, one pass
 
     def backbone_head(self, canvas):
-        if self._bev is None:
-            self._bev = FoldedBEVBackbone(self.blocks, self.deblocks, [self.conv_cls, self.conv_box, self.conv_dir_cls])
-        return (self._bev.merged(canvas),)
+        return (self._bev_folded().merged(canvas),)
 
     @torch.no_grad()
     def forward(self, points, point_offsets):

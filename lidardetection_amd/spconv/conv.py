@@ -110,22 +110,21 @@ class SparseConvolution(SparseModule):
             _schedule_mask_order(datas, "order", datas["nbr"])
 
     def _resolve(self, input):
-        """-> (indices, out_indices, out_shape, fwd_table, bwd_table, flip) for this layer on `input` (rulebook built
-        or fetched through indice_key); tables are None for a 1x1 convolution.  self._datas = the rulebook dict used."""
-        self._datas = None
+        """-> (indices, out_indices, out_shape, fwd_table, bwd_table, flip, datas) for this layer on `input` (rulebook built
+        or fetched through indice_key); tables are None for a 1x1 convolution; datas = the rulebook dict used (returned,
+        not kept on the module: a module may be entered again before an earlier call has finished)."""
         indices = input.indices
         spatial_shape, batch_size = input.spatial_shape, input.batch_size
         if indices.dtype != torch.int32:
             indices = indices.int()
         indices = indices.contiguous()
         if self.conv1x1 and not self.inverse:
-            return indices, indices, spatial_shape, None, None, False
+            return indices, indices, spatial_shape, None, None, False, None
         datas = input.find_indice_pair(self.indice_key)
         if self.inverse:
             assert datas is not None and self.indice_key is not None, "inverse conv needs the rulebook of its paired conv"
             assert datas["out_indices"].shape[0] == indices.shape[0], "inverse conv input does not match the paired conv's output"
-            self._datas = datas
-            return indices, datas["in_indices"], datas["in_spatial_shape"], datas["nbr_t"], datas["nbr"], False
+            return indices, datas["in_indices"], datas["in_spatial_shape"], datas["nbr_t"], datas["nbr"], False, datas
         if self.subm:
             if datas is None:
                 nbr = ops.subm_rulebook(indices, spatial_shape, self.kernel_size)
@@ -133,8 +132,7 @@ class SparseConvolution(SparseModule):
                          "in_spatial_shape": spatial_shape, "out_spatial_shape": spatial_shape}
                 if self.indice_key is not None:
                     input.indice_dict[self.indice_key] = datas
-            self._datas = datas
-            return indices, indices, spatial_shape, datas["nbr"], datas["nbr"], True
+            return indices, indices, spatial_shape, datas["nbr"], datas["nbr"], True, datas
         out_shape = ops.get_conv_output_size(spatial_shape, self.kernel_size, self.stride, self.padding)
         if datas is None:
             out_indices, nbr, nbr_t = ops.conv_rulebook(indices, batch_size, spatial_shape, self.kernel_size, self.stride,
@@ -143,23 +141,20 @@ class SparseConvolution(SparseModule):
                      "in_spatial_shape": spatial_shape, "out_spatial_shape": out_shape}
             if self.indice_key is not None:
                 input.indice_dict[self.indice_key] = datas
-        self._datas = datas
-        return indices, datas["out_indices"], out_shape, datas["nbr"], datas["nbr_t"], False
+        return indices, datas["out_indices"], out_shape, datas["nbr"], datas["nbr_t"], False, datas
 
     def forward(self, input):
         assert isinstance(input, SparseConvTensor)
-        indices, out_indices, out_shape, fwd_table, bwd_table, flip = self._resolve(input)
+        indices, out_indices, out_shape, fwd_table, bwd_table, flip, datas = self._resolve(input)
         if fwd_table is None:
             f = torch.mm(input.features, self.weight.view(self.in_channels, self.out_channels))
             if self.bias is not None:
                 f = f + self.bias
         else:
             # mask orders are cached per table in the rulebook dict: "order" belongs to datas["nbr"], "order_t" to datas["nbr_t"]
-            datas = self._datas
             keys = ("order_t", "order") if self.inverse else (("order", "order") if self.subm else ("order", "order_t"))
             orders = (datas, *keys) if (input.features.is_cuda and fwd_table.shape[1] <= 31) else None
             f = ops.indice_conv(input.features, self.weight, self.bias, fwd_table, bwd_table, flip, orders)
-        self._datas = None
         out = SparseConvTensor(f, out_indices, out_shape, input.batch_size)
         out.indice_dict, out.grid = input.indice_dict, input.grid
         return out
@@ -188,7 +183,7 @@ class SparseConvolution(SparseModule):
         Equals the unfused module sequence to fp32 rounding (one re-associated multiply)."""
         assert isinstance(input, SparseConvTensor)
         assert bn is None or (not bn.training and bn.track_running_stats), "BatchNorm must be in eval mode to be folded"
-        indices, out_indices, out_shape, fwd_table, _, _ = self._resolve(input)
+        indices, out_indices, out_shape, fwd_table, _, _, datas = self._resolve(input)
         w, b = self._folded(bn)
         feats = input.features.detach().contiguous()
         if fwd_table is None:
@@ -198,12 +193,11 @@ class SparseConvolution(SparseModule):
             if relu:
                 f = torch.relu_(f)
         else:
-            st, datas = None, self._datas
+            st = None
             if ops.sorted_gemm_supported(w.shape[0], self.in_channels, self.out_channels):
                 # mask order of the table's rows, shared through indice_key
                 st = ops.cached_mask_order(datas, "order_t" if self.inverse else "order", fwd_table)
             f = ops.indice_conv_fused(feats, fwd_table, w, b, None if residual is None else residual.contiguous(), relu, st)
-        self._datas = None
         out = SparseConvTensor(f, out_indices, out_shape, input.batch_size)
         out.indice_dict, out.grid = input.indice_dict, input.grid
         return out

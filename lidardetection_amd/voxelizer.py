@@ -26,7 +26,7 @@ class BatchVoxelizer:
         self.max_num_points = int(max_num_points)
         self.max_voxels = int(max_voxels)
         self.C = int(num_point_features)
-        self.algo = int(algo)  # 0 auto, 1 LDS-binned, 2 global hash (include/lidar_hip.h)
+        self.algo = int(algo)  # 0 auto, 1 LDS-binned (3 launches), 3 LDS-binned fused (2 launches), 2 global hash (include/lidar_hip.h)
         self._range_h = _lib.host_f32(self.point_cloud_range)
         self._vs_h = _lib.host_f32(self.voxel_size)
         self._grid_h = _lib.host_i32(self.grid_size)
@@ -41,9 +41,26 @@ class BatchVoxelizer:
             ws = torch.empty(nbytes, dtype=torch.uint8, device=device)
             _lib.check(L.lidar_voxelize_workspace_init(_lib.ptr(ws), nbytes, batch, n_max, self.max_voxels,
                                                        _lib.stream()), "lidar_voxelize_workspace_init")
-            ent = (ws, nbytes)
+            # the kernels mirror their sticky error bits into this pinned host word (device-visible on ROCm): the hot path
+            # polls it on the host at no cost — no copy, no synchronisation (lidar_voxelize_set_error_mirror)
+            mirror = torch.zeros(1, dtype=torch.int32).pin_memory()
+            _lib.check(L.lidar_voxelize_set_error_mirror(_lib.ptr(ws), nbytes, batch, n_max, self.max_voxels, _lib.ptr(mirror),
+                                                         _lib.stream()), "lidar_voxelize_set_error_mirror")
+            ent = (ws, nbytes, mirror)
             self._ws = {key: ent}  # keep one workspace alive
         return ent
+
+    def poll_error(self):
+        """Sync-free look at the mirrored sticky flag of the live workspace: raises if an EARLIER call overflowed an LDS hash
+        bin (its output was then wrong).  __call__ polls on entry, so a bad batch is reported one call late at the latest;
+        callers that need it at once use check_error_flag (one device read) or voxelize_frames (redoes the batch)."""
+        for ws, nbytes, mirror in self._ws.values():
+            flag = int(mirror[0])
+            if flag != 0:
+                mirror[0] = 0
+                self._ws = {}                 # a fresh workspace (and a cleared device flag) for whatever comes next
+                raise _lib.LidarHipError(f"lidar_voxelize: an earlier call overflowed an LDS hash bin (flag {flag}): its voxels are "
+                                         "incomplete; use algo=2 (global hash) for such input")
 
     def alloc_outputs(self, batch, device):
         rows = batch * self.max_voxels
@@ -65,7 +82,8 @@ class BatchVoxelizer:
             raise _lib.LidarHipError(f"points must be (N, {self.C})")
         batch = point_offsets.numel() - 1
         n_max = max(int(n_max), 1)
-        ws, nbytes = self._workspace(batch, n_max, points.device)
+        self.poll_error()
+        ws, nbytes, _ = self._workspace(batch, n_max, points.device)
         if out is None:
             out = self.alloc_outputs(batch, points.device)
         L = _lib.lib()
@@ -78,7 +96,7 @@ class BatchVoxelizer:
 
     def error_flag(self, batch, n_max, device):
         """Host-synchronous read of the LDS-binned path's sticky overflow flag (0 = fine)."""
-        ws, nbytes = self._workspace(batch, max(int(n_max), 1), device)
+        ws, nbytes, _ = self._workspace(batch, max(int(n_max), 1), device)
         return _lib.lib().lidar_voxelize_error_flag(_lib.ptr(ws), nbytes, batch, max(int(n_max), 1), self.max_voxels)
 
     def check_error_flag(self, batch, n_max, device):
@@ -98,7 +116,7 @@ class BatchVoxelizer:
         out = self(pts, offs_d, n_max, compact=True)
         total = int(out["voxel_offsets"][-1].item())
         if self.algo != 2 and self.error_flag(len(sizes), n_max, pts.device) != 0:
-            # a hash bin overflowed its LDS budget (thousands of points in one bin: adversarial or degenerate input):
+            # a hash bin overflowed its LDS budget (thousands of distinct voxels in one bin: adversarial input):
             # redo the batch on the global-hash path, which has no such limit (the sticky flag is cleared by re-init)
             self._ws = {}
             keep, self.algo = self.algo, 2

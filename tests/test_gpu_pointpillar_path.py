@@ -20,8 +20,8 @@ pytestmark = pytest.mark.gpu
 def _check_voxel_parity(frames, vs, rng, P, maxv, C, dev, repeat=2):
     exp = [c_oracle.voxelize(f, vs, rng, P, maxv) for f in frames]
     ev, ec, en = pp_oracle.collate(exp)
-    # both kernel paths: 1 = LDS-binned hashing (default for n_max <= 32768), 2 = global hash table
-    for algo in (1, 2):
+    # all kernel paths: 3 = LDS-binned fused 2-launch (default for n_max <= 32768), 1 = LDS-binned 3-launch, 2 = global hash
+    for algo in (3, 1, 2):
         _check_one_algo(frames, vs, rng, P, maxv, C, dev, repeat, algo, exp, ev, ec, en)
 
 
@@ -67,13 +67,15 @@ def test_voxelize_out_of_range_and_edges(dev):
     _check_voxel_parity([pts], synth.PP_VOXEL, synth.PP_RANGE, 32, 16000, 4, dev)
 
 
-def test_voxelize_bin_overflow_falls_back(dev):
-    """20 000 points in ONE pillar overflow a single LDS hash bin: voxelize_frames detects the sticky flag and redoes the
-    batch on the global-hash path; results still equal the sequential oracle."""
+@pytest.mark.parametrize("algo", [0, 1])
+def test_voxelize_bin_overflow_falls_back(dev, algo):
+    """20 000 points in ONE pillar put more entries into a single LDS hash bin than its entry list holds.  The fused path
+    (algo 0 -> 3) switches that bin to its streaming variant and stays exact WITHOUT raising the flag; the 3-launch path
+    (algo 1) sets the sticky flag, voxelize_frames sees it and redoes the batch on the global-hash path."""
     r = np.random.default_rng(3)
     pts = np.concatenate([r.uniform(10.0, 10.15, (20000, 2)), r.uniform(-2, 0, (20000, 1)), r.uniform(0, 1, (20000, 1))], 1).astype(np.float32)
     other = synth.cloud_ring(2003)[:3000]
-    vz = BatchVoxelizer(synth.PP_VOXEL, synth.PP_RANGE, 32, 16000)
+    vz = BatchVoxelizer(synth.PP_VOXEL, synth.PP_RANGE, 32, 16000, algo=algo)
     exp = [c_oracle.voxelize(f, synth.PP_VOXEL, synth.PP_RANGE, 32, 16000) for f in (pts, other)]
     ev, ec, en = pp_oracle.collate(exp)
     for _ in range(2):
@@ -81,8 +83,74 @@ def test_voxelize_bin_overflow_falls_back(dev):
         assert np.array_equal(out["voxel_coords"].cpu().numpy(), ec.astype(np.int32))
         assert np.array_equal(out["voxel_num_points"].cpu().numpy(), en)
         assert np.array_equal(out["voxels"].cpu().numpy(), ev)
+        if algo == 0:
+            assert vz.error_flag(2, 20000, dev) == 0
     out = vz.voxelize_frames([other], device=dev)      # and the fast path works again afterwards
     assert np.array_equal(out["voxels"].cpu().numpy(), exp[1][0])
+
+
+def _zero_padded(frame, n_pad):
+    return np.concatenate([frame, np.zeros((n_pad, frame.shape[1]), np.float32)], 0)
+
+
+def test_voxelize_zero_padded_clouds_on_the_hot_path(dev):
+    """Zero-padded frames (the padding lands in ONE voxel: (0,0,0) lies inside the KITTI range) through BatchVoxelizer.__call__
+    — the sync-free entry the model forwards and bench.py use: exact, and no error flag (this used to drop points
+    silently once a bin held more than 6144 entries)."""
+    P, maxv = 32, 16000
+    frames = [_zero_padded(synth.cloud_ring(2000)[:9000], 11000), _zero_padded(synth.cloud_uniform(1000, n=12000), 8000),
+              synth.cloud_uniform(1001)]
+    vz = BatchVoxelizer(synth.PP_VOXEL, synth.PP_RANGE, P, maxv, 4)
+    sizes = [len(f) for f in frames]
+    pts = torch.from_numpy(np.concatenate(frames)).to(dev)
+    offs = torch.tensor(np.concatenate([[0], np.cumsum(sizes)]), dtype=torch.int32, device=dev)
+    for _ in range(2):
+        o = vz(pts, offs, max(sizes), compact=True)
+        offsets = o["voxel_offsets"].cpu().numpy()
+        for f, pf in enumerate(frames):
+            vo, co, nu = c_oracle.voxelize(pf, synth.PP_VOXEL, synth.PP_RANGE, P, maxv)
+            a, b = int(offsets[f]), int(offsets[f + 1])
+            assert b - a == len(vo), f
+            assert np.array_equal(o["voxels"][a:b].cpu().numpy(), vo), f
+            assert np.array_equal(o["voxel_num_points"][a:b].cpu().numpy(), nu)
+            assert np.array_equal(o["voxel_coords"][a:b, 1:].cpu().numpy(), co)
+    torch.cuda.synchronize()
+    vz.poll_error()                                     # nothing was raised
+    assert vz.error_flag(len(frames), max(sizes), dev) == 0
+
+
+def _cells_of_one_bin(n_cells, G, nx=432, ny=496):
+    """pillar centres of `n_cells` distinct PointPillar cells whose keys all fall into hash bin 0 of G (csrc/voxelize.hip)"""
+    key = np.arange(nx * ny, dtype=np.uint64)           # vxl_bin_of24: 24-bit multiplies, bins by pillar
+    h = (((key & np.uint64(0xFFFFFF)) * np.uint64(0x5BCA6B)) & np.uint64(0xFFFFFFFF)) ^ (key >> np.uint64(9))
+    sel = key[((((h >> np.uint64(8)) & np.uint64(0xFFFF)) * np.uint64(G)) >> np.uint64(16)) == 0][:n_cells].astype(np.int64)
+    assert len(sel) == n_cells
+    pts = np.zeros((n_cells, 4), np.float32)
+    pts[:, 0] = (sel % nx + 0.5) * 0.16
+    pts[:, 1] = (sel // nx + 0.5) * 0.16 - 39.68
+    pts[:, 2] = -1.0
+    return pts
+
+
+def test_voxelize_true_bin_overflow_is_reported_without_a_sync(dev):
+    """9 000 DISTINCT pillars in one LDS hash bin (adversarial: built from the hash itself) exceed the bin's table.  The
+    kernels mirror the sticky flag into pinned host memory: __call__ raises at the next call without any device read;
+    voxelize_frames redoes the batch on the global-hash path and is exact."""
+    from lidardetection_amd import _lib
+    adv = _cells_of_one_bin(9000, G=8)                  # n_max 20000 -> 8 bins per frame
+    frames = [np.concatenate([adv, synth.cloud_uniform(1000, n=11000)], 0)]
+    vz = BatchVoxelizer(synth.PP_VOXEL, synth.PP_RANGE, 32, 16000, 4)
+    pts = torch.from_numpy(frames[0]).to(dev)
+    offs = torch.tensor([0, len(frames[0])], dtype=torch.int32, device=dev)
+    vz(pts, offs, 20000)
+    torch.cuda.synchronize()                            # (only so that the test is deterministic: the mirror write has landed)
+    with pytest.raises(_lib.LidarHipError):
+        vz(pts, offs, 20000)
+    out = vz.voxelize_frames(frames, device=dev)        # detects, falls back, exact
+    vo, co, nu = c_oracle.voxelize(frames[0], synth.PP_VOXEL, synth.PP_RANGE, 32, 16000)
+    assert np.array_equal(out["voxels"].cpu().numpy(), vo)
+    assert np.array_equal(out["voxel_coords"][:, 1:].cpu().numpy(), co)
+    assert np.array_equal(out["voxel_num_points"].cpu().numpy(), nu)
 
 
 def test_pillar_vfe_vs_reference_golden(dev, golden_dir):
@@ -170,6 +238,36 @@ def test_rotated_nms_keep_bit_exact(dev, thresh, seed, objects):
     assert keep[:num].tolist() == keep_o.tolist()
     sel, _ = iou3d_nms_utils.nms_gpu(torch.from_numpy(boxes).to(dev), torch.from_numpy(scores).to(dev), thresh)
     assert sel.cpu().tolist() == order[keep_o].tolist()
+
+
+@pytest.mark.parametrize("thresh", [0.01, 0.1, 0.7])
+@pytest.mark.parametrize("seed,objects,copies", [(3020, 2, 700), (3021, 3, 500)])
+def test_rotated_nms_dense_tiles_bit_exact(dev, thresh, seed, objects, copies):
+    """A few objects with hundreds of proposals each: almost every pair of a 64x64 tile passes the bounding-circle test, so the
+    tile has more candidates than the pair list holds (NMS_PAIR_CAP) and runs in four 16-row rounds (this path
+    had no test).  Mask words and keep list vs the oracle; pairs whose oracle IoU lies within 2e-6 of the threshold may flip
+    with the last ulp of the trig functions and are taken from the device before the greedy replay."""
+    boxes, scores = synth.boxes_nms(seed=seed, objects=objects, copies=copies)
+    order = np.argsort(-scores, kind="stable")
+    bs = boxes[order]
+    n = len(bs)
+    mask_o = c_oracle.nms_mask(bs, thresh)
+    iou = c_oracle.pairwise(bs, bs, 1)
+    assert ((iou > 0).sum() - n) / (n * (n - 1)) > 0.25          # dense: over a quarter of all pairs overlap
+    tb = torch.from_numpy(bs).to(dev)
+    mask_d = iou3d_nms_cuda.nms_mask_debug(tb, thresh).cpu().numpy().view(np.uint64)
+    near = np.argwhere(np.abs(iou - thresh) < 2e-6)
+    for i, j in near:
+        if j > i:                                                  # upper triangle only (what the greedy reads)
+            bit = np.uint64(1) << np.uint64(j % 64)
+            mask_o[i, j // 64] = (mask_o[i, j // 64] & ~bit) | (mask_d[i, j // 64] & bit)
+    print(f"thr {thresh}: {len(near)} pairs within 2e-6 of the threshold")
+    for i in range(n):
+        assert np.array_equal(mask_d[i, i // 64:], mask_o[i, i // 64:]), f"mask row {i}"
+    keep_o = c_oracle.nms_greedy(mask_o)
+    keep = torch.LongTensor(n)
+    num = iou3d_nms_cuda.nms_gpu(tb, keep, thresh)
+    assert keep[:num].tolist() == keep_o.tolist()
 
 
 def test_nms_normal_and_pre_maxsize(dev):
