@@ -61,6 +61,17 @@ int lidar_voxelize_set_error_mirror(void *ws, size_t ws_bytes, int batch, int n_
 /* host-synchronous read of the sticky overflow flag of algo 1 / 3 (0 = fine); not for use inside captures */
 int lidar_voxelize_error_flag(void *ws, size_t ws_bytes, int batch, int n_max, int max_voxels);
 
+/* HOST voxel generator: spconv.utils.VoxelGeneratorV2.generate for ONE frame on a CPU core, for the reference's real call
+ * site — DataProcessor.transform_points_to_voxels inside forked DataLoader workers (pcdet/datasets/processor/
+ * data_processor.py:48-80, pcdet/datasets/__init__.py:73), which must not touch the GPU.  Touches no HIP state.
+ *   points (n, C) f32 HOST; voxels (max_voxels, max_points, C), coords_zyx (max_voxels, 3) [z, y, x], num_points (max_voxels)
+ *   caller-allocated and UNinitialised: rows [0, return value) are fully written (zero padded), the rest is left alone.
+ *   scratch: lidar_voxelize_cpu_scratch_bytes(n) bytes.  Returns the voxel count (>= 0) or a negative LIDAR_ERR_*. */
+size_t lidar_voxelize_cpu_scratch_bytes(int n);
+int lidar_voxelize_cpu(const float *points, int n, int num_features, const float *range6, const float *voxel_size3,
+                       const int *grid3, int max_points, int max_voxels, float *voxels, int *coords_zyx, int *num_points,
+                       void *scratch, size_t scratch_bytes);
+
 /* ------------------------------------------------------------------ PillarVFE (one PFN layer, eval)
  * Replaces PillarVFE.forward + PFNLayer.forward (pcdet/models/backbones_3d/vfe/pillar_vfe.py:94-123,
  * :29-49) with BatchNorm1d(eps=1e-3) in eval mode folded by the caller:

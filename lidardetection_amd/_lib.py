@@ -75,6 +75,8 @@ SIGNATURES = {
     "lidar_rotate_iou_eval": (i32, [vp, i32, vp, i32, i32, vp, vp]),
     "lidar_boxes_iou_bev_cpu": (i32, [vp, i32, vp, i32, vp]),
     "lidar_points_in_boxes_cpu": (i32, [vp, i32, vp, i32, vp]),
+    "lidar_voxelize_cpu_scratch_bytes": (sz, [i32]),
+    "lidar_voxelize_cpu": (i32, [vp, i32, i32, vp, vp, vp, i32, i32, vp, vp, vp, vp, sz]),
 }
 
 _lib = None

@@ -112,10 +112,11 @@ class FoldedBEVBackbone:
         self.up_channels = [s[1][2].numel() for s in self.stages]
         for h in heads:
             assert tuple(h.kernel_size) == (1, 1) and tuple(h.stride) == (1, 1)
-        self.head_wt = torch.cat([h.weight.detach().flatten(1) for h in heads], 0).t().contiguous()   # (C_in, sum C_head)
-        self.head_b = torch.cat([h.bias.detach() if h.bias is not None else h.weight.new_zeros(h.weight.shape[0]) for h in heads],
-                                0).contiguous()
         self.head_split = [h.weight.shape[0] for h in heads]
+        if heads:   # (a backbone used without merged 1x1 heads — e.g. AnchorHeadMulti's 3x3 branches — calls features() only)
+            self.head_wt = torch.cat([h.weight.detach().flatten(1) for h in heads], 0).t().contiguous()   # (C_in, sum C_head)
+            self.head_b = torch.cat([h.bias.detach() if h.bias is not None else h.weight.new_zeros(h.weight.shape[0])
+                                     for h in heads], 0).contiguous()
         self._cat = None
 
     def features(self, canvas):

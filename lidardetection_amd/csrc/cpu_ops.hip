@@ -124,3 +124,71 @@ LIDAR_EXPORT int lidar_points_in_boxes_cpu(const float *boxes, int n_boxes, cons
     }
     return LIDAR_OK;
 }
+
+// ------------------------------------------------------------------ host voxel generator
+// spconv's VoxelGeneratorV2.generate as the reference calls it from DataLoader WORKER processes
+// (pcdet/datasets/processor/data_processor.py:48-80; workers are forked, pcdet/datasets/__init__.py:73, and must not touch
+// the GPU).  Same result as lidar_voxelize / the sequential scan (SURVEY.md Appendix A.1, v1.2 `continue` semantics), but
+// written for a host core: an open-addressing hash map over the occupied cells (a few hundred KB in L2) instead of spconv's
+// dense coor_to_voxelidx grid (360 MB for the SECOND grid, touched at random), and only the rows that are produced get
+// their zero padding written (the reference zero-fills max_voxels x P x C up front).
+LIDAR_EXPORT size_t lidar_voxelize_cpu_scratch_bytes(int n) {
+    size_t cap = 1024;
+    while (cap < 2 * (size_t)(n > 0 ? n : 1)) cap <<= 1;
+    return cap * 8;
+}
+
+LIDAR_EXPORT int lidar_voxelize_cpu(const float *points, int n, int num_features, const float *range6, const float *voxel_size3,
+                                    const int *grid3, int max_points, int max_voxels, float *voxels, int *coords_zyx,
+                                    int *num_points, void *scratch, size_t scratch_bytes) {
+    if (!points || !range6 || !voxel_size3 || !grid3 || !voxels || !coords_zyx || !num_points || !scratch) return LIDAR_ERR_ARG;
+    if (n < 0 || num_features < 3 || max_points <= 0 || max_voxels <= 0) return LIDAR_ERR_ARG;
+    if ((double)grid3[0] * grid3[1] * grid3[2] >= 4294967295.0) return LIDAR_ERR_ARG;
+    size_t cap = 1024;
+    while (cap < 2 * (size_t)(n > 0 ? n : 1)) cap <<= 1;
+    if (scratch_bytes < cap * 8) return LIDAR_ERR_WORKSPACE;
+    uint32_t *keys = static_cast<uint32_t *>(scratch);
+    int *vals = reinterpret_cast<int *>(keys + cap);
+    for (size_t k = 0; k < cap; ++k) keys[k] = 0xFFFFFFFFu;
+    const uint32_t mask = (uint32_t)cap - 1u;
+    const int C = num_features, P = max_points;
+    const uint32_t nx = (uint32_t)grid3[0], ny = (uint32_t)grid3[1];
+    const size_t row = (size_t)P * C;
+    int nvox = 0;
+    for (int i = 0; i < n; ++i) {
+        const float *p = points + (size_t)i * C;
+        const float fx = std::floor((p[0] - range6[0]) / voxel_size3[0]);
+        const float fy = std::floor((p[1] - range6[1]) / voxel_size3[1]);
+        const float fz = std::floor((p[2] - range6[2]) / voxel_size3[2]);
+        if (!(fx >= 0.f && fx < (float)grid3[0] && fy >= 0.f && fy < (float)grid3[1] && fz >= 0.f && fz < (float)grid3[2])) continue;
+        const uint32_t cx = (uint32_t)fx, cy = (uint32_t)fy, cz = (uint32_t)fz;
+        const uint32_t key = (cz * ny + cy) * nx + cx;
+        uint32_t h = (key * 2654435761u) & mask;
+        int vid = -1;
+        for (;;) {
+            const uint32_t k = keys[h];
+            if (k == key) { vid = vals[h]; break; }
+            if (k == 0xFFFFFFFFu) break;
+            h = (h + 1u) & mask;
+        }
+        if (vid < 0) {
+            if (nvox >= max_voxels) continue;          // v1.2: skip the point, keep scanning
+            vid = nvox++;
+            keys[h] = key;
+            vals[h] = vid;
+            coords_zyx[3 * vid + 0] = (int)cz;
+            coords_zyx[3 * vid + 1] = (int)cy;
+            coords_zyx[3 * vid + 2] = (int)cx;
+            num_points[vid] = 0;
+            float *r = voxels + (size_t)vid * row;
+            for (size_t e = 0; e < row; ++e) r[e] = 0.f;
+        }
+        const int slot = num_points[vid];
+        if (slot < P) {
+            float *dst = voxels + (size_t)vid * row + (size_t)slot * C;
+            for (int c = 0; c < C; ++c) dst[c] = p[c];
+            num_points[vid] = slot + 1;
+        }
+    }
+    return nvox;
+}

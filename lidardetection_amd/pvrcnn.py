@@ -1,0 +1,256 @@
+"""PV-RCNN-KITTI forward on one MI355X (BASELINE.json configs[3], bs 8): the SECOND trunk plus the point branch and the RoI head.
+
+Topology from tools/cfgs/kitti_models/pv_rcnn.yaml (test mode), written from its shapes:
+  voxelise -> MeanVFE -> VoxelBackBone8x (keeps x_conv1..4) -> HeightCompression -> BaseBEVBackbone [5, 5] -> AnchorHeadSingle
+  -> proposals: class-agnostic rotated NMS on the raw class logits, pre 1024 / thr 0.7 / post 100 (roi_head_template.py:45-99)
+  -> VoxelSetAbstraction (pcdet/models/backbones_3d/pfe/voxel_set_abstraction.py:119-240): 2048 keypoints per frame by
+     furthest-point sampling of the raw points; per keypoint: bilinear BEV features (256) + StackSAModuleMSG over the raw points
+     (radii 0.4/0.8, 16/16 samples, 4 -> 16 -> 16 twice) and over the voxel centres of x_conv1..4 (:120-144 of the yaml);
+     640 -> 128 fusion (Linear + BN + ReLU)
+  -> PointHeadSimple (dense_heads/point_head_simple.py:60-90): 640 -> 256 -> 256 -> 1, sigmoid = keypoint weight
+  -> PVRCNNHead (roi_heads/pvrcnn_head.py:73-177): 6^3 grid points per RoI, StackSAModuleMSG over the weighted keypoints
+     (radii 0.8/1.6, 16/16 samples, 131 -> 64 -> 64 twice), shared FC 27648 -> 256 -> 256, class and box branches, box decode
+     relative to the RoI (roi_head_template.py:235-263)
+  -> final class-agnostic NMS: sigmoid(score) >= 0.1, thr 0.1, post 500 (detector3d_template.py:236-262).
+Hot-path ops are this repo's HIP kernels (voxelise, sparse conv, FPS, ball query, grouping, batched NMS, anchor decode); MLPs are
+stock torch.  Batched where the reference loops over samples in Python: one FPS launch for all frames of equal size, per-level
+point counts by bincount, ONE batched NMS for the proposals of all frames and one for the final boxes.  Random-init weights.
+"""
+import numpy as np
+import torch
+import torch.nn as nn
+
+from . import anchor_post
+from .ext import iou3d_nms_cuda
+from .pcdet.ops.pointnet2.pointnet2_batch import pointnet2_utils as pn_batch
+from .pcdet.ops.pointnet2.pointnet2_stack import pointnet2_modules as pn_stack_modules
+from .pcdet.ops.pointnet2.pointnet2_stack import pointnet2_utils as pn_stack
+from .pcdet.utils import common_utils
+from .second import SECONDKitti
+
+# pv_rcnn.yaml:119-144: source -> (downsample factor, radii, nsamples, MLP widths behind the input width)
+VSA_SOURCES = {
+    "x_conv1": (1, [0.4, 0.8], [16, 16], [[16, 16], [16, 16]], 16),
+    "x_conv2": (2, [0.8, 1.2], [16, 32], [[32, 32], [32, 32]], 32),
+    "x_conv3": (4, [1.2, 2.4], [16, 32], [[64, 64], [64, 64]], 64),
+    "x_conv4": (8, [2.4, 4.8], [16, 32], [[64, 64], [64, 64]], 64),
+}
+
+
+def bilinear_bev(bev_nhwc, x, y):
+    """bev_nhwc (B, H, W, C), x / y (B, M) in feature-map cells -> (B, M, C); the reference's bilinear_interpolate_torch
+    (voxel_set_abstraction.py:9-39) for all frames at once: clamped corner indices, UNclamped weights."""
+    B, H, W, C = bev_nhwc.shape
+    x0f, y0f = torch.floor(x), torch.floor(y)
+    x0, y0 = x0f.long(), y0f.long()
+    x1, y1 = x0 + 1, y0 + 1
+    x0, x1 = x0.clamp(0, W - 1), x1.clamp(0, W - 1)
+    y0, y1 = y0.clamp(0, H - 1), y1.clamp(0, H - 1)
+    flat = bev_nhwc.reshape(B, H * W, C)
+
+    def at(yy, xx):
+        return torch.gather(flat, 1, (yy * W + xx).unsqueeze(-1).expand(-1, -1, C))
+    wa = (x1.type_as(x) - x) * (y1.type_as(y) - y)
+    wb = (x1.type_as(x) - x) * (y - y0.type_as(y))
+    wc = (x - x0.type_as(x)) * (y1.type_as(y) - y)
+    wd = (x - x0.type_as(x)) * (y - y0.type_as(y))
+    return at(y0, x0) * wa.unsqueeze(-1) + at(y1, x0) * wb.unsqueeze(-1) + at(y0, x1) * wc.unsqueeze(-1) + at(y1, x1) * wd.unsqueeze(-1)
+
+
+def roi_grid_points(rois, grid_size):
+    """rois (R, 7) -> global grid points (R, grid^3, 3) (pvrcnn_head.py:120-143)."""
+    R = rois.shape[0]
+    idx = torch.ones((grid_size,) * 3, device=rois.device).nonzero().float()                  # (g^3, 3) [x, y, z] index
+    size = rois[:, 3:6].unsqueeze(1)
+    local = (idx.unsqueeze(0) + 0.5) / grid_size * size - size / 2
+    glob = common_utils.rotate_points_along_z(local.clone(), rois[:, 6]) + rois[:, 0:3].unsqueeze(1)
+    return glob.view(R, -1, 3)
+
+
+def fc_stack(cin, widths, cout, dropout=0.0):
+    """RoIHeadTemplate.make_fc_layers (roi_head_template.py:30-43): Conv1d(k=1)/BN/ReLU blocks (+ dropout after the first),
+    then a biased Conv1d to `cout`"""
+    layers, c = [], cin
+    for k, w in enumerate(widths):
+        layers += [nn.Conv1d(c, w, kernel_size=1, bias=False), nn.BatchNorm1d(w), nn.ReLU()]
+        c = w
+        if dropout >= 0 and k == 0:
+            layers.append(nn.Dropout(dropout))
+    layers.append(nn.Conv1d(c, cout, kernel_size=1, bias=True))
+    return nn.Sequential(*layers)
+
+
+class PVRCNNKitti(SECONDKitti):
+    def __init__(self, batch_size=8, max_voxels=16000, n_max=20000, device="cuda", num_keypoints=2048, grid_size=6):
+        super().__init__(batch_size=batch_size, max_voxels=max_voxels, n_max=n_max, device=device)
+        self.num_keypoints, self.grid_size = num_keypoints, grid_size
+        self.roi_pre, self.roi_thresh, self.roi_post = 1024, 0.7, 100            # ROI_HEAD.NMS_CONFIG.TEST
+        self.score_thresh, self.nms_thresh, self.nms_pre, self.nms_post = 0.1, 0.1, 4096, 500   # POST_PROCESSING
+        # ---- VoxelSetAbstraction
+        self.SA_rawpoints = pn_stack_modules.StackSAModuleMSG(radii=[0.4, 0.8], nsamples=[16, 16], mlps=[[1, 16, 16], [1, 16, 16]],
+                                                              use_xyz=True, pool_method='max_pool')
+        self.SA_layers, self.SA_layer_names, self.downsample = nn.ModuleList(), [], {}
+        c_in = 256 + 32                                                          # bev + raw points
+        for name, (ds, radii, ns, mlps, cin) in VSA_SOURCES.items():
+            self.SA_layers.append(pn_stack_modules.StackSAModuleMSG(radii=list(radii), nsamples=list(ns),
+                                                                    mlps=[[cin] + list(m) for m in mlps], use_xyz=True,
+                                                                    pool_method='max_pool'))
+            self.SA_layer_names.append(name)
+            self.downsample[name] = ds
+            c_in += sum(m[-1] for m in mlps)
+        assert c_in == 640
+        self.vsa_point_feature_fusion = nn.Sequential(nn.Linear(c_in, 128, bias=False), nn.BatchNorm1d(128), nn.ReLU())
+        # ---- PointHeadSimple (class-agnostic, on the features before fusion)
+        self.point_cls_layers = nn.Sequential(nn.Linear(c_in, 256, bias=False), nn.BatchNorm1d(256), nn.ReLU(),
+                                              nn.Linear(256, 256, bias=False), nn.BatchNorm1d(256), nn.ReLU(), nn.Linear(256, 1))
+        # ---- PVRCNNHead
+        self.roi_grid_pool_layer = pn_stack_modules.StackSAModuleMSG(radii=[0.8, 1.6], nsamples=[16, 16],
+                                                                     mlps=[[128, 64, 64], [128, 64, 64]], use_xyz=True,
+                                                                     pool_method='max_pool')
+        pre = grid_size ** 3 * 128
+        self.shared_fc_layer = nn.Sequential(nn.Conv1d(pre, 256, 1, bias=False), nn.BatchNorm1d(256), nn.ReLU(), nn.Dropout(0.3),
+                                             nn.Conv1d(256, 256, 1, bias=False), nn.BatchNorm1d(256), nn.ReLU())
+        self.cls_layers = fc_stack(256, [256, 256], 1, dropout=0.3)
+        self.reg_layers = fc_stack(256, [256, 256], 7, dropout=0.3)
+        for m in (self.shared_fc_layer, self.cls_layers, self.reg_layers):          # init_weights('xavier'), :52-70
+            for l in m.modules():
+                if isinstance(l, nn.Conv1d):
+                    nn.init.xavier_normal_(l.weight)
+                    if l.bias is not None:
+                        nn.init.constant_(l.bias, 0)
+        nn.init.normal_(self.reg_layers[-1].weight, mean=0, std=0.001)
+        self.to(device).eval()
+
+    # ---- stages --------------------------------------------------------------------------------
+    def trunk(self, points, point_offsets):
+        """SECOND trunk -> (multi-scale sparse tensors, BEV map (B, 256, 200, 176) channels-last, merged dense-head output)"""
+        feats, coords = self.voxelize_vfe(points, point_offsets)
+        bd = self.backbone3d({"voxel_features": feats, "voxel_coords": coords, "batch_size": self.B})
+        bev = bd["encoded_spconv_tensor"].dense_bev()
+        (head,) = self.backbone_head(bev)
+        return bd["multi_scale_3d_features"], bev, head
+
+    def proposals(self, head):
+        """proposal_layer (roi_head_template.py:45-99), all frames at once -> rois (B, post, 7) zero padded, roi_scores (raw
+        logits), roi_labels (1-based), num (B,)"""
+        a, nc = self.num_anchor_per_loc, self.num_class
+        cls = head[..., :a * nc].reshape(self.B, -1, nc)
+        scores_all, labels_all = cls.max(dim=-1)                                   # raw logits: cls_preds_normalized is False
+        k = min(self.roi_pre, scores_all.shape[1])
+        top_scores, top_idx = torch.topk(scores_all, k, dim=1)
+        boxes = anchor_post.decode_topk(head, top_idx, self.anchors, a, box_off=a * nc, dir_off=a * (nc + 7),
+                                        num_dir_bins=self.num_dir_bins, dir_offset=self.dir_offset,
+                                        dir_limit_offset=self.dir_limit_offset)
+        post = min(self.roi_post, k)
+        keep, num = iou3d_nms_cuda.nms_batch(boxes, None, self.roi_thresh, max_keep=post)
+        num = torch.clamp(num, max=post)
+        valid = torch.arange(post, device=keep.device).unsqueeze(0) < num.unsqueeze(1)
+        sel = torch.where(valid, keep[:, :post], torch.zeros_like(keep[:, :post])).clamp_(0, k - 1)
+        rois = torch.gather(boxes, 1, sel.unsqueeze(-1).expand(-1, -1, 7)) * valid.unsqueeze(-1)
+        roi_scores = torch.gather(top_scores, 1, sel) * valid
+        roi_labels = (torch.gather(labels_all, 1, torch.gather(top_idx, 1, sel)) + 1) * valid
+        return rois, roi_scores, roi_labels, num, (boxes, top_scores)
+
+    def keypoints(self, points, point_offsets, sizes):
+        """get_sampled_points (voxel_set_abstraction.py:119-157) -> (B, num_keypoints, 3): FPS per frame, starting at point 0"""
+        xyz = points[:, :3]
+        if len(set(sizes)) == 1 and sizes[0] >= self.num_keypoints:                # equal-size frames: one launch for all of them
+            xyz_b = xyz.reshape(self.B, sizes[0], 3).contiguous()
+            idx = pn_batch.furthest_point_sample(xyz_b, self.num_keypoints).long()
+            return torch.gather(xyz_b, 1, idx.unsqueeze(-1).expand(-1, -1, 3))
+        out, start = [], 0
+        for n in sizes:
+            cur = xyz[start:start + n].unsqueeze(0).contiguous()
+            idx = pn_stack.furthest_point_sample(cur, self.num_keypoints).long()
+            if n < self.num_keypoints:                                             # :142-144: wrap around
+                empty = self.num_keypoints - n
+                idx[0, -empty:] = idx[0, :empty]
+            out.append(cur[0][idx[0]].unsqueeze(0))
+            start += n
+        return torch.cat(out, 0)
+
+    def set_abstraction(self, points, sizes, kp, multi_scale, bev):
+        """VoxelSetAbstraction.forward (:159-240) -> (point_features_before_fusion (B*K, 640), point_features (B*K, 128))"""
+        B, K = kp.shape[0], kp.shape[1]
+        dev = kp.device
+        feats = []
+        stride = 8
+        x_idx = (kp[:, :, 0] - self.pc_range[0]) / self.voxel_size[0] / stride
+        y_idx = (kp[:, :, 1] - self.pc_range[1]) / self.voxel_size[1] / stride
+        feats.append(bilinear_bev(bev.permute(0, 2, 3, 1), x_idx, y_idx))          # channels-last storage: (B, H, W, C) is a view
+        new_xyz = kp.reshape(-1, 3).contiguous()
+        new_cnt = torch.full((B,), K, dtype=torch.int32, device=dev)
+        xyz_cnt = torch.tensor(sizes, dtype=torch.int32, device=dev)
+        _, f = self.SA_rawpoints(xyz=points[:, :3].contiguous(), xyz_batch_cnt=xyz_cnt, new_xyz=new_xyz, new_xyz_batch_cnt=new_cnt,
+                                 features=points[:, 3:].contiguous())
+        feats.append(f.view(B, K, -1))
+        for layer, name in zip(self.SA_layers, self.SA_layer_names):
+            t = multi_scale[name]
+            xyz = common_utils.get_voxel_centers(t.indices[:, 1:4], self.downsample[name], self.voxel_size, self.pc_range)
+            cnt = torch.bincount(t.indices[:, 0].long(), minlength=B).int()         # rows are grouped by frame, frames ascending
+            _, f = layer(xyz=xyz.contiguous(), xyz_batch_cnt=cnt, new_xyz=new_xyz, new_xyz_batch_cnt=new_cnt,
+                         features=t.features.contiguous())
+            feats.append(f.view(B, K, -1))
+        before = torch.cat(feats, dim=2).view(B * K, -1)
+        return before, self.vsa_point_feature_fusion(before)
+
+    def roi_head(self, rois, kp, point_features, point_scores):
+        """PVRCNNHead.forward, test mode (:145-177) -> rcnn_cls (B*R, 1), decoded boxes (B, R, 7)"""
+        B, R = rois.shape[0], rois.shape[1]
+        dev = rois.device
+        weighted = point_features * point_scores.view(-1, 1)                        # :88
+        grid = roi_grid_points(rois.reshape(-1, 7), self.grid_size).view(B, -1, 3)  # (B, R * 216, 3)
+        new_xyz = grid.reshape(-1, 3).contiguous()
+        new_cnt = torch.full((B,), grid.shape[1], dtype=torch.int32, device=dev)
+        xyz_cnt = torch.full((B,), kp.shape[1], dtype=torch.int32, device=dev)
+        _, pooled = self.roi_grid_pool_layer(xyz=kp.reshape(-1, 3).contiguous(), xyz_batch_cnt=xyz_cnt, new_xyz=new_xyz,
+                                             new_xyz_batch_cnt=new_cnt, features=weighted.contiguous())
+        g3 = self.grid_size ** 3
+        pooled = pooled.view(B * R, g3, -1).permute(0, 2, 1).contiguous().view(B * R, -1, 1)     # (B*R, C * 216, 1)
+        shared = self.shared_fc_layer(pooled)
+        rcnn_cls = self.cls_layers(shared).transpose(1, 2).contiguous().squeeze(dim=1)
+        rcnn_reg = self.reg_layers(shared).transpose(1, 2).contiguous().squeeze(dim=1)
+        # generate_predicted_boxes (roi_head_template.py:235-263): ResidualCoder against the RoI moved to the origin
+        local = rois.clone()
+        local[:, :, 0:3] = 0
+        dec = self.decode_residual(rcnn_reg.view(B, R, 7), local).view(-1, 7)
+        dec = common_utils.rotate_points_along_z(dec.unsqueeze(1), rois[:, :, 6].reshape(-1)).squeeze(1)
+        dec[:, 0:3] += rois[:, :, 0:3].reshape(-1, 3)
+        return rcnn_cls, dec.view(B, R, 7)
+
+    @staticmethod
+    def decode_residual(enc, anchors):
+        """ResidualCoder.decode_torch (box_coder_utils.py:45-77), 7 values"""
+        xa, ya, za, dxa, dya, dza, ra = torch.split(anchors, 1, dim=-1)
+        xt, yt, zt, dxt, dyt, dzt, rt = torch.split(enc, 1, dim=-1)
+        diagonal = torch.sqrt(dxa ** 2 + dya ** 2)
+        return torch.cat([xt * diagonal + xa, yt * diagonal + ya, zt * dza + za, torch.exp(dxt) * dxa, torch.exp(dyt) * dya,
+                          torch.exp(dzt) * dza, rt + ra], dim=-1)
+
+    def final_nms(self, rcnn_cls, boxes, roi_labels):
+        """post_processing, class-agnostic branch with roi_labels (detector3d_template.py:236-262), all frames at once"""
+        B, R = boxes.shape[0], boxes.shape[1]
+        scores = torch.sigmoid(rcnn_cls.view(B, R))
+        masked = torch.where(scores >= self.score_thresh, scores, scores.new_full((), -1.0))
+        k = min(self.nms_pre, R)
+        top, idx = torch.topk(masked, k, dim=1)
+        counts = (top >= self.score_thresh).sum(1).to(torch.int32)
+        cand = torch.gather(boxes, 1, idx.unsqueeze(-1).expand(-1, -1, 7)).contiguous()
+        post = min(self.nms_post, k)
+        keep, num = iou3d_nms_cuda.nms_batch(cand, counts, self.nms_thresh, max_keep=post)
+        num = torch.clamp(num, max=post)
+        valid = torch.arange(post, device=keep.device).unsqueeze(0) < num.unsqueeze(1)
+        sel = torch.where(valid, keep[:, :post], torch.zeros_like(keep[:, :post])).clamp_(0, k - 1)
+        return (torch.gather(cand, 1, sel.unsqueeze(-1).expand(-1, -1, 7)), torch.gather(top, 1, sel),
+                torch.gather(roi_labels, 1, torch.gather(idx, 1, sel)), num)
+
+    @torch.no_grad()
+    def forward(self, points, point_offsets, sizes):
+        """points (sum N, 4), point_offsets (B+1) i32 device, sizes = the same frame sizes as a host list"""
+        multi_scale, bev, head = self.trunk(points, point_offsets)
+        rois, roi_scores, roi_labels, _, _ = self.proposals(head)
+        kp = self.keypoints(points, point_offsets, sizes)
+        before, fused = self.set_abstraction(points, sizes, kp, multi_scale, bev)
+        point_scores = torch.sigmoid(self.point_cls_layers(before)).max(dim=-1)[0]
+        rcnn_cls, boxes = self.roi_head(rois, kp, fused, point_scores)
+        return self.final_nms(rcnn_cls, boxes, roi_labels)

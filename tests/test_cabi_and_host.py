@@ -146,3 +146,69 @@ def test_every_native_symbol_the_reference_wrappers_call_is_exported():
         assert not missing, (rel, missing)
         total += len(names)
     assert total >= 20
+
+
+def _cases_for_host_voxel_generator():
+    r = np.random.default_rng(21)
+    dense = synth.cloud_uniform(1002, n=5000)
+    dense[:, :2] = dense[:, :2] * 0.02 + np.array([10.0, 0.0], np.float32)           # ~100 points per pillar: the P cap
+    lo, hi = np.array(synth.PP_RANGE[:3], np.float32), np.array(synth.PP_RANGE[3:], np.float32)
+    edges = np.array([[lo[0], lo[1], lo[2], 0.1], [hi[0], 0, 0, 0.2], [np.nextafter(hi[0], -np.inf, dtype=np.float32), 0, 0, 0.3],
+                      [-0.001, 0, 0, 0.4], [5, 5, 1.0, 0.5], [5, 5, 0.999, 0.6], [0.16, 0.16, 0, 0.8], [0.15999, 0.16, 0, 0.9],
+                      [np.nan, 0, 0, 1.0], [1e9, 0, 0, 1.0]], np.float32)
+    ring = synth.cloud_ring(2002)
+    return [
+        ("pp ring shuffled", ring[r.permutation(len(ring))], synth.PP_VOXEL, synth.PP_RANGE, 32, 16000),
+        ("pp uniform, voxel cap", synth.cloud_uniform(1000), synth.PP_VOXEL, synth.PP_RANGE, 32, 16000),
+        ("pp dense pillars, P cap", dense, synth.PP_VOXEL, synth.PP_RANGE, 32, 16000),
+        ("P = 1, tiny cap", dense, synth.PP_VOXEL, synth.PP_RANGE, 1, 50),
+        ("second", synth.cloud_ring(2000), synth.SEC_VOXEL, synth.SEC_RANGE, 5, 16000),
+        ("nuscenes, 5 features", synth.cloud_nus(4000), synth.NUS_VOXEL, synth.NUS_RANGE, 10, 60000),
+        ("edges / NaN / far", edges, synth.PP_VOXEL, synth.PP_RANGE, 32, 16000),
+        ("empty", np.zeros((0, 4), np.float32), synth.PP_VOXEL, synth.PP_RANGE, 32, 16000),
+    ]
+
+
+def test_host_voxel_generator_bit_exact_vs_oracle_and_reference_call_pattern():
+    """spconv.utils.VoxelGeneratorV2 / VoxelGenerator .generate(numpy) — the reference's DataLoader-worker call
+    (pcdet/datasets/processor/data_processor.py:48-80) — runs lidar_voxelize_cpu (csrc/cpu_ops.hip: own hash-map scan, no GPU,
+    no oracle): dict / tuple outputs bit-exact vs the sequential oracle on PointPillar / SECOND / NuScenes shapes, caps, edge
+    points and an empty frame."""
+    from lidardetection_amd.spconv.utils import VoxelGenerator, VoxelGeneratorV2
+    from oracle import c_oracle
+    for name, pts, vs, rng, P, mv in _cases_for_host_voxel_generator():
+        ev, ec, en = c_oracle.voxelize(pts, vs, rng, P, mv)
+        g2 = VoxelGeneratorV2(voxel_size=vs, point_cloud_range=rng, max_num_points=P, max_voxels=mv)
+        out = g2.generate(pts)
+        assert isinstance(out, dict) and out["voxel_num"] == len(ev), name
+        assert out["voxels"].dtype == np.float32 and out["coordinates"].dtype == np.int32
+        assert np.array_equal(out["voxels"].view(np.uint32), ev.view(np.uint32)), name
+        assert np.array_equal(out["coordinates"], ec) and np.array_equal(out["num_points_per_voxel"], en), name
+        assert np.array_equal(out["voxel_point_mask"][:, :, 0] > 0, np.arange(P)[None, :] < en[:, None]), name
+        v, c, n = VoxelGenerator(voxel_size=vs, point_cloud_range=rng, max_num_points=P, max_voxels=mv).generate(pts)
+        assert np.array_equal(v, ev) and np.array_equal(c, ec) and np.array_equal(n, en), name
+        assert g2.grid_size.tolist() == np.round((np.array(rng[3:]) - np.array(rng[:3])) / np.array(vs)).astype(np.int64).tolist()
+
+
+def _generate_in_child(q, pts):
+    from lidardetection_amd.spconv.utils import VoxelGeneratorV2
+    out = VoxelGeneratorV2(synth.PP_VOXEL, synth.PP_RANGE, 32, 16000).generate(pts)
+    q.put((out["voxels"], out["coordinates"], out["num_points_per_voxel"]))
+
+
+def test_host_voxel_generator_runs_in_a_forked_worker():
+    """the reference's DataLoader workers are forked children: generate() must work there (it touches no GPU state)"""
+    import multiprocessing as mp
+    from oracle import c_oracle
+    from lidardetection_amd import _lib
+    _lib.lib()                                             # parent has the library loaded, like a training process
+    pts = synth.cloud_ring(2004)
+    ctx = mp.get_context("fork")
+    q = ctx.Queue()
+    p = ctx.Process(target=_generate_in_child, args=(q, pts))
+    p.start()
+    v, c, n = q.get(timeout=120)
+    p.join(timeout=60)
+    assert p.exitcode == 0
+    ev, ec, en = c_oracle.voxelize(pts, synth.PP_VOXEL, synth.PP_RANGE, 32, 16000)
+    assert np.array_equal(v, ev) and np.array_equal(c, ec) and np.array_equal(n, en)

@@ -126,3 +126,36 @@ def test_eval_iou_oracle_known_answers():
     np.testing.assert_allclose(c_oracle.rotate_iou_eval(sq, dia, 2)[0, 0], inter, atol=1e-4)
     np.testing.assert_allclose(c_oracle.rotate_iou_eval(sq, dia, -1)[0, 0], inter / (8 - inter), atol=1e-5)
     assert c_oracle.rotate_iou_eval(a[:0], b).shape == (0, 2)
+
+
+@pytest.mark.parametrize("ksize,stride,padding,subm", [((3, 3, 3), (1, 1, 1), (1, 1, 1), True), ((3, 3, 3), (2, 2, 2), (1, 1, 1), False),
+                                                       ((3, 3, 3), (2, 2, 2), (0, 1, 1), False), ((3, 1, 1), (2, 1, 1), (0, 0, 0), False)])
+def test_sparse_oracle_equals_dense_conv_oracle(ksize, stride, padding, subm):
+    """The full-grid oracle (oracle/spconv_sparse_oracle.py: binary search over the active sites + one fp64 matmul per kernel
+    offset) against the dense conv3d oracle and the brute-force rulebook (oracle/spconv_oracle.py) on a grid small enough to
+    densify: same output sites, same features, same number of pairs per offset."""
+    from oracle import spconv_oracle as so, spconv_sparse_oracle as sp
+    r = np.random.default_rng(11)
+    shape, B, cin, cout = [9, 12, 10], 2, 5, 7
+    cells = shape[0] * shape[1] * shape[2]
+    pick = np.concatenate([np.sort(r.choice(cells, 160, replace=False)) + b * cells for b in range(B)])
+    b_, rem = np.divmod(pick, cells)
+    z, rem = np.divmod(rem, shape[1] * shape[2])
+    y, x = np.divmod(rem, shape[2])
+    idx = np.stack([b_, z, y, x], 1).astype(np.int64)
+    idx = idx[r.permutation(len(idx))]                    # row order must not matter
+    feats = r.standard_normal((len(idx), cin))
+    w = r.standard_normal((*ksize, cin, cout))
+    bias = r.standard_normal(cout)
+    triples, outs = so.rulebook(idx, shape, list(ksize), list(stride), list(padding), subm)
+    counts = np.bincount([t[0] for t in triples], minlength=int(np.prod(ksize)))
+    if subm:
+        got, n_k = sp.subm_conv(feats, idx, shape, w, bias, list(ksize))
+        want = so.conv_features(feats, idx, B, shape, w, bias, list(ksize), [1, 1, 1], [0, 0, 0], True, idx).numpy()
+    else:
+        got, oidx, oshape, n_k = sp.sparse_conv(feats, idx, shape, w, bias, list(ksize), list(stride), list(padding))
+        assert [tuple(int(v) for v in c) for c in oidx] == outs               # same active outputs, ascending (b, z, y, x)
+        assert oshape == so.out_shape(shape, ksize, stride, padding)
+        want = so.conv_features(feats, idx, B, shape, w, bias, list(ksize), list(stride), list(padding), False, np.array(outs)).numpy()
+    assert n_k == counts.tolist()
+    np.testing.assert_allclose(got, want, rtol=0, atol=1e-12)
