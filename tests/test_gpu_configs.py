@@ -253,5 +253,9 @@ def test_pvrcnn_kitti_bs8(dev):
                 assert np.array_equal(fl[f, :len(e)].cpu().numpy(), roi_labels[f].cpu().numpy()[e])
         # ---- and the assembled forward gives the same thing
         out = m(pts, offs, sizes)
-    for a, b in zip(out, (fb, fs, fl, fn)):
-        assert torch.equal(a, b)
+    # same functions, same inputs — but the dense layers (MIOpen / hipBLASLt) may pick another kernel when the free workspace
+    # differs between the two passes, so fp32 sums can differ in their last bits: counts and labels exact, values to 1e-4
+    assert torch.equal(out[3], fn) and torch.equal(out[2], fl)
+    dmax = float((out[0] - fb).abs().max())
+    print(f"assembled vs staged forward: max |box diff| {dmax:.2e}, max |score diff| {float((out[1] - fs).abs().max()):.2e}")
+    assert dmax <= 1e-4 * max(1.0, float(fb.abs().max())) and float((out[1] - fs).abs().max()) <= 1e-4
