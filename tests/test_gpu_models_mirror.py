@@ -132,6 +132,33 @@ def test_second_front_end_on_kitti_shapes(dev):
     assert bd["spatial_features"].shape == (2, 256, 200, 176)
     assert bd["encoded_spconv_tensor"].spatial_shape == [2, 200, 176]
     assert torch.isfinite(bd["spatial_features"]).all()
+    # the dense map is exactly the sparse rows scattered (height_compression.py:21-24): rebuild it from the rows
+    t = bd["encoded_spconv_tensor"]
+    dense = torch.zeros((2, 128, 2, 200, 176), device=dev)
+    i = t.indices.long()
+    dense[i[:, 0], :, i[:, 1], i[:, 2], i[:, 3]] = t.features
+    assert torch.equal(bd["spatial_features"], dense.view(2, 256, 200, 176))
+
+
+def test_second_backbone_full_grid_frame_vs_sparse_oracle(dev):
+    """ONE full-size SECOND-KITTI frame (41 x 1600 x 1408 grid, ~16 k voxels) through VoxelBackBone8x, BatchNorm statistics
+    perturbed: every tap (x_conv1..4, encoded tensor) against the sparse fp64 oracle (oracle/spconv_sparse_oracle.py: binary search
+    over the active sites + one float64 matmul per kernel offset) — the dense conv3d oracle cannot hold this grid.  Active sites
+    bit-exact as sets, features within 1e-4 of the feature scale (reference: spconv_backbone.py:76-163)."""
+    from test_gpu_configs import _check_backbone_full_grid
+    o = BatchVoxelizer(synth.SEC_VOXEL, synth.SEC_RANGE, 5, 16000).voxelize_frames([synth.cloud_ring(2007)], device=dev)
+    feats = pillar_ops.mean_vfe(o["voxels"], o["voxel_num_points"])
+    torch.manual_seed(5)
+    for cls in (spconv_backbone.VoxelBackBone8x, spconv_backbone.VoxelResBackBone8x):
+        m = cls(AttrDict(), 4, [1408, 1600, 40]).to(dev).eval()
+        with torch.no_grad():
+            for mod in m.modules():
+                if isinstance(mod, torch.nn.BatchNorm1d):
+                    mod.running_mean.uniform_(-0.2, 0.2); mod.running_var.uniform_(0.5, 1.5)
+                    mod.weight.uniform_(0.8, 1.2); mod.bias.uniform_(-0.1, 0.1)
+        errs = _check_backbone_full_grid(m, feats, o["voxel_coords"], dev)
+        assert set(errs) == {"conv1", "conv2", "conv3", "conv4", "conv_out"}
+        print(cls.__name__, "full grid, max err / scale:", {k: f"{v:.1e}" for k, v in errs.items()})
 
 
 def test_model_nms_utils(dev):
@@ -146,9 +173,22 @@ def test_model_nms_utils(dev):
     keep = c_oracle.nms(bs[top], ss[top], 0.1)[:100]
     exp = np.nonzero(mask)[0][top[keep]]
     assert sel.cpu().tolist() == exp.tolist() and np.allclose(sc.cpu().numpy(), scores[exp])
-    cls_scores = torch.stack([ts, ts.flip(0) * 0.9], 1)
-    ps, pl, pb = model_nms_utils.multi_classes_nms(cls_scores, tb, cfg, score_thresh=0.2)
-    assert ps.shape[0] == pl.shape[0] == pb.shape[0] and set(pl.cpu().tolist()) <= {0, 1} and ps.shape[0] <= 200
+    # multi_classes_nms (model_nms_utils.py:28-65) replayed class by class against the oracle: per class the score mask, the
+    # top NMS_PRE_MAXSIZE by score, the rotated NMS keep list, its first NMS_POST_MAXSIZE entries — concatenated in class order
+    s3 = np.stack([scores, scores[::-1] * np.float32(0.9), np.roll(scores, 777) * np.float32(0.05)], 1).astype(np.float32)
+    ps, pl, pb = model_nms_utils.multi_classes_nms(torch.from_numpy(s3).to(dev), tb, cfg, score_thresh=0.2)
+    es, el, eb = [], [], []
+    for k in range(s3.shape[1]):
+        col = s3[:, k]
+        msk = col >= np.float32(0.2)
+        ids = np.nonzero(msk)[0]
+        top = np.argsort(-col[msk], kind="stable")[:1024]
+        kept = c_oracle.nms(boxes[ids][top], col[ids][top], 0.1)[:100] if len(top) else np.zeros(0, np.int64)
+        chosen = ids[top[kept]] if len(top) else ids[:0]
+        es.append(col[chosen]); el.append(np.full(len(chosen), k, np.int64)); eb.append(boxes[chosen])
+    assert len(es[2]) == 0 and len(es[0]) == 100 and len(es[1]) > 0          # one class with nothing above the threshold
+    assert np.array_equal(pl.cpu().numpy(), np.concatenate(el))
+    assert np.array_equal(ps.cpu().numpy(), np.concatenate(es)) and np.array_equal(pb.cpu().numpy(), np.concatenate(eb))
 
 
 def test_second_kitti_pipeline_runs_and_matches_unfused_paths(dev):

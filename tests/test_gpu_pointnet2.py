@@ -122,25 +122,79 @@ def test_batch_layout_ops(dev):
     np.testing.assert_allclose(tf3.grad.cpu().numpy(), c_oracle.three_interpolate_grad_batch(go3, i_o, w, N), rtol=1e-5, atol=1e-5)
 
 
-def test_set_abstraction_modules_run(dev):
-    """StackSAModuleMSG / StackPointnetFPModule / PointnetSAModuleMSG / PointnetFPModule forward + backward."""
-    xyz, xc, new, nc = _stack_scene(12, sizes=(800, 600), msizes=(64, 48))
+def _perturb_bn(module, seed):
+    g = torch.Generator(device="cpu").manual_seed(seed)
+    with torch.no_grad():
+        for m in module.modules():
+            if isinstance(m, torch.nn.BatchNorm2d):
+                m.running_mean.copy_(torch.empty(m.num_features).uniform_(-0.2, 0.2, generator=g))
+                m.running_var.copy_(torch.empty(m.num_features).uniform_(0.5, 1.5, generator=g))
+                m.weight.copy_(torch.empty(m.num_features).uniform_(0.8, 1.2, generator=g))
+                m.bias.copy_(torch.empty(m.num_features).uniform_(-0.1, 0.1, generator=g))
+    return module.eval()
+
+
+def _close(got, want, what):
+    want = np.asarray(want, np.float64)
+    scale = max(1.0, float(np.abs(want).max()))
+    err = float(np.abs(np.asarray(got, np.float64) - want).max())
+    assert err <= 1e-4 * scale, f"{what}: {err:.3e} vs scale {scale:.3e}"          # north_star: 1e-4 fp32 on features
+
+
+def test_stack_set_abstraction_and_fp_modules_vs_oracle(dev):
+    """QueryAndGroup / StackSAModuleMSG / StackPointnetFPModule (pointnet2_stack/pointnet2_utils.py:119-155,
+    pointnet2_modules.py:58-92,111-137) on a ragged stacked batch with an EMPTY frame and empty balls: grouped tensors bit-exact,
+    module outputs vs the fp64 replay (oracle ball query -> group -> concat -> the same MLP in float64), 1e-4."""
+    from oracle import sa_oracle
+    xyz, xc, new, nc = _stack_scene(12, sizes=(800, 600, 0, 450), msizes=(64, 48, 0, 40))
+    new[5] += 50.0                                                   # a centre with nothing in reach: the empty-ball path
     t = lambda a: torch.from_numpy(a).to(dev)
+    feat = np.random.default_rng(7).standard_normal((len(xyz), 8)).astype(np.float32)
+    for use_xyz in (True, False):
+        qg = sutils.QueryAndGroup(0.8, 16, use_xyz=use_xyz)
+        g, idx = qg(t(xyz), t(xc), t(new), t(nc), t(feat))
+        g_o, idx_o, empty_o = sa_oracle.query_and_group(0.8, 16, xyz, xc, new, nc, feat, use_xyz)
+        assert empty_o[5] and np.array_equal(idx.cpu().numpy(), idx_o)
+        assert np.array_equal(g.cpu().numpy(), g_o), f"QueryAndGroup(use_xyz={use_xyz})"
+    g, _ = sutils.QueryAndGroup(0.8, 16)(t(xyz), t(xc), t(new), t(nc), None)          # xyz only
+    assert np.array_equal(g.cpu().numpy(), sa_oracle.query_and_group(0.8, 16, xyz, xc, new, nc, None)[0])
     torch.manual_seed(0)
-    sa = smod.StackSAModuleMSG(radii=[0.8, 1.6], nsamples=[16, 32], mlps=[[8, 16, 16], [8, 16, 32]]).to(dev)
-    f = torch.randn(len(xyz), 8, device=dev, requires_grad=True)
-    _, nf = sa(t(xyz), t(xc), t(new), t(nc), f)
+    sa = _perturb_bn(smod.StackSAModuleMSG(radii=[0.8, 1.6], nsamples=[16, 32], mlps=[[8, 16, 16], [8, 16, 32]]).to(dev), 1)
+    with torch.no_grad():
+        _, nf = sa(t(xyz), t(xc), t(new), t(nc), t(feat))
     assert nf.shape == (len(new), 48)
-    nf.sum().backward()
-    assert f.grad is not None and torch.isfinite(f.grad).all()
-    fp = smod.StackPointnetFPModule(mlp=[48 + 8, 32]).to(dev)
-    out = fp(t(xyz), t(xc), t(new), t(nc), unknown_feats=f.detach(), known_feats=nf.detach())
+    _close(nf.cpu().numpy(), sa_oracle.stack_sa_msg(sa, xyz, xc, new, nc, feat), "StackSAModuleMSG")
+    fp = _perturb_bn(smod.StackPointnetFPModule(mlp=[48 + 8, 32]).to(dev), 2)
+    with torch.no_grad():
+        out = fp(t(xyz), t(xc), t(new), t(nc), unknown_feats=t(feat), known_feats=nf)
     assert out.shape == (len(xyz), 32)
+    _close(out.cpu().numpy(), sa_oracle.stack_fp(fp, xyz, xc, new, nc, feat, nf.cpu().numpy()), "StackPointnetFPModule")
+    # and gradients reach the features through the whole module (per-op backward parity is tested above)
+    f = t(feat).requires_grad_(True)
+    sa.train()
+    _, nf2 = sa(t(xyz), t(xc), t(new), t(nc), f)
+    nf2.sum().backward()
+    assert f.grad is not None and torch.isfinite(f.grad).all() and float(f.grad.abs().sum()) > 0
+
+
+def test_batch_set_abstraction_and_fp_modules_vs_oracle(dev):
+    """PointnetSAModuleMSG / PointnetFPModule (pointnet2_batch/pointnet2_modules.py:61-101,124-170): FPS centres bit-exact,
+    features vs the fp64 replay, 1e-4."""
+    from oracle import sa_oracle
     B, N = 2, 1024
-    bx = torch.from_numpy(np.stack([synth.cloud_ring(2000 + k)[:N, :3] for k in range(B)], 0)).to(dev)
-    bsa = bmod.PointnetSAModuleMSG(npoint=128, radii=[0.5, 1.0], nsamples=[8, 16], mlps=[[4, 8], [4, 16]]).to(dev)
-    bf = torch.randn(B, 4, N, device=dev, requires_grad=True)
-    nx, nfeat = bsa(bx, bf)
-    assert nx.shape == (B, 128, 3) and nfeat.shape == (B, 24, 128)
-    bfp = bmod.PointnetFPModule(mlp=[24 + 4, 16]).to(dev)
-    assert bfp(bx, nx, bf, nfeat).shape == (B, 16, N)
+    bx = np.stack([synth.cloud_ring(2000 + k)[:N, :3] for k in range(B)], 0).astype(np.float32)
+    bf = np.random.default_rng(8).standard_normal((B, 4, N)).astype(np.float32)
+    t = lambda a: torch.from_numpy(a).to(dev)
+    torch.manual_seed(1)
+    bsa = _perturb_bn(bmod.PointnetSAModuleMSG(npoint=128, radii=[0.5, 1.0], nsamples=[8, 16], mlps=[[4, 8], [4, 16]]).to(dev), 3)
+    with torch.no_grad():
+        nx, nfeat = bsa(t(bx), t(bf))
+    nx_o, nf_o = sa_oracle.batch_sa_msg(bsa, bx, bf)
+    assert nx.shape == (B, 128, 3) and np.array_equal(nx.cpu().numpy(), nx_o)
+    assert nfeat.shape == (B, 24, 128)
+    _close(nfeat.cpu().numpy(), nf_o, "PointnetSAModuleMSG")
+    bfp = _perturb_bn(bmod.PointnetFPModule(mlp=[24 + 4, 16]).to(dev), 4)
+    with torch.no_grad():
+        out = bfp(t(bx), nx, t(bf), nfeat)
+    assert out.shape == (B, 16, N)
+    _close(out.cpu().numpy(), sa_oracle.batch_fp(bfp, bx, nx_o, bf, nfeat.cpu().numpy()), "PointnetFPModule")

@@ -79,16 +79,30 @@ def test_roipoint_pool3d(dev):
     po, eo = c_oracle.roipoint_pool3d(xyz, bx, feat, S)
     assert np.array_equal(empty.cpu().numpy(), eo) and eo.sum() >= 1
     assert np.array_equal(pooled.cpu().numpy(), po)
-    # S larger than every box's point count -> cyclic duplication path
-    pool2 = roipoint_pool3d_utils.RoIPointPool3d(num_sampled_points=512, pool_extra_width=[0.2, 0.2, 0.2])
-    p2, e2 = pool2(torch.from_numpy(xyz).to(dev), torch.from_numpy(feat).to(dev), torch.from_numpy(bx).to(dev))
+    # S larger than every box's point count -> cyclic duplication path, boxes enlarged by pool_extra_width.  The device and
+    # glibc may differ in the last ulp of cos / sin of the heading, which can move a point that sits ON an enlarged face to
+    # the other side; such points (within 1e-3 of a face of any enlarged box, in float64) are taken out of the scene, and the
+    # result must then be exact for EVERY box.
     bxe = bx.copy()
     bxe[:, :, 3:6] += 0.2
-    po2, eo2 = c_oracle.roipoint_pool3d(xyz, bxe, feat, 512)
-    # the enlarged faces may now graze a point: compare only boxes whose oracle membership has a safe margin
+    keep = np.ones((B, N), bool)
+    for b in range(B):
+        p64, q = xyz[b].astype(np.float64), bxe[b].astype(np.float64)
+        d = p64[None, :, :] - q[:, None, :3]
+        c, s_ = np.cos(-q[:, 6])[:, None], np.sin(-q[:, 6])[:, None]
+        lx, ly = d[..., 0] * c - d[..., 1] * s_, d[..., 0] * s_ + d[..., 1] * c
+        near = ((np.abs(np.abs(lx) - q[:, None, 3] / 2) < 1e-3) | (np.abs(np.abs(ly) - q[:, None, 4] / 2) < 1e-3)
+                | (np.abs(np.abs(d[..., 2]) - q[:, None, 5] / 2) < 1e-3))
+        keep[b] = ~near.any(0)
+    n_keep = int(keep.sum(1).min())
+    assert n_keep > N - 400                                           # only a handful of points are affected
+    xyz2 = np.stack([xyz[b][keep[b]][:n_keep] for b in range(B)], 0).copy()
+    feat2 = np.stack([feat[b][keep[b]][:n_keep] for b in range(B)], 0).copy()
+    pool2 = roipoint_pool3d_utils.RoIPointPool3d(num_sampled_points=512, pool_extra_width=[0.2, 0.2, 0.2])
+    p2, e2 = pool2(torch.from_numpy(xyz2).to(dev), torch.from_numpy(feat2).to(dev), torch.from_numpy(bx).to(dev))
+    po2, eo2 = c_oracle.roipoint_pool3d(xyz2, bxe, feat2, 512)
     assert np.array_equal(e2.cpu().numpy(), eo2)
-    same = (p2.cpu().numpy() == po2).reshape(B, M, -1).all(-1)
-    assert same.mean() > 0.95
+    assert np.array_equal(p2.cpu().numpy(), po2)
 
 
 @pytest.mark.parametrize("criterion", [-1, 0, 1, 2])
