@@ -51,26 +51,39 @@ def cpu_baseline(frames, model, nframes):
     m.B = 1
     m.fold_bn = False           # the HIP epilogue has no CPU path: stock modules on the host
     m.anchors = m.anchors.cpu()
-    t0 = time.perf_counter()
+    st = {"voxelize": 0.0, "pfn_scatter": 0.0, "backbone_head": 0.0, "post_decode": 0.0, "nms": 0.0}
+    clk = time.perf_counter
+    t0 = clk()
     for f in frames[:nframes]:
+        a = clk()
         vox, coords, num = c_oracle.voxelize(f, synth.PP_VOXEL, synth.PP_RANGE, 32, model.voxelizer.max_voxels)
+        st["voxelize"] += clk() - a
         coords4 = np.pad(coords, ((0, 0), (1, 0)))
         n = m.pfn_norm
         with torch.no_grad():
+            a = clk()
             feat = pp_oracle.pillar_vfe(torch.from_numpy(vox), torch.from_numpy(num).float(), torch.from_numpy(coords4).float(),
                                         m.pfn_linear.weight, n.weight, n.bias, n.running_mean, n.running_var,
                                         synth.PP_VOXEL, synth.PP_RANGE, eps=n.eps)
             canvas = pp_oracle.pillar_scatter(feat, torch.from_numpy(coords4).float(), 1, m.nx, m.ny)
+            st["pfn_scatter"] += clk() - a
+            a = clk()
             cls, box, dirs = m.backbone_head(canvas)
+            st["backbone_head"] += clk() - a
+            a = clk()
             scores, _ = torch.sigmoid(cls[0]).max(dim=-1)
             msk = scores >= m.score_thresh
             sc, idx = torch.topk(scores[msk], k=min(m.nms_pre, int(msk.sum())))
             oi = msk.nonzero().view(-1)[idx]
             boxes = m.decode(box[0][oi], m.anchors[oi], dirs[0][oi])
+            st["post_decode"] += clk() - a
+        a = clk()
         c_oracle.nms_sorted(boxes.numpy(), m.nms_thresh)
-    dt = time.perf_counter() - t0
+        st["nms"] += clk() - a
+    dt = clk() - t0
     return {"value": nframes / dt, "unit": "frames/s", "cores": torch.get_num_threads(), "kind": "port",
-            "sample": f"{nframes} frame(s) of the same workload: C oracle voxelise+NMS (1 thread) + torch-CPU "
+            "stage_ms_per_frame": {k: v / nframes * 1e3 for k, v in st.items()},
+            "sample": f"{nframes} frame(s) of the same workload: C oracle voxelise + NMS (1 thread each) + torch-CPU "
                       f"PFN/scatter/backbone/head ({torch.get_num_threads()} threads), {dt:.1f} s"}
 
 
@@ -186,13 +199,20 @@ def main():
     P, C = 32, 4
     alg_bytes = 16 * npts + total_rows * (P * C * 4 + 16 + 4)          # 16N + V(4PC + 16 + 4)
     achieved = alg_bytes / (vox_ms * 1e-3) / 1e9
-    # HBM traffic of the same launch from the committed PMC passes (profiles/r01/voxelize_pmc.json; rocprofv3 counters
-    # cannot be collected from inside the timed run).  Upper bracket of the read side, see the file's fetch_correction.
-    traffic = None
-    pmc = os.path.join(ROOT, "profiles", "r01", "voxelize_pmc.json")
+    # HBM traffic of the same launch sequence: rocprofv3 PMC counters cannot be collected from inside this run, so the figure
+    # comes from the committed passes (profiles/r02/voxelize_pmc.json) and is only reported when that file was taken from the
+    # SAME kernel source (sha256 of csrc/voxelize.hip recorded beside it); otherwise null — never a stale number.
+    traffic, traffic_src = None, None
+    pmc = os.path.join(ROOT, "profiles", "r02", "voxelize_pmc.json")
     if os.path.exists(pmc) and args.batch == 16:
+        import hashlib
         with open(pmc) as fh:
-            traffic = json.load(fh).get("traffic_bytes_per_launch_high")
+            rec = json.load(fh)
+        with open(os.path.join(ROOT, "lidardetection_amd", "csrc", "voxelize.hip"), "rb") as fh:
+            sha = hashlib.sha256(fh.read()).hexdigest()[:16]
+        if rec.get("kernel_source_sha256_16") == sha:
+            traffic = rec.get("traffic_bytes_per_launch_high")
+            traffic_src = f"profiles/r02/voxelize_pmc.json (voxelize.hip sha256 {sha}; FETCH_SIZE upper bracket + WRITE_SIZE, separate --pmc passes)"
     frames_total = args.batch * args.steps * world
     res = {
         "metric": "frames/sec (fwd+NMS) PointPillar-KITTI", "value": frames_total / dt, "unit": "frames/s",
@@ -204,7 +224,7 @@ def main():
                    "frames_per_step": args.batch, "replicas": world},
         "roofline": {"bound": "hbm", "kernel": "lidar_voxelize (vxl_keybin = key + bin + zero-fill roles in one launch, vxl_emit)",
                      "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
-                     "traffic": traffic, "alg_bytes_per_launch": alg_bytes, "ms_per_launch": vox_ms,
+                     "traffic": traffic, "traffic_source": traffic_src, "alg_bytes_per_launch": alg_bytes, "ms_per_launch": vox_ms,
                      # informational: an empty HIP event pair recorded at the same place (dispatch + marker latency that the
                      # bracket above also contains); `frac` does NOT subtract it
                      "event_pair_overhead_ms": ev_overhead_ms},
@@ -229,6 +249,16 @@ def main():
             tp, outp = gpu_time(lambda: model.post_process(*hb))
         print(f"[stages ms/batch] voxelize {tv:.3f} vfe+scatter {ts:.3f} backbone+head {tb:.3f} post+nms {tp:.3f} "
               f"kept/frame {outp[3].float().mean().item():.1f}", file=sys.stderr)
+    if rank == 0 and world == 1 and not args.no_extra:
+        sys.path.insert(0, os.path.join(ROOT, "tools"))
+        import bench_extra
+        del out, canvas, vox
+        try:
+            res["extra"] = bench_extra.pp_kernels(model, pts, offs)
+        except Exception as e:
+            res["extra"] = {"pp_kernels_error": repr(e)[:200]}
+        torch.cuda.empty_cache()
+        res["extra"].update(bench_extra.collect(device))
     if rank == 0:
         if not args.no_cpu_baseline and world == 1:
             try:
