@@ -42,7 +42,13 @@ extern "C" {
  *                 zero-padded clouds — is handled exactly by a streaming variant); 1 and 3 need n_max <= 32768 and
  *                 have no global atomics on the data path; more distinct voxels / list cells in ONE hash bin than its
  *                 LDS holds (adversarial input only) sets the sticky flag read by lidar_voxelize_error_flag / mirrored
- *                 to the host by lidar_voxelize_set_error_mirror; 2: global hash table (any n_max)
+ *                 to the host by lidar_voxelize_set_error_mirror; 2: global hash table (any n_max);
+ *                 4: as 3 with a RESIDENT output buffer (compact layout): the caller passes the SAME voxels / num_points
+ *                 buffers call after call and does not write to them in between; the zero padding then survives from call
+ *                 to call and only the slots the previous call filled are re-zeroed (~30 MB of HBM traffic per 16 KITTI
+ *                 frames instead of 150 MB), results unchanged.  The workspace remembers the buffer addresses: another
+ *                 buffer (or the first call) is cleared in full, so only an in-place modification by the caller between
+ *                 calls can break the contract
  *   voxels        (batch*max_voxels, max_points, C) f32; rows [0, total) fully written (zero padded)
  *   coords        (batch*max_voxels, 4) i32 [b, z, y, x]
  *   num_points    (batch*max_voxels) i32

@@ -69,6 +69,8 @@ struct VxWs {
     int *fillst;     // [2] LDS path, compact mode: [0] rows the NEXT call should pre-clear (last total + 25 % + 1024),
                      //     [1] the value this call's fill role used (copied by the bin launch; read by the emit launch)
     int *bvox;       // [B][VXL_GMAX] fused launch: first points (= voxels) found by bin g of frame f (plain stores, no zeroing)
+    long long *resident;  // [4] resident-output mode (algo 4): {voxels ptr, num_points ptr, rows the previous call produced, P * C};
+                          //     [0] == 0: no valid history (the next resident call clears the whole buffer)
     int **mirror;    // [1] optional device-visible HOST address (pinned, mapped) that also receives the error bits, so the
                      //     host can poll the flag without a copy or a sync (lidar_voxelize_set_error_mirror); null = none
 };
@@ -119,6 +121,7 @@ static size_t vx_carve(void *base, int B, int n_max, int max_voxels, VxWs *w) {
     p = take((size_t)B * 4); if (w) w->nvox = (int *)p;
     p = take(256); if (w) w->fillst = (int *)p;
     p = take((size_t)B * 16 * 4 + 256); if (w) w->bvox = (int *)p;
+    p = take(256); if (w) w->resident = (long long *)p;
     p = take(256); if (w) w->mirror = (int **)p;
     return off;
 }
@@ -140,6 +143,7 @@ __global__ void vx_ws_init_kernel(VxWs w, long long nh, long long nl, long long 
     if (i == 0) {
         *w.err = 0;
         *w.mirror = nullptr;
+        w.resident[0] = w.resident[1] = w.resident[2] = w.resident[3] = 0;
         w.fillst[0] = w.fillst[1] = 0x7fffffff;     // no history yet: clear the whole buffer
     }
 }
@@ -349,6 +353,7 @@ __global__ __launch_bounds__(256) void vx_rows_kernel(const float *__restrict__ 
             }
         }
         if (blockIdx.x == (unsigned)row_blocks && f == 0 && threadIdx.x == 0) {
+            w.resident[0] = 0;                       // this path leaves no resident-output history
             int b = 0;
             for (int k = 0; k < p.batch; ++k) {
                 voxel_offsets[k] = p.compact ? b : k * p.max_voxels;
@@ -755,7 +760,7 @@ template <bool C4>
 __global__ __launch_bounds__(1024) void vxl_emit_kernel(const float *__restrict__ points, const int *__restrict__ offsets,
                                                         VxParams p, VxWs w, int G, float *__restrict__ voxels,
                                                         int *__restrict__ coords, int *__restrict__ num_points,
-                                                        int *__restrict__ voxel_offsets, int fused) {
+                                                        int *__restrict__ voxel_offsets, int fused, int resident) {
     __shared__ int s_part[16], s_wcnt[16];
     __shared__ int s_base;
     const int tile = blockIdx.x, f = blockIdx.y, t = threadIdx.x, l = t & 63, wv = t >> 6;
@@ -802,6 +807,12 @@ __global__ __launch_bounds__(1024) void vxl_emit_kernel(const float *__restrict_
             // rows the next call's fill role should clear up front (nobody reads fillst[0] during this launch)
             const long long next = (long long)carry + carry / 4 + 1024;
             w.fillst[0] = p.compact ? (int)min(next, (long long)p.batch * p.max_voxels) : 0x7fffffff;
+            // resident-output history for the next call (a non-resident call leaves rows beyond its fill extent unspecified,
+            // so it invalidates the history)
+            w.resident[0] = resident ? (long long)reinterpret_cast<uintptr_t>(voxels) : 0ll;
+            w.resident[1] = (long long)reinterpret_cast<uintptr_t>(num_points);
+            w.resident[2] = carry;
+            w.resident[3] = (long long)p.P * p.C;
         }
     }
     const long long cleared_rows = p.compact ? (long long)w.fillst[1] : 0x7fffffffll;
@@ -1035,7 +1046,8 @@ template <bool C4>
 __global__ __launch_bounds__(1024) void vxl_keybin_kernel(const float *__restrict__ points, const int *__restrict__ offsets,
                                                           VxParams p, VxWs w, int G, int nbinwg, int nfillwg,
                                                           float *__restrict__ voxels, long long total_f4,
-                                                          long long tail_floats, int help16) {
+                                                          long long tail_floats, int help16, int resident,
+                                                          const int *__restrict__ prev_counts) {
     __shared__ uint32_t s_key[VXL_S];   // keys; after phase C: list offset of the slot
     __shared__ int s_first[VXL_S];
     __shared__ int s_cnt[VXL_S];
@@ -1045,13 +1057,34 @@ __global__ __launch_bounds__(1024) void vxl_keybin_kernel(const float *__restric
     __shared__ int s_nent, s_total, s_nrisk;
     __shared__ float4 s_risk[VXL_RISK_CAP];   // points whose cell the exact division must decide: (x, y, z, index)
     const int id = blockIdx.x, t = threadIdx.x, l = t & 63;
+    // ---- resident output (algo 4): the buffer still holds the previous call's result on an otherwise all-zero background, so
+    // only the slots that call filled are re-zeroed (rows x count x 16 B instead of the whole padded buffer).  Valid only if the
+    // history in the workspace names this very buffer / count array / row width; otherwise: clear everything, as a first call.
+    const bool res_hist = resident && p.compact && w.resident[0] == (long long)reinterpret_cast<uintptr_t>(voxels) &&
+                          w.resident[1] == (long long)reinterpret_cast<uintptr_t>(prev_counts) &&
+                          w.resident[3] == (long long)p.P * p.C;
     // ---- fill geometry (all roles): chunks of 64 KiB; the last help16/16 of them belong to the bin roles
-    const long long lim_rows = p.compact ? (long long)w.fillst[0] : 0x7fffffffll;
+    const long long lim_rows = (p.compact && !resident) ? (long long)w.fillst[0] : 0x7fffffffll;
     const long long lim_f4 = (lim_rows >= 0x7fffffffll) ? total_f4 : min(total_f4, (lim_rows * p.P * p.C + 3) / 4);
     const long long nchunks = (lim_f4 + VXL_FILL_F4_PER_WG - 1) / VXL_FILL_F4_PER_WG;
     const long long nhelp = nchunks * help16 / 16, nmain = nchunks - nhelp;
     float4 *dst = reinterpret_cast<float4 *>(voxels);
     if (id >= nbinwg) {                  // ---- fill role (block-uniform)
+        if (res_hist) {                  // re-zero what the previous call wrote: one thread per row, `count` slots each
+            const long long prev_rows = w.resident[2];
+            const int rowlen = p.P * p.C;
+            for (long long r = (long long)(id - nbinwg) * 1024 + t; r < prev_rows; r += (long long)nfillwg * 1024) {
+                const int c = min(prev_counts[r], p.P);
+                if (C4) {
+                    float4 *o = dst + r * p.P;
+                    for (int sl = 0; sl < c; ++sl) o[sl] = make_float4(0.f, 0.f, 0.f, 0.f);
+                } else {
+                    float *o = voxels + r * rowlen;
+                    for (int e = 0; e < c * p.C; ++e) o[e] = 0.f;
+                }
+            }
+            return;
+        }
         vxl_fill_chunks(dst, id - nbinwg, nfillwg, nmain, lim_f4, t);
         if (id == nbinwg && (long long)t < tail_floats) voxels[total_f4 * 4 + t] = 0.f;     // bytes past the last float4
         return;
@@ -1073,7 +1106,8 @@ __global__ __launch_bounds__(1024) void vxl_keybin_kernel(const float *__restric
         const int start = offsets[f];
         const int n = min(offsets[f + 1] - start, p.n_max);
         const int nt = (n + 1023) >> 10;
-        if (id == 0 && t == 0) w.fillst[1] = w.fillst[0];   // what the fill roles of THIS call use; the emit launch reads it
+        // rows the fill roles of THIS call leave zero (the emit launch reads it): everything in resident mode
+        if (id == 0 && t == 0) w.fillst[1] = resident ? 0x7fffffff : w.fillst[0];
         for (int k = t; k < VXL_S / 4; k += 1024) {
             reinterpret_cast<uint4 *>(s_key)[k] = make_uint4(VX_EMPTY, VX_EMPTY, VX_EMPTY, VX_EMPTY);
             reinterpret_cast<int4 *>(s_first)[k] = make_int4(VX_INF, VX_INF, VX_INF, VX_INF);
@@ -1231,7 +1265,7 @@ __global__ __launch_bounds__(1024) void vxl_keybin_kernel(const float *__restric
     }
     VXL_STAMP(7);
     // ---- done with the index build: help with the tail of the fill
-    vxl_fill_chunks(dst, nmain + id, nbinwg, nchunks, lim_f4, t);
+    if (!res_hist) vxl_fill_chunks(dst, nmain + id, nbinwg, nchunks, lim_f4, t);
 }
 
 static int vxl_bins(int n_max) { return divup(n_max, VXL_PTS_PER_BIN); }
@@ -1243,7 +1277,7 @@ static int vxl_env_int(const char *name, int dflt) {
 
 // fused key + bin + fill launch, then emit: 2 launches
 static void vxl_run_fused(const float *points, const int *point_offsets, const VxParams &p, const VxWs &w, bool c4,
-                          float *voxels, int *coords, int *num_points, int *voxel_offsets, hipStream_t s) {
+                          float *voxels, int *coords, int *num_points, int *voxel_offsets, hipStream_t s, int resident) {
     // share (in 1/16) of the fill left to the bin roles once they are done: 0 measured best (33.9 / 34.7 / 35.4 / 36.4 us
     // for 1 / 2 / 3 / 4 sixteenths) — the bin roles are the longer pole of the launch
     const int help16 = 0;
@@ -1257,11 +1291,11 @@ static void vxl_run_fused(const float *points, const int *point_offsets, const V
     const int nfillwg = nbinwg < 192 ? 256 - nbinwg : 64;              // one resident workgroup per CU (LDS-bound)
     if (tail_floats > 1024) (void)hipMemsetAsync(voxels, 0, (size_t)total_floats * sizeof(float), s);   // unaligned buffer
     const long long tf = tail_floats <= 1024 ? tail_floats : 0;
-    if (c4) hipLaunchKernelGGL(vxl_keybin_kernel<true>, dim3(nbinwg + nfillwg), dim3(1024), 0, s, points, point_offsets, p, w, G, nbinwg, nfillwg, voxels, total_f4, tf, help16);
-    else hipLaunchKernelGGL(vxl_keybin_kernel<false>, dim3(nbinwg + nfillwg), dim3(1024), 0, s, points, point_offsets, p, w, G, nbinwg, nfillwg, voxels, total_f4, tf, help16);
+    if (c4) hipLaunchKernelGGL(vxl_keybin_kernel<true>, dim3(nbinwg + nfillwg), dim3(1024), 0, s, points, point_offsets, p, w, G, nbinwg, nfillwg, voxels, total_f4, tf, help16, resident, num_points);
+    else hipLaunchKernelGGL(vxl_keybin_kernel<false>, dim3(nbinwg + nfillwg), dim3(1024), 0, s, points, point_offsets, p, w, G, nbinwg, nfillwg, voxels, total_f4, tf, help16, resident, num_points);
     const dim3 ge(ntiles, p.batch);
-    if (c4) hipLaunchKernelGGL(vxl_emit_kernel<true>, ge, dim3(1024), 0, s, points, point_offsets, p, w, G, voxels, coords, num_points, voxel_offsets, 1);
-    else hipLaunchKernelGGL(vxl_emit_kernel<false>, ge, dim3(1024), 0, s, points, point_offsets, p, w, G, voxels, coords, num_points, voxel_offsets, 1);
+    if (c4) hipLaunchKernelGGL(vxl_emit_kernel<true>, ge, dim3(1024), 0, s, points, point_offsets, p, w, G, voxels, coords, num_points, voxel_offsets, 1, resident);
+    else hipLaunchKernelGGL(vxl_emit_kernel<false>, ge, dim3(1024), 0, s, points, point_offsets, p, w, G, voxels, coords, num_points, voxel_offsets, 1, resident);
 }
 
 static void vxl_run(const float *points, const int *point_offsets, const VxParams &p, const VxWs &w, bool c4,
@@ -1289,8 +1323,8 @@ static void vxl_run(const float *points, const int *point_offsets, const VxParam
     else if (items <= 24) hipLaunchKernelGGL(vxl_bin_kernel<24>, gb, dim3(1024), 0, s, point_offsets, p, w, G);
     else hipLaunchKernelGGL(vxl_bin_kernel<32>, gb, dim3(1024), 0, s, point_offsets, p, w, G);
     const dim3 ge(ntiles, p.batch);
-    if (c4) hipLaunchKernelGGL(vxl_emit_kernel<true>, ge, dim3(1024), 0, s, points, point_offsets, p, w, G, voxels, coords, num_points, voxel_offsets, 0);
-    else hipLaunchKernelGGL(vxl_emit_kernel<false>, ge, dim3(1024), 0, s, points, point_offsets, p, w, G, voxels, coords, num_points, voxel_offsets, 0);
+    if (c4) hipLaunchKernelGGL(vxl_emit_kernel<true>, ge, dim3(1024), 0, s, points, point_offsets, p, w, G, voxels, coords, num_points, voxel_offsets, 0, 0);
+    else hipLaunchKernelGGL(vxl_emit_kernel<false>, ge, dim3(1024), 0, s, points, point_offsets, p, w, G, voxels, coords, num_points, voxel_offsets, 0, 0);
 }
 
 // ------------------------------------------------------------------ C ABI
@@ -1366,14 +1400,16 @@ LIDAR_EXPORT int lidar_voxelize(const float *points, const int *point_offsets, i
     hipStream_t s = (hipStream_t)stream;
     const bool c4 = (num_features == 4) && ((reinterpret_cast<uintptr_t>(points) & 15) == 0) &&
                     ((reinterpret_cast<uintptr_t>(voxels) & 15) == 0);
-    // algo 0 = auto, 1 = LDS-binned 3 launches, 3 = LDS-binned fused 2 launches (both: n_max <= 32768, max_points < 16384),
-    // 2 = global hash table (any size)
+    // algo 0 = auto, 1 = LDS-binned 3 launches, 3 = LDS-binned fused 2 launches, 4 = 3 with a resident output buffer
+    // (1 / 3 / 4: n_max <= 32768, max_points < 16384), 2 = global hash table (any size)
     const bool lds_ok = (n_max <= VXL_MAX_ITEMS * 1024) && (max_points <= VXL_MMASK);
-    if ((algo == 1 || algo == 3) && !lds_ok) return LIDAR_ERR_ARG;
+    if ((algo == 1 || algo == 3 || algo == 4) && !lds_ok) return LIDAR_ERR_ARG;
     static const int auto_algo = vxl_env_int("LIDAR_VXL_ALGO", 3);
     if (algo == 0 && lds_ok) algo = (auto_algo == 1) ? 1 : 3;
-    if (algo == 3) {
-        vxl_run_fused(points, point_offsets, p, w, c4, voxels, coords, num_points, voxel_offsets, s);
+    if (algo == 3 || algo == 4) {
+        const bool unaligned = ((reinterpret_cast<uintptr_t>(voxels) & 15) != 0);      // the resident clear wants 16-B rows
+        vxl_run_fused(points, point_offsets, p, w, c4, voxels, coords, num_points, voxel_offsets, s,
+                      (algo == 4 && compact && !unaligned) ? 1 : 0);
         return lidar_check_launch("lidar_voxelize(fused)");
     }
     if (algo == 1) {

@@ -74,6 +74,10 @@ def limit_period(val, offset=0.5, period=np.pi):
 
 
 class PointPillarKITTI(nn.Module):
+    # the model owns its voxel output buffers and nothing writes to them between forwards: keep their zero padding resident
+    # (BatchVoxelizer.__call__(resident=True)); set to False to rewrite the whole padded buffer every call
+    resident_voxels = True
+
     def __init__(self, batch_size=16, max_voxels=16000, n_max=20000, device="cuda",
                  score_thresh=0.1, nms_thresh=0.01, nms_pre=4096, nms_post=500, channels_last=True, fold_bn=True):
         super().__init__()
@@ -133,7 +137,7 @@ class PointPillarKITTI(nn.Module):
 
     # ---- stages (kept separate so bench.py can time them) ------------------------------------
     def voxelize(self, points, point_offsets):
-        return self.voxelizer(points, point_offsets, self.n_max, compact=True, out=self._vox_out)
+        return self.voxelizer(points, point_offsets, self.n_max, compact=True, out=self._vox_out, resident=self.resident_voxels)
 
     def vfe_scatter(self, vox):
         w, s, t = self._pfn_folded()

@@ -45,7 +45,7 @@ class SECONDKitti(PointPillarKITTI):
 
     # ---- stages --------------------------------------------------------------------------------
     def voxelize_vfe(self, points, point_offsets):
-        vox = self.voxelizer(points, point_offsets, self.n_max, compact=True, out=self._vox_out)
+        vox = self.voxelizer(points, point_offsets, self.n_max, compact=True, out=self._vox_out, resident=self.resident_voxels)
         total = int(vox["voxel_offsets"][self.B])               # the sparse stack needs exact row counts (one read-back)
         feats = pillar_ops.mean_vfe(vox["voxels"][:total], vox["voxel_num_points"][:total])
         return feats, vox["voxel_coords"][:total]

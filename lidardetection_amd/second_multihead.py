@@ -95,6 +95,8 @@ class SingleHead(nn.Module):
 
 
 class SECONDMultiHeadNuScenes(nn.Module):
+    resident_voxels = True      # see PointPillarKITTI.resident_voxels
+
     def __init__(self, batch_size=4, max_voxels=60000, n_max=30000, device="cuda", score_thresh=0.1, nms_thresh=0.2,
                  nms_pre=1000, nms_post=83):
         super().__init__()
@@ -137,7 +139,7 @@ class SECONDMultiHeadNuScenes(nn.Module):
 
     # ---- stages --------------------------------------------------------------------------------
     def voxelize_vfe(self, points, point_offsets):
-        vox = self.voxelizer(points, point_offsets, self.n_max, compact=True, out=self._vox_out)
+        vox = self.voxelizer(points, point_offsets, self.n_max, compact=True, out=self._vox_out, resident=self.resident_voxels)
         total = int(vox["voxel_offsets"][self.B])               # the sparse stack needs exact row counts (one read-back)
         feats = pillar_ops.mean_vfe(vox["voxels"][:total], vox["voxel_num_points"][:total])
         return feats, vox["voxel_coords"][:total]

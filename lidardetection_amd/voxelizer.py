@@ -71,10 +71,13 @@ class BatchVoxelizer:
             "voxel_offsets": torch.empty((batch + 1,), dtype=torch.int32, device=device),
         }
 
-    def __call__(self, points, point_offsets, n_max, compact=True, out=None):
+    def __call__(self, points, point_offsets, n_max, compact=True, out=None, resident=False):
         """points (sum N, C) f32 cuda; point_offsets (B+1) int32 cuda; n_max >= max frame size (host int).
         Returns dict(voxels, voxel_coords [b,z,y,x], voxel_num_points, voxel_offsets); rows beyond
-        voxel_offsets[-1] are unspecified.  No host synchronisation."""
+        voxel_offsets[-1] are unspecified.  No host synchronisation.
+        resident=True (with a persistent `out` that nobody else writes to between calls): the zero padding of `out` is kept
+        from call to call and only the previous call's occupied slots are re-zeroed (include/lidar_hip.h, algo 4); the result is
+        bit-identical, and rows beyond voxel_offsets[-1] are then all zero."""
         _lib.require_cuda(points, point_offsets)
         if points.dtype != torch.float32 or point_offsets.dtype != torch.int32:
             raise _lib.LidarHipError("points must be float32 and point_offsets int32")
@@ -87,8 +90,9 @@ class BatchVoxelizer:
         if out is None:
             out = self.alloc_outputs(batch, points.device)
         L = _lib.lib()
+        algo = 4 if (resident and compact and self.algo in (0, 3, 4) and n_max <= 32768) else self.algo
         _lib.check(L.lidar_voxelize(_lib.ptr(points), _lib.ptr(point_offsets), batch, n_max, self.C, self._range_h,
-                                    self._vs_h, self._grid_h, self.max_num_points, self.max_voxels, int(bool(compact)), self.algo,
+                                    self._vs_h, self._grid_h, self.max_num_points, self.max_voxels, int(bool(compact)), algo,
                                     _lib.ptr(out["voxels"]), _lib.ptr(out["voxel_coords"]),
                                     _lib.ptr(out["voxel_num_points"]), _lib.ptr(out["voxel_offsets"]), _lib.ptr(ws),
                                     nbytes, _lib.stream()), "lidar_voxelize")

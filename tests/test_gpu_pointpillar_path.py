@@ -490,3 +490,57 @@ def test_voxelize_adaptive_fill_over_successive_calls(dev):
             assert np.array_equal(o["voxel_num_points"][a:b].cpu().numpy(), nu)
             assert np.array_equal(o["voxel_coords"][a:b, 1:].cpu().numpy(), co)
         assert vz.error_flag(len(frames), 20000, dev) == 0
+
+
+@pytest.mark.parametrize("shape", ["pp", "nus"])
+def test_voxelize_resident_output_equals_fresh_output(dev, shape):
+    """Resident output buffer (include/lidar_hip.h algo 4, BatchVoxelizer(resident=True)): the zero padding survives from call to
+    call and only the previous call's occupied slots are re-zeroed.  Alternating sparse / dense / tiny / empty batches through ONE
+    buffer must give, after every call, exactly the sequential oracle's rows on an otherwise ALL-ZERO buffer; a different buffer,
+    or a non-resident call in between, must be detected (workspace history) and cleared in full even when it is poisoned."""
+    if shape == "pp":
+        vs, rng, P, maxv, C = synth.PP_VOXEL, synth.PP_RANGE, 32, 16000, 4
+        gen = lambda kind, f: {"sparse": synth.cloud_ring(2000 + f), "dense": synth.cloud_uniform(1000 + f),
+                               "tiny": synth.cloud_uniform(1100 + f)[:500], "empty": np.zeros((0, 4), np.float32)}[kind]
+        n_max = 20000
+    else:
+        vs, rng, P, maxv, C = synth.NUS_VOXEL, synth.NUS_RANGE, 10, 60000, 5
+        gen = lambda kind, f: {"sparse": synth.cloud_nus(4000 + f)[:9000], "dense": synth.cloud_nus(4100 + f),
+                               "tiny": synth.cloud_nus(4200 + f)[:300], "empty": np.zeros((0, 5), np.float32)}[kind]
+        n_max = 30000
+    B = 3
+    vz = BatchVoxelizer(vs, rng, P, maxv, C)
+    out = vz.alloc_outputs(B, dev)
+    out["voxels"].fill_(float("nan"))                     # the first resident call must clear everything
+
+    def run_and_check(kinds, buf, resident=True, whole_buffer=True):
+        frames = [gen(k, f) for f, k in enumerate(kinds)]
+        sizes = [len(f) for f in frames]
+        pts = torch.from_numpy(np.concatenate(frames) if sum(sizes) else np.zeros((1, C), np.float32)).to(dev)
+        offs = torch.tensor(np.concatenate([[0], np.cumsum(sizes)]), dtype=torch.int32, device=dev)
+        o = vz(pts, offs, n_max, compact=True, out=buf, resident=resident)
+        offsets = o["voxel_offsets"].cpu().numpy()
+        for f, pf in enumerate(frames):
+            vo, co, nu = c_oracle.voxelize(pf, vs, rng, P, maxv)
+            a, b = int(offsets[f]), int(offsets[f + 1])
+            assert b - a == len(vo), (kinds, f)
+            assert np.array_equal(o["voxels"][a:b].cpu().numpy().view(np.uint32), vo.view(np.uint32)), (kinds, f)
+            assert np.array_equal(o["voxel_num_points"][a:b].cpu().numpy(), nu) and np.array_equal(o["voxel_coords"][a:b, 1:].cpu().numpy(), co)
+        if whole_buffer:
+            assert not o["voxels"][int(offsets[-1]):].any(), kinds      # everything beyond the produced rows is zero
+        return o
+
+    for kinds in (["sparse"] * 3, ["dense"] * 3, ["sparse", "tiny", "dense"], ["tiny"] * 3, ["empty", "dense", "empty"],
+                  ["dense"] * 3, ["empty"] * 3, ["sparse"] * 3):
+        run_and_check(kinds, out)
+    other = vz.alloc_outputs(B, dev)
+    other["voxels"].fill_(float("nan"))
+    run_and_check(["dense"] * 3, other)                   # another buffer: history does not match -> full clear
+    run_and_check(["sparse"] * 3, other)
+    out["voxels"].fill_(float("nan"))                     # the old buffer was modified behind the voxeliser's back, but the
+    run_and_check(["dense"] * 3, out)                     # history names `other` now: cleared in full again
+    # a non-resident call leaves rows beyond its fill extent unspecified: it must invalidate the history
+    run_and_check(["tiny"] * 3, out, resident=False, whole_buffer=False)
+    out["voxels"][5000:].fill_(float("nan"))              # (those rows are "unspecified" after a non-resident call)
+    run_and_check(["dense"] * 3, out)
+    assert vz.error_flag(B, n_max, dev) == 0
