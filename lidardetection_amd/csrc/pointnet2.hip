@@ -15,6 +15,7 @@
 //     gathered feature rows and the (M, C, nsample) output are accessed with full 256-B wave transactions;
 //   * scatter-add backward passes issue float atomics as contiguous per-wave row segments.
 #include "common.h"
+#include <type_traits>
 
 #define PN_TPB 256
 #define PN_TILE 1024
@@ -433,6 +434,242 @@ __global__ __launch_bounds__(TPB) void fps_kernel(int n, int m, int block_ref_ma
         }
 }
 
+// ------------------------------------------------------------------ bucketed FPS (4 096 <= n <= 20 480)
+// The kernel above spends its round on n distance updates although a new sample only lowers the running distances of the
+// points around it.  Here the points of a sample are sorted once into spatial buckets of 64 (Morton order of a 32 x 32 x/y
+// grid over the sample's extent; a bucket = one register slot of one wave, a point = one lane), every bucket keeps its bounding
+// box and the largest running distance of its points (with that point's tie key and coordinates), and a round
+//   1. tests every bucket: lb = squared distance from the new sample to the bucket's box, evaluated with the SAME fp32
+//      expression shape as a point distance, so lb <= d(p) for every point p of the bucket by monotonicity of each rounding;
+//      lb >= the bucket's largest running distance  =>  min(running, d) changes nothing there: the bucket is skipped;
+//   2. updates the few buckets that remain (a wave-uniform branch per register slot), re-deriving their maximum;
+//   3. takes the argmax over the buckets' maxima: wave -> one LDS partial per wave -> ONE barrier -> every wave finishes.
+// The running-distance array is the reference's, element for element, and the argmax uses the same total order (value, then
+// the reference's tie key), so the sample sequence is identical — only work that cannot change it is left out.
+// 8 waves x 40 slots x 64 lanes = 20 480 points; coordinates live in registers (2 waves per SIMD), running distances in LDS.
+#define FB_W 8
+#define FB_S 40
+#define FB_TPB (FB_W * 64)
+#define FB_CAP (FB_W * FB_S * 64)
+
+__device__ __forceinline__ float fb_dpp_max_row(float v) {        // max of each 16-lane row, in all of its lanes
+    v = fmaxf(v, __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), DPP_XOR1, 0xf, 0xf, true)));
+    v = fmaxf(v, __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), DPP_XOR2, 0xf, 0xf, true)));
+    v = fmaxf(v, __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), DPP_HALF_MIRROR, 0xf, 0xf, true)));
+    v = fmaxf(v, __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), DPP_MIRROR, 0xf, 0xf, true)));
+    return v;
+}
+__device__ __forceinline__ float fb_rl(float v, int lane) { return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), lane)); }
+__device__ __forceinline__ float fb_wave_max(float v) {            // wave-uniform max of 64 lanes
+    v = fb_dpp_max_row(v);
+    return fmaxf(fmaxf(fb_rl(v, 15), fb_rl(v, 31)), fmaxf(fb_rl(v, 47), fb_rl(v, 63)));
+}
+__device__ __forceinline__ float fb_wave_min(float v) { return -fb_wave_max(-v); }
+// best (value, key) of 64 lanes, wave-uniform
+__device__ __forceinline__ void fb_wave_best(float &v, int &key) {
+    fps_row_reduce(v, key);
+    float bv = fb_rl(v, 15);
+    int bk = __builtin_amdgcn_readlane(key, 15);
+#pragma unroll
+    for (int q = 31; q < 64; q += 16) {
+        const float ov = fb_rl(v, q);
+        const int ok = __builtin_amdgcn_readlane(key, q);
+        const bool take = fps_better(ov, ok, bv, bk);
+        bv = take ? ov : bv;
+        bk = take ? ok : bk;
+    }
+    v = bv;
+    key = bk;
+}
+__device__ __forceinline__ int fb_tie_key(int k, int block_ref_mask) {
+    return (int)((__brev((unsigned)(k & block_ref_mask)) >> 17) << 15) | k;
+}
+__device__ __forceinline__ int fb_morton5(int cx, int cy) {
+    int m = 0;
+#pragma unroll
+    for (int b = 0; b < 5; ++b) m |= (((cx >> b) & 1) << (2 * b)) | (((cy >> b) & 1) << (2 * b + 1));
+    return m;
+}
+
+typedef float fb_v16 __attribute__((ext_vector_type(16)));
+// register slot (hi * 16 + lo) of a 48-slot bank, hi / lo wave-uniform
+__device__ __forceinline__ float fb_pick(fb_v16 b0, fb_v16 b1, fb_v16 b2, int hi, int lo) {
+    const float a = b0[lo], b = b1[lo], c = b2[lo];
+    return hi == 0 ? a : (hi == 1 ? b : c);
+}
+#define FB_PUT(B, j, v) do { if ((j) < 16) B##0[(j) & 15] = (v); else if ((j) < 32) B##1[(j) & 15] = (v); else B##2[(j) & 15] = (v); } while (0)
+
+__global__ __launch_bounds__(FB_TPB) void fps_bucket_kernel(int n, int m, int block_ref_mask, const float *__restrict__ data,
+                                                            float *__restrict__ temp, int *__restrict__ idxs) {
+    __shared__ unsigned short s_perm[FB_CAP];        // sorted rank -> original point index
+    __shared__ float s_md[FB_CAP];                   // running distances by sorted rank (only active buckets touch them)
+    __shared__ int s_hist[1024];
+    __shared__ int s_wsum[FB_W];
+    __shared__ float s_ext[4][FB_W];
+    __shared__ float4 s_rec[2][FB_W][2];             // per round parity and wave: (value, tie key, x, y), (z, -, -, -)
+    const int bidx = blockIdx.x, t = threadIdx.x, l = t & 63;
+    const int wv = __builtin_amdgcn_readfirstlane(t >> 6);
+    const float *D = data + (size_t)bidx * n * 3;
+    float *T = temp + (size_t)bidx * n;
+    int *O = idxs + (size_t)bidx * m;
+    // ---- x / y extent of the sample
+    float xlo = 3.0e38f, xhi = -3.0e38f, ylo = 3.0e38f, yhi = -3.0e38f;
+    for (int k = t; k < n; k += FB_TPB) {
+        const float x = D[(size_t)k * 3], y = D[(size_t)k * 3 + 1];
+        xlo = fminf(xlo, x); xhi = fmaxf(xhi, x); ylo = fminf(ylo, y); yhi = fmaxf(yhi, y);
+    }
+    xlo = fb_wave_min(xlo); xhi = fb_wave_max(xhi); ylo = fb_wave_min(ylo); yhi = fb_wave_max(yhi);
+    if (l == 0) { s_ext[0][wv] = xlo; s_ext[1][wv] = xhi; s_ext[2][wv] = ylo; s_ext[3][wv] = yhi; }
+    for (int k = t; k < 1024; k += FB_TPB) s_hist[k] = 0;
+    __syncthreads();
+#pragma unroll
+    for (int q = 0; q < FB_W; ++q) {
+        xlo = fminf(xlo, s_ext[0][q]); xhi = fmaxf(xhi, s_ext[1][q]); ylo = fminf(ylo, s_ext[2][q]); yhi = fmaxf(yhi, s_ext[3][q]);
+    }
+    const float sx = 32.0f / fmaxf(xhi - xlo, 1e-6f), sy = 32.0f / fmaxf(yhi - ylo, 1e-6f);
+    auto cell_of = [&](int k) {
+        const float x = D[(size_t)k * 3], y = D[(size_t)k * 3 + 1];
+        const int cx = min(max((int)((x - xlo) * sx), 0), 31), cy = min(max((int)((y - ylo) * sy), 0), 31);   // NaN -> 0
+        return fb_morton5(cx, cy);
+    };
+    // ---- counting sort by cell (any assignment of points to buckets gives the same samples; compact ones skip more)
+    for (int k = t; k < n; k += FB_TPB) atomicAdd(&s_hist[cell_of(k)], 1);
+    __syncthreads();
+    {
+        const int a = s_hist[2 * t], b = s_hist[2 * t + 1];
+        const int inc = wave_incl_scan(a + b);
+        if (l == 63) s_wsum[wv] = inc;
+        __syncthreads();
+        int base = 0;
+        for (int q = 0; q < wv; ++q) base += s_wsum[q];
+        s_hist[2 * t] = base + inc - a - b;
+        s_hist[2 * t + 1] = base + inc - b;
+    }
+    __syncthreads();
+    for (int k = t; k < n; k += FB_TPB) s_perm[atomicAdd(&s_hist[cell_of(k)], 1)] = (unsigned short)k;
+    __syncthreads();
+    // ---- registers: slot j of wave wv = bucket j * FB_W + wv, lane l = its l-th point
+    // coordinates: 3 x 16 register slots per axis; a wave-uniform slot number selects one with M0-relative register addressing
+    // (v_movrels), so the code below is the same for every bucket (40 specialised copies of it thrash the instruction cache)
+    fb_v16 PX0 = {}, PX1 = {}, PX2 = {}, PY0 = {}, PY1 = {}, PY2 = {}, PZ0 = {}, PZ1 = {}, PZ2 = {};
+    // bucket state, meaningful in lane j (< FB_S) for bucket j of this wave
+    float blx = 0.f, bly = 0.f, blz = 0.f, bhx = 0.f, bhy = 0.f, bhz = 0.f;    // bounding box
+    float bm = -1.0f, bcx = 0.f, bcy = 0.f, bcz = 0.f;                          // largest running distance, its point
+    int bk = 0x7fffffff;                                                        // ... and that point's tie key
+#pragma unroll
+    for (int j = 0; j < FB_S; ++j) {
+        const int rank = (j * FB_W + wv) * 64 + l;
+        const bool valid = rank < n;
+        const int k = valid ? (int)s_perm[rank] : 0;
+        const float qx = D[(size_t)k * 3], qy = D[(size_t)k * 3 + 1], qz = D[(size_t)k * 3 + 2];
+        FB_PUT(PX, j, qx); FB_PUT(PY, j, qy); FB_PUT(PZ, j, qz);
+        s_md[(j * FB_W + wv) * 64 + l] = valid ? T[k] : -1.0f;                   // lanes without a point never win
+        const float inf = 3.0e38f;
+        const float lx = fb_wave_min(valid ? qx : inf), ly = fb_wave_min(valid ? qy : inf), lz = fb_wave_min(valid ? qz : inf);
+        const float hx = fb_wave_max(valid ? qx : -inf), hy = fb_wave_max(valid ? qy : -inf), hz = fb_wave_max(valid ? qz : -inf);
+        const bool any = (j * FB_W + wv) * 64 < n;
+        if (l == j) {
+            blx = lx; bly = ly; blz = lz; bhx = hx; bhy = hy; bhz = hz;
+            bm = any ? 3.0e38f : -1.0f;                                          // "unknown, large": the first round visits it
+        }
+    }
+    float x1 = D[0], y1 = D[1], z1 = D[2];
+    if (t == 0) O[0] = 0;
+#ifdef FB_STATS
+    long long fb_nact = 0, fb_t[6] = {0, 0, 0, 0, 0, 0}, fb_c0 = clock64();
+#define FB_T(k) do { const long long c_ = clock64(); fb_t[k] += c_ - fb_c0; fb_c0 = c_; } while (0)
+#else
+#define FB_T(k) do { } while (0)
+#endif
+    for (int r = 1; r < m; ++r) {
+        // 1. which of my buckets can change?  (same expression shape as the point distance below)
+        const float gx = fmaxf(fmaxf(blx - x1, x1 - bhx), 0.f), gy = fmaxf(fmaxf(bly - y1, y1 - bhy), 0.f),
+                    gz = fmaxf(fmaxf(blz - z1, z1 - bhz), 0.f);
+        const float lb = gx * gx + gy * gy + gz * gz;
+        unsigned long long act = __ballot(l < FB_S && lb < bm);
+#ifdef FB_STATS
+        fb_nact += __popcll(act);
+#endif
+        FB_T(0);
+        // 2. update them (about one bucket per wave and round): new running distances, and the bucket's new maximum with the
+        // point that holds it.  The register slot is reached through a balanced tree of wave-uniform branches (fb_dispatch).
+        while (act) {                                                            // wave-uniform
+            const int j = __builtin_ctzll(act);
+            act &= act - 1ull;
+            const int base = (j * FB_W + wv) * 64;
+            const float old = s_md[base + l];
+            const int kpt = (int)s_perm[base + l];                               // (requested together with the distances)
+            const int hi = j >> 4, lo = j & 15;                                   // wave-uniform
+            const float qx = fb_pick(PX0, PX1, PX2, hi, lo), qy = fb_pick(PY0, PY1, PY2, hi, lo), qz = fb_pick(PZ0, PZ1, PZ2, hi, lo);
+            const float dx = qx - x1, dy = qy - y1, dz = qz - z1;
+            const float nd = fminf(dx * dx + dy * dy + dz * dz, old);
+            s_md[base + l] = nd;
+            const float vmax = fb_wave_max(nd);
+            const unsigned long long tie = __ballot(nd == vmax);
+            int wl = __builtin_ctzll(tie);
+            if (__builtin_expect(__popcll(tie) > 1, 0)) {                        // equal maxima: the reference's tie rule decides
+                float tv = (nd == vmax) ? 1.f : 0.f;
+                int tk = fb_tie_key(kpt, block_ref_mask);
+                const int mine = tk;
+                fb_wave_best(tv, tk);
+                wl = __builtin_ctzll(__ballot(nd == vmax && mine == tk));
+            }
+            const float cx = fb_rl(qx, wl), cy = fb_rl(qy, wl), cz = fb_rl(qz, wl);
+            const int key = fb_tie_key(__builtin_amdgcn_readlane(kpt, wl), block_ref_mask);
+            if (l == j) { bm = vmax; bk = key; bcx = cx; bcy = cy; bcz = cz; }
+        }
+        FB_T(1);
+        // 3. best bucket of this wave -> one LDS record per wave -> barrier -> every wave finishes from the FB_W records
+        // (reductions on the VALUE only; the tie key is looked at when two maxima coincide, which is rare)
+        const float v = fb_wave_max((l < FB_S) ? bm : -2.0f);
+        unsigned long long cand = __ballot(l < FB_S && bm == v);
+        int jl = __builtin_ctzll(cand);
+        int key = __builtin_amdgcn_readlane(bk, jl);
+        cand &= cand - 1ull;
+        while (__builtin_expect(cand != 0ull, 0)) {
+            const int j2 = __builtin_ctzll(cand);
+            cand &= cand - 1ull;
+            const int k2 = __builtin_amdgcn_readlane(bk, j2);
+            if (k2 < key) { key = k2; jl = j2; }
+        }
+        const int buf = r & 1;
+        if (l == 0) {
+            s_rec[buf][wv][0] = make_float4(v, __int_as_float(key), fb_rl(bcx, jl), fb_rl(bcy, jl));
+            s_rec[buf][wv][1].x = fb_rl(bcz, jl);
+        }
+        FB_T(2);
+        __syncthreads();
+        FB_T(3);
+        const float4 ra = s_rec[buf][l & (FB_W - 1)][0];
+        const float rz = s_rec[buf][l & (FB_W - 1)][1].x;
+        const float fv = fb_rl(fb_dpp_max_row(ra.x), 0);                          // every 16-lane row holds all FB_W records
+        unsigned long long wc = __ballot(l < FB_W && ra.x == fv);
+        int wq = __builtin_ctzll(wc);
+        int fk = __builtin_amdgcn_readlane(__float_as_int(ra.y), wq);
+        wc &= wc - 1ull;
+        while (__builtin_expect(wc != 0ull, 0)) {
+            const int w2 = __builtin_ctzll(wc);
+            wc &= wc - 1ull;
+            const int k2 = __builtin_amdgcn_readlane(__float_as_int(ra.y), w2);
+            if (k2 < fk) { fk = k2; wq = w2; }
+        }
+        x1 = fb_rl(ra.z, wq); y1 = fb_rl(ra.w, wq); z1 = fb_rl(rz, wq);
+        if (t == 0) O[r] = fk & 0x7FFF;
+        FB_T(4);
+    }
+#ifdef FB_STATS   // debug build: bucket-rounds visited by this wave -> temp[wave]; cycles per phase of wave 0 -> temp[16..20]
+    __syncthreads();
+    if (l == 0) T[wv] = (float)fb_nact;
+    if (t == 0) for (int q = 0; q < 5; ++q) T[16 + q] = (float)fb_t[q];
+    return;
+#endif
+#pragma unroll
+    for (int j = 0; j < FB_S; ++j) {
+        const int rank = (j * FB_W + wv) * 64 + l;
+        if (rank < n) T[s_perm[rank]] = s_md[rank];                               // the reference leaves the distances in temp
+    }
+}
+
 // generic fallback (any n): running distances stay in global memory, same tie rule
 __global__ __launch_bounds__(1024) void fps_generic_kernel(int n, int m, int block_ref, const float *__restrict__ data,
                                                            float *__restrict__ temp, int *__restrict__ idxs) {
@@ -489,6 +726,10 @@ LIDAR_EXPORT int lidar_furthest_point_sampling(int b, int n, int m, const float 
     int block_ref = 1;
     while (block_ref * 2 <= n && block_ref * 2 <= 1024) block_ref *= 2;
     const int items = divup(n, 1024);
+    if (n >= 4096 && n <= FB_CAP && m >= 64) {       // large samples: spatial buckets, most of every round is skipped
+        hipLaunchKernelGGL(fps_bucket_kernel, dim3(b), dim3(FB_TPB), 0, s, n, m, block_ref - 1, points, temp, idx);
+        return lidar_check_launch("lidar_furthest_point_sampling(bucket)");
+    }
 #define FPS_CASE(J, TPB) hipLaunchKernelGGL((fps_kernel<J, TPB>), dim3(b), dim3(TPB), (size_t)J * 1024 * sizeof(float), s, n, m, block_ref - 1, points, temp, idx)
     if (items <= 2) FPS_CASE(2, 1024);
     else if (items <= 4) FPS_CASE(4, 1024);

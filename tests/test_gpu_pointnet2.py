@@ -69,6 +69,25 @@ def test_furthest_point_sampling(dev, n, m):
     assert torch.equal(out, outb)
 
 
+@pytest.mark.parametrize("n,m", [(19968, 2048), (4096, 64), (20480, 300), (7001, 2500)])
+def test_furthest_point_sampling_bucketed_kernel(dev, n, m):
+    """The bucketed kernel (4 096 <= n <= 20 480: spatial buckets, rounds skip every bucket the new sample cannot change) must
+    give the reference's sample sequence bit for bit: KITTI-like ring clouds, a uniform cloud, a coarse lattice full of exact
+    ties (the tie rule), a cloud with thousands of DUPLICATED points (zero distances, ties at 0), and the running distances
+    left in `temp` must equal the oracle's as well."""
+    ring = np.concatenate([synth.cloud_ring(2000)[:, :3], synth.cloud_ring(2001)[:, :3]], 0)[:n]
+    if len(ring) < n:
+        ring = np.concatenate([ring, synth.cloud_ring(2002)[:n - len(ring), :3]], 0)
+    uni = synth.cloud_uniform(1000, n=n)[:, :3]
+    lattice = np.round(synth.cloud_uniform(1001, n=n)[:, :3] * 2) / 2
+    dup = synth.cloud_ring(2003)[:, :3][np.random.default_rng(5).integers(0, 3000, n)]
+    pts = np.stack([ring, uni, lattice, dup], 0).astype(np.float32)
+    out = sutils.furthest_point_sample(torch.from_numpy(pts).to(dev), m)
+    want = c_oracle.fps(pts, m)
+    for b, name in enumerate(("ring", "uniform", "lattice", "duplicates")):
+        assert np.array_equal(out[b].cpu().numpy(), want[b]), name
+
+
 def test_three_nn_and_interpolate_stack(dev):
     xyz, xc, new, nc = _stack_scene(7, sizes=(1200, 2, 900), msizes=(300, 2, 1))
     t = lambda a: torch.from_numpy(a).to(dev)
