@@ -232,11 +232,16 @@ int lidar_spconv_implicit_gemm_fused(const float *in_features, const int *nbr, i
  * rows with equal masks share MFMA tiles and offsets unused by a whole workgroup are skipped entirely.  Every output
  * still sums the same products in the same (offset) order: results are bit-identical to the table-order call. */
 int lidar_spconv_row_masks(const int *nbr, int n_out, int K, int *masks, void *stream);
-/* the argsort itself (csrc/mask_sort.hip): order[i] = table row visited i-th, masks ascending as K-bit unsigned numbers; rocPRIM
- * onesweep radix sort over the K significant bits (6 launches for K = 27; torch.argsort takes ~30 at these sizes).  No
- * reference counterpart: spconv 1.x has no row ordering (Appendix A.3 of SURVEY.md). */
-size_t lidar_spconv_mask_order_workspace_bytes(int n_out, int K);
-int lidar_spconv_mask_order(const int *masks, int n_out, int K, int *order, void *ws, size_t ws_bytes, void *stream);
+/* Row order for lidar_spconv_implicit_gemm_sorted WITHOUT a sort: every row finds its mask's group in an open-addressing table
+ * (a table holds only a few thousand distinct masks) and takes a rank in it; groups are laid out by their top 12 mask bits (measured:
+ * as good for the GEMM as a full sort), a row's position = first position of its group + its rank.  masks (n_out): bit k =
+ * nbr[row][k] >= 0; order (n_out): table row visited i-th — equal masks contiguous, groups ascending in their top 12 bits.
+ * 3 launches, no host sync.  The workspace keeps the table, which must be empty when a call starts (lidar_spconv_mask_group_init
+ * once per buffer; every call leaves it empty) and whose layout depends on the buffer size only: always pass the same (ws,
+ * ws_bytes) pair, sized for the largest table, and do not share one workspace between streams.  K <= 31. */
+size_t lidar_spconv_mask_group_workspace_bytes(int n_out);
+int lidar_spconv_mask_group_init(void *ws, size_t ws_bytes, void *stream);
+int lidar_spconv_mask_group(const int *nbr, int n_out, int K, int *masks, int *order, void *ws, size_t ws_bytes, void *stream);
 int lidar_spconv_sorted_gemm_supported(int K, int Cin, int Cout);
 int lidar_spconv_implicit_gemm_sorted(const float *in_features, const int *nbr, const int *row_mask, const int *order,
                                       int n_out, int K, int Cin, int Cout, const float *weight, const float *bias,

@@ -57,8 +57,9 @@ SIGNATURES = {
     "lidar_spconv_implicit_gemm": (i32, [vp, vp, i32, i32, i32, i32, vp, vp, vp, vp]),
     "lidar_spconv_implicit_gemm_fused": (i32, [vp, vp, i32, i32, i32, i32, vp, vp, vp, i32, vp, vp]),
     "lidar_spconv_row_masks": (i32, [vp, i32, i32, vp, vp]),
-    "lidar_spconv_mask_order_workspace_bytes": (sz, [i32, i32]),
-    "lidar_spconv_mask_order": (i32, [vp, i32, i32, vp, vp, sz, vp]),
+    "lidar_spconv_mask_group_workspace_bytes": (sz, [i32]),
+    "lidar_spconv_mask_group_init": (i32, [vp, sz, vp]),
+    "lidar_spconv_mask_group": (i32, [vp, i32, i32, vp, vp, vp, sz, vp]),
     "lidar_spconv_sorted_gemm_supported": (i32, [i32, i32, i32]),
     "lidar_spconv_implicit_gemm_sorted": (i32, [vp, vp, vp, vp, i32, i32, i32, i32, vp, vp, vp, i32, vp, vp]),
     "lidar_spconv_wgrad": (i32, [vp, vp, vp, i32, i32, i32, i32, vp, vp]),

@@ -759,6 +759,208 @@ LIDAR_EXPORT int lidar_spconv_row_masks(const int *nbr, int n_out, int K, int *m
     return lidar_check_launch("lidar_spconv_row_masks");
 }
 
+// ------------------------------------------------------------------ mask order without a sort
+// The mask-ordered GEMM needs the rows of a table grouped by their K-bit neighbour-offset mask, similar masks near each other.
+// Measured on the SECOND-KITTI tables (tools/mask_stats.py, tools/group_order_probe.py): 150-430 k rows hold only 8-25 k DISTINCT
+// masks; equal masks contiguous but groups in random order costs +26 % GEMM time against a full sort, while groups ordered by
+// their top 12 mask bits only (any order inside such a bin) is as fast as the full sort (2.09 vs 2.08 ms for the stack).
+// So no sort (rocPRIM onesweep took 6 launches and 130-150 us per table):
+//   1. every row finds / claims the slot of its mask in a plain open-addressing hash table and takes a rank inside that group
+//      (one wave-aggregated atomic per distinct mask of a wave); the group's 12-bit bin is counted on the side;
+//   2. every group adds its size to its bin's cursor (one atomic per GROUP) -> first position = scanned bin offset + that;
+//   3. position of a row = first position of its group + its rank: scatter.
+// 3 launches, no host sync.  Any grouping gives bit-identical GEMM results (each output row is summed by its own lane in fixed
+// offset order); the order inside a bin / a group depends on atomic timing and does not matter.
+#define MG_BINS 4096
+#define MG_BIN_BITS 12
+#define MG_EMPTY 0xFFFFFFFFu
+
+struct MgWs {
+    unsigned *keys;   // [capmax] distinct masks (MG_EMPTY = free); persistent: empty between calls
+    int *cnt;         // [capmax] rows per group; zero between calls
+    int *off;         // [capmax] first position of the group
+    int *bincnt;      // [MG_BINS] rows per 12-bit bin; zero between calls
+    int *bincur;      // [MG_BINS] running cursor inside the bin; zero between calls
+    int *rslot;       // [capmax / 2] slot of the row
+    int *rrank;       // [capmax / 2] rank of the row inside its group
+    size_t capmax;
+};
+
+static size_t mg_bytes(size_t capmax) { return 256 + 12 * capmax + 2 * MG_BINS * 4 + 8 * (capmax / 2) + 2048; }
+
+static size_t mg_cap_of(int n) {
+    size_t c = 1 << 16;
+    while (c < 2 * (size_t)(n > 0 ? n : 1)) c <<= 1;
+    return c;
+}
+
+// the layout is a function of the buffer size alone (the same for init and for every call on that buffer)
+static bool mg_carve(void *base, size_t ws_bytes, MgWs *w) {
+    size_t cap = 1 << 16;
+    if (mg_bytes(cap) > ws_bytes) return false;
+    while (mg_bytes(cap * 2) <= ws_bytes) cap <<= 1;
+    char *p = (char *)base + 256;
+    w->capmax = cap;
+    w->keys = (unsigned *)p; p += 4 * cap;
+    w->cnt = (int *)p; p += 4 * cap;
+    w->off = (int *)p; p += 4 * cap;
+    w->bincnt = (int *)p; p += 4 * MG_BINS;
+    w->bincur = (int *)p; p += 4 * MG_BINS;
+    p = (char *)base + align_up((size_t)(p - (char *)base), 256);
+    w->rslot = (int *)p; p += 4 * (cap / 2);
+    w->rrank = (int *)p;
+    return true;
+}
+
+__global__ void mg_init_kernel(MgWs w) {
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < w.capmax; i += (size_t)gridDim.x * blockDim.x) {
+        w.keys[i] = MG_EMPTY;
+        w.cnt[i] = 0;
+        if (i < MG_BINS) w.bincnt[i] = w.bincur[i] = 0;
+    }
+}
+
+__device__ __forceinline__ int mg_bin(unsigned m, int K) { return (int)(K > MG_BIN_BITS ? (m >> (K - MG_BIN_BITS)) : m); }
+
+// masks of 1024 consecutive rows (as sc_row_masks_kernel), then every row finds / claims the group of its mask and a rank in it.
+// Global atomics on a group / bin counter serialise at the L2 (~10 ns each on one address), and 40 % of a table's rows can carry
+// ONE mask: the rows of a workgroup therefore meet in an LDS table first (LDS atomics), and the workgroup touches each global
+// counter once per distinct mask it holds.
+#define MG_ROWS 1024
+#define MG_LSLOTS 2048
+__global__ __launch_bounds__(MG_ROWS) void mg_insert_kernel(const int *__restrict__ nbr, int n_out, int K, int *__restrict__ masks, MgWs w,
+                                                           int cap_shift) {
+    __shared__ unsigned s_mask[MG_ROWS];
+    __shared__ unsigned s_key[MG_LSLOTS];
+    __shared__ int s_cnt[MG_LSLOTS];
+    __shared__ int s_first[MG_LSLOTS];
+    __shared__ int s_gslot[MG_LSLOTS];
+    __shared__ int s_bin[MG_BINS];                                  // rows of this workgroup per 12-bit bin
+    const int t = threadIdx.x;
+    const long long row0 = (long long)blockIdx.x * MG_ROWS;
+    const int rows = (int)min((long long)MG_ROWS, (long long)n_out - row0);
+    s_mask[t] = 0u;
+    s_key[t] = s_key[t + MG_ROWS] = MG_EMPTY;
+    s_cnt[t] = s_cnt[t + MG_ROWS] = 0;
+    for (int q = t; q < MG_BINS; q += MG_ROWS) s_bin[q] = 0;
+    __syncthreads();
+    const int *base = nbr + row0 * K;
+    const int total = rows * K;
+    for (int i = t; i < total; i += MG_ROWS) {
+        const int r = i / K, k = i - r * K;
+        if (base[i] >= 0) atomicOr(&s_mask[r], 1u << k);
+    }
+    __syncthreads();
+    const bool valid = t < rows;
+    const unsigned m = s_mask[t];
+    int ls = 0, lrank = 0;
+    if (valid) {
+        masks[row0 + t] = (int)m;
+        ls = (int)((m * 2654435761u) >> (32 - 11));
+        for (;;) {                                                  // 1024 rows into 2048 slots: always terminates
+            const unsigned old = atomicCAS(&s_key[ls], MG_EMPTY, m);
+            if (old == MG_EMPTY || old == m) break;
+            ls = (ls + 1) & (MG_LSLOTS - 1);
+        }
+        lrank = atomicAdd(&s_cnt[ls], 1);
+    }
+    __syncthreads();
+    const unsigned capm = (1u << (32 - cap_shift)) - 1u;
+    for (int q = t; q < MG_LSLOTS; q += MG_ROWS) {                  // one global visit per distinct mask of the workgroup
+        const unsigned key = s_key[q];
+        if (key == MG_EMPTY) continue;
+        unsigned slot = (key * 2654435761u) >> cap_shift;
+        for (unsigned probe = 0; probe <= capm; ++probe) {
+            unsigned old = __hip_atomic_load(&w.keys[slot], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            if (old == MG_EMPTY) old = atomicCAS(&w.keys[slot], MG_EMPTY, key);
+            if (old == MG_EMPTY || old == key) break;
+            slot = (slot + 1u) & capm;
+        }
+        const int c = s_cnt[q];
+        s_gslot[q] = (int)slot;
+        s_first[q] = atomicAdd(&w.cnt[slot], c);
+        atomicAdd(&s_bin[mg_bin(key, K)], c);
+    }
+    __syncthreads();
+    for (int q = t; q < MG_BINS; q += MG_ROWS)
+        if (s_bin[q]) atomicAdd(&w.bincnt[q], s_bin[q]);            // once per bin this workgroup touches
+    if (valid) {
+        w.rslot[row0 + t] = s_gslot[ls];
+        w.rrank[row0 + t] = s_first[ls] + lrank;
+    }
+}
+
+// one thread per table slot: a group's first position = offset of its 12-bit bin (every workgroup scans the 4096 bin counts for
+// itself) + the bin's running cursor; the slot is left empty for the next call
+__global__ __launch_bounds__(1024) void mg_assign_kernel(MgWs w, int K, size_t cap) {
+    __shared__ int s_bin[MG_BINS];      // scanned bin offsets
+    __shared__ int s_cur[MG_BINS];      // rows of this workgroup's groups per bin -> the workgroup's base inside the bin
+    __shared__ int s_w[16];
+    const int t = threadIdx.x, l = t & 63, wv = t >> 6;
+    const int4 c = reinterpret_cast<const int4 *>(w.bincnt)[t];
+    const int mine = c.x + c.y + c.z + c.w;
+    const int inc = wave_incl_scan(mine);
+    if (l == 63) s_w[wv] = inc;
+    for (int q = t; q < MG_BINS; q += 1024) s_cur[q] = 0;
+    __syncthreads();
+    int o = inc - mine;
+    for (int k = 0; k < wv; ++k) o += s_w[k];
+    s_bin[4 * t] = o; s_bin[4 * t + 1] = o + c.x; s_bin[4 * t + 2] = o + c.x + c.y; s_bin[4 * t + 3] = o + c.x + c.y + c.z;
+    const size_t slot = (size_t)blockIdx.x * 1024 + t;
+    const int n = slot < cap ? w.cnt[slot] : 0;
+    int b = 0, loc = 0;
+    if (n > 0) {
+        b = mg_bin(w.keys[slot], K);
+        loc = atomicAdd(&s_cur[b], n);                              // LDS: place among this workgroup's groups of the bin
+    }
+    __syncthreads();
+    for (int q = t; q < MG_BINS; q += 1024) {                       // one global atomic per bin this workgroup touches
+        const int v = s_cur[q];
+        if (v) s_cur[q] = atomicAdd(&w.bincur[q], v);
+    }
+    __syncthreads();
+    if (n > 0) {
+        w.off[slot] = s_bin[b] + s_cur[b] + loc;
+        w.keys[slot] = MG_EMPTY;
+        w.cnt[slot] = 0;
+    }
+}
+
+__global__ void mg_scatter_kernel(int n_out, MgWs w, int *__restrict__ order) {
+    const int r = blockIdx.x * blockDim.x + threadIdx.x;
+    if (r < MG_BINS) w.bincnt[r] = w.bincur[r] = 0;                 // (nobody reads them in this launch)
+    if (r < n_out) order[w.off[w.rslot[r]] + w.rrank[r]] = r;
+}
+
+LIDAR_EXPORT size_t lidar_spconv_mask_group_workspace_bytes(int n_out) { return mg_bytes(mg_cap_of(n_out)); }
+
+// once per workspace (and after a failed call): the table must be empty when lidar_spconv_mask_group starts; it leaves it empty
+LIDAR_EXPORT int lidar_spconv_mask_group_init(void *ws, size_t ws_bytes, void *stream) {
+    MgWs w;
+    if (!ws || !mg_carve(ws, ws_bytes, &w)) return LIDAR_ERR_WORKSPACE;
+    hipLaunchKernelGGL(mg_init_kernel, dim3(512), dim3(1024), 0, (hipStream_t)stream, w);
+    return lidar_check_launch("lidar_spconv_mask_group_init");
+}
+
+// nbr (n_out, K <= 31) -> masks (n_out): bit k = nbr[row][k] >= 0; order (n_out): order[i] = table row visited i-th, rows with
+// equal masks contiguous, groups ordered by their top 12 mask bits
+LIDAR_EXPORT int lidar_spconv_mask_group(const int *nbr, int n_out, int K, int *masks, int *order, void *ws, size_t ws_bytes,
+                                         void *stream) {
+    if (n_out < 0 || K <= 0 || K > 31) return LIDAR_ERR_ARG;
+    if (n_out == 0) return LIDAR_OK;
+    if (!nbr || !masks || !order || !ws) return LIDAR_ERR_ARG;
+    MgWs w;
+    const size_t cap = mg_cap_of(n_out);
+    if (!mg_carve(ws, ws_bytes, &w) || cap > w.capmax) return LIDAR_ERR_WORKSPACE;
+    int lg = 0;
+    while (((size_t)1 << lg) < cap) ++lg;
+    hipStream_t s = (hipStream_t)stream;
+    hipLaunchKernelGGL(mg_insert_kernel, dim3(divup(n_out, MG_ROWS)), dim3(MG_ROWS), 0, s, nbr, n_out, K, masks, w, 32 - lg);
+    hipLaunchKernelGGL(mg_assign_kernel, dim3(divup((long long)cap, 1024)), dim3(1024), 0, s, w, K, cap);
+    hipLaunchKernelGGL(mg_scatter_kernel, dim3(divup(n_out > MG_BINS ? n_out : MG_BINS, 256)), dim3(256), 0, s, n_out, w, order);
+    return lidar_check_launch("lidar_spconv_mask_group");
+}
+
 // 1 when lidar_spconv_implicit_gemm_sorted can run this shape
 LIDAR_EXPORT int lidar_spconv_sorted_gemm_supported(int K, int Cin, int Cout) {
     return (K > 0 && K <= 32 && (Cout & 3) == 0 && Cout > 0 && Cout <= IG_MAX_C &&

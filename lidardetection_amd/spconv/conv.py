@@ -20,7 +20,7 @@ def _schedule_mask_order(datas, key, table):
     main = torch.cuda.current_stream(dev)
     side = _SIDE_STREAMS.get(dev)
     if side is None:
-        side = _SIDE_STREAMS[dev] = torch.cuda.Stream(dev)
+        side = _SIDE_STREAMS[dev] = torch.cuda.Stream(dev, priority=-1)        # short, latency-critical kernels: ahead of the GEMMs
     side.wait_stream(main)                      # the table is produced on the main stream
     table.record_stream(side)
     with torch.cuda.stream(side):

@@ -168,7 +168,8 @@ def run_stages_pipelined(stages, x):
     feat = torch.cuda.current_stream(dev)
     rb = _RULEBOOK_STREAMS.get(dev)
     if rb is None:
-        rb = _RULEBOOK_STREAMS[dev] = torch.cuda.Stream(dev)
+        rb = _RULEBOOK_STREAMS[dev] = torch.cuda.Stream(dev, priority=-1)     # the rulebook chain is the critical path of the forward: its
+                                                                            # short kernels must not queue behind the GEMM workgroups
     indices = x.indices if x.indices.dtype == torch.int32 else x.indices.int()
     indices = indices.contiguous()
     x.indices = indices

@@ -123,25 +123,34 @@ def sorted_gemm_supported(K, Cin, Cout):
     return K <= 31 and bool(_lib.lib().lidar_spconv_sorted_gemm_supported(K, Cin, Cout))
 
 
-_ORDER_VIA_TORCH = __import__("os").environ.get("LIDAR_MASK_ORDER_TORCH", "0") == "1"
+_MG_WS = {}
+
+
+def _mask_group_workspace(n, device):
+    """persistent workspace of lidar_spconv_mask_group for the CURRENT stream (its slot table must be empty between calls and two
+    streams must not share one): grown with headroom, initialised once per buffer"""
+    L = _lib.lib()
+    need = int(L.lidar_spconv_mask_group_workspace_bytes(n))
+    key = (str(device), int(_lib.stream().value or 0))
+    ws = _MG_WS.get(key)
+    if ws is None or ws.numel() < need:
+        ws = torch.empty(need + need // 4, dtype=torch.uint8, device=device)
+        _lib.check(L.lidar_spconv_mask_group_init(_lib.ptr(ws), ws.numel(), _lib.stream()), "lidar_spconv_mask_group_init")
+        _MG_WS[key] = ws
+    return ws
 
 
 def mask_order(nbr):
-    """(n_out, K <= 31) neighbour table -> (row offset bit masks, the row order that sorts them).  Visiting rows in that
-    order puts equal masks into the same MFMA tiles, so tiles stop multiplying padding rows and whole offsets drop out per
-    workgroup (include/lidar_hip.h: lidar_spconv_implicit_gemm_sorted)."""
+    """(n_out, K <= 31) neighbour table -> (row offset bit masks, a row order that groups equal masks, similar masks adjacent).
+    Visiting rows in that order puts equal masks into the same MFMA tiles, so tiles stop multiplying padding rows and whole
+    offsets drop out per workgroup (include/lidar_hip.h: lidar_spconv_mask_group, lidar_spconv_implicit_gemm_sorted)."""
     n_out, K = nbr.shape
     masks = torch.empty(n_out, dtype=torch.int32, device=nbr.device)
     order = torch.empty(n_out, dtype=torch.int32, device=nbr.device)
     if n_out:
-        L = _lib.lib()
-        _lib.check(L.lidar_spconv_row_masks(_lib.ptr(nbr), n_out, K, _lib.ptr(masks), _lib.stream()), "lidar_spconv_row_masks")
-        if _ORDER_VIA_TORCH:                    # A/B knob (LIDAR_MASK_ORDER_TORCH=1): torch.argsort instead of the C-ABI sort
-            return masks, torch.argsort(masks).int()
-        wsb = int(L.lidar_spconv_mask_order_workspace_bytes(n_out, K))
-        ws = torch.empty(wsb, dtype=torch.uint8, device=nbr.device)
-        _lib.check(L.lidar_spconv_mask_order(_lib.ptr(masks), n_out, K, _lib.ptr(order), _lib.ptr(ws), wsb, _lib.stream()),
-                   "lidar_spconv_mask_order")
+        ws = _mask_group_workspace(n_out, nbr.device)
+        _lib.check(_lib.lib().lidar_spconv_mask_group(_lib.ptr(nbr), n_out, K, _lib.ptr(masks), _lib.ptr(order), _lib.ptr(ws), ws.numel(),
+                                                      _lib.stream()), "lidar_spconv_mask_group")
     return masks, order
 
 
