@@ -216,6 +216,26 @@ int lidar_spconv_conv_outputs(const int *indices, int n, int batch, int D, int H
                               void *ws, size_t ws_bytes, void *stream);
 int lidar_spconv_conv_tables(int n, int kD, int kH, int kW, int sD, int sH, int sW, int num_out, int *nbr, int *nbr_t,
                              void *ws, size_t ws_bytes, void *stream);
+/* The same rulebooks through DENSE index grids (csrc/rulebook_grid.hip): one persistent (batch, D, H, W) int32 grid per resolution
+ * level, owned by the caller, every cell "empty" (0x7FFFFFFF) between uses; a coordinate lookup is one load instead of a hash probe
+ * sequence, and nothing is built or cleared per table.  Tables and output numbering are identical to the hash builder's.
+ *   lidar_spconv_grid_init     once per grid
+ *   lidar_spconv_grid_rows     mode 0: rows of a tensor -> grid (atomicMin: duplicates keep the lowest row); 1: the same cells
+ *                              back to empty; 2: plain store (output rows after lidar_spconv_grid_outputs); n_dev optional
+ *   lidar_spconv_grid_table    nbr (n_out, K): SubM (stride 1, padding k / 2, out_indices = the input rows) or regular forward
+ *   lidar_spconv_grid_table_t  nbr_t (n, K) of a regular convolution, from the OUTPUT level's grid
+ *   lidar_spconv_grid_outputs  unique output sites in first-touch order -> out_indices, *num_out (device); grid_out (empty on
+ *                              entry) is left holding candidate ids: follow with lidar_spconv_grid_rows(out_indices, mode 2) */
+int lidar_spconv_grid_init(int *grid, size_t cells, void *stream);
+int lidar_spconv_grid_rows(const int *indices, int n, const int *n_dev, int D, int H, int W, int *grid, int mode, void *stream);
+int lidar_spconv_grid_table(const int *out_indices, int n_out, int D, int H, int W, int kD, int kH, int kW, int sD, int sH, int sW,
+                            int pD, int pH, int pW, const int *grid_in, int *nbr, void *stream);
+int lidar_spconv_grid_table_t(const int *indices, int n, int D, int H, int W, int kD, int kH, int kW, int sD, int sH, int sW, int pD,
+                              int pH, int pW, const int *grid_out, int *nbr_t, void *stream);
+size_t lidar_spconv_grid_outputs_workspace_bytes(int n, int K);
+int lidar_spconv_grid_outputs(const int *indices, int n, int D, int H, int W, int kD, int kH, int kW, int sD, int sH, int sW, int pD,
+                              int pH, int pW, int *grid_out, int *out_indices, int *num_out, void *ws, size_t ws_bytes,
+                              void *stream);
 /* indice_conv forward (and input gradient with the transposed table + transposed weights):
  * out (n_out, Cout) = sum_k in[nbr[., k]] @ weight[k] (+ bias); weight (K, Cin, Cout); fp32 MFMA; Cin, Cout <= 128 */
 int lidar_spconv_implicit_gemm(const float *in_features, const int *nbr, int n_out, int K, int Cin, int Cout,

@@ -67,10 +67,10 @@ class SparseConvolution(SparseModule):
             return False
         return self.indice_key is None or self.indice_key not in indice_dict
 
-    def begin_rulebook(self, indices, spatial_shape, batch_size):
+    def begin_rulebook(self, indices, spatial_shape, batch_size, indice_dict=None):
         """regular (strided) conv only: start the output-site search early (ops.conv_rulebook_begin)"""
         assert not self.subm and not self.inverse and not self.conv1x1
-        return ops.conv_rulebook_begin(indices, batch_size, spatial_shape, self.kernel_size, self.stride, self.padding)
+        return ops.conv_rulebook_begin(indices, batch_size, spatial_shape, self.kernel_size, self.stride, self.padding, indice_dict)
 
     def build_rulebook(self, indices, spatial_shape, batch_size, indice_dict, pending=None):
         """Coordinate-only part of forward(): makes sure this layer's rulebook is in `indice_dict` and returns the
@@ -84,7 +84,7 @@ class SparseConvolution(SparseModule):
             return datas["in_indices"], datas["in_spatial_shape"]
         if self.subm:
             if datas is None:
-                nbr = ops.subm_rulebook(indices, spatial_shape, self.kernel_size)
+                nbr = ops.subm_rulebook(indices, spatial_shape, self.kernel_size, batch_size, indice_dict)
                 datas = {"subm": True, "nbr": nbr, "nbr_t": nbr, "in_indices": indices, "out_indices": indices,
                          "in_spatial_shape": spatial_shape, "out_spatial_shape": spatial_shape}
                 if self.indice_key is not None:
@@ -94,7 +94,7 @@ class SparseConvolution(SparseModule):
         out_shape = ops.get_conv_output_size(spatial_shape, self.kernel_size, self.stride, self.padding)
         if datas is None:
             if pending is None:
-                pending = self.begin_rulebook(indices, spatial_shape, batch_size)
+                pending = self.begin_rulebook(indices, spatial_shape, batch_size, indice_dict)
             out_indices, nbr, nbr_t = ops.conv_rulebook_finish(pending)
             datas = {"subm": False, "nbr": nbr, "nbr_t": nbr_t, "in_indices": indices, "out_indices": out_indices,
                      "in_spatial_shape": spatial_shape, "out_spatial_shape": out_shape}
@@ -127,7 +127,7 @@ class SparseConvolution(SparseModule):
             return indices, datas["in_indices"], datas["in_spatial_shape"], datas["nbr_t"], datas["nbr"], False, datas
         if self.subm:
             if datas is None:
-                nbr = ops.subm_rulebook(indices, spatial_shape, self.kernel_size)
+                nbr = ops.subm_rulebook(indices, spatial_shape, self.kernel_size, batch_size, input.indice_dict)
                 datas = {"subm": True, "nbr": nbr, "nbr_t": nbr, "in_indices": indices, "out_indices": indices,
                          "in_spatial_shape": spatial_shape, "out_spatial_shape": spatial_shape}
                 if self.indice_key is not None:
@@ -136,7 +136,7 @@ class SparseConvolution(SparseModule):
         out_shape = ops.get_conv_output_size(spatial_shape, self.kernel_size, self.stride, self.padding)
         if datas is None:
             out_indices, nbr, nbr_t = ops.conv_rulebook(indices, batch_size, spatial_shape, self.kernel_size, self.stride,
-                                                        self.padding)
+                                                        self.padding, input.indice_dict)
             datas = {"subm": False, "nbr": nbr, "nbr_t": nbr_t, "in_indices": indices, "out_indices": out_indices,
                      "in_spatial_shape": spatial_shape, "out_spatial_shape": out_shape}
             if self.indice_key is not None:

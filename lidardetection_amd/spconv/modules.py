@@ -129,7 +129,7 @@ def prebuild_rulebooks(module, indices, spatial_shape, batch_size, indice_dict, 
                 if nxt.conv1x1 or nxt.subm:
                     continue                      # stays on this level
                 if not nxt.inverse and nxt.needs_new_rulebook(indice_dict) and id(nxt) not in pending:
-                    pending[id(nxt)] = nxt.begin_rulebook(indices, spatial_shape, batch_size)
+                    pending[id(nxt)] = nxt.begin_rulebook(indices, spatial_shape, batch_size, indice_dict)
                 break
         indices, spatial_shape = conv.build_rulebook(indices, spatial_shape, batch_size, indice_dict, pending.pop(id(conv), None))
     return indices, spatial_shape
@@ -145,13 +145,15 @@ def _begin_first_strided(module, indices, spatial_shape, batch_size, indice_dict
             continue
         if conv.subm or conv.inverse or not conv.needs_new_rulebook(indice_dict) or indices.shape[0] == 0:
             return None
-        return {id(conv): conv.begin_rulebook(indices, spatial_shape, batch_size)}
+        return {id(conv): conv.begin_rulebook(indices, spatial_shape, batch_size, indice_dict)}
     return None
 
 
 def _hand_tables_to(stream, indice_dict):
     """tables are allocated on the rulebook stream and read on the feature stream: tell the caching allocator"""
-    for datas in indice_dict.values():
+    for name, datas in indice_dict.items():
+        if name == "__grid_token__":
+            continue
         for key in ("nbr", "nbr_t", "in_indices", "out_indices"):
             t = datas.get(key)
             if torch.is_tensor(t) and t.is_cuda:

@@ -22,22 +22,132 @@ def _hash_table(indices, spatial_shape):
     return table, cap
 
 
-def subm_rulebook(indices, spatial_shape, ksize):
-    """-> nbr (N, K) int32.  outputs == inputs."""
+# ---------------------------------------------------------------------------------------------- dense index grids
+class GridPool:
+    """Persistent (batch, D, H, W) int32 index grids, one per resolution level (csrc/rulebook_grid.hip): a coordinate lookup of
+    the rulebook builders is then one load instead of a hash probe sequence.  A grid is allocated and set to "empty" once, holds
+    the rows of ONE coordinate tensor at a time, and is wiped by revisiting exactly the cells that were written (the pool keeps
+    its own copy of those coordinates: the caller's tensor may be a reused buffer).  Which tensor a grid holds is tracked per
+    forward (`token`, kept in the rulebook dict), so a level's grid is scattered once and then serves the SubM table of the level,
+    the strided convolution leaving it and the one entering it.  Levels too large for the budget fall back to the hash builder."""
+    MAX_BYTES_PER_GRID = int(__import__("os").environ.get("LIDAR_SPCONV_GRID_MAX_GB", "8")) << 30
+    ENABLED = __import__("os").environ.get("LIDAR_SPCONV_GRID", "1") != "0"
+
+    def __init__(self):
+        self.grids = {}        # (device, B, D, H, W) -> [grid, held coords copy or None, n held, token, stream event]
+        self.counter = 0
+
+    def new_token(self):
+        self.counter += 1
+        return self.counter
+
+    def _entry(self, device, batch, shape):
+        key = (str(device), int(batch), *[int(v) for v in shape])
+        ent = self.grids.get(key)
+        if ent is None:
+            cells = int(batch) * int(shape[0]) * int(shape[1]) * int(shape[2])
+            if not self.ENABLED or cells * 4 > self.MAX_BYTES_PER_GRID or cells <= 0:
+                return None
+            grid = torch.empty(cells, dtype=torch.int32, device=device)
+            _lib.check(_lib.lib().lidar_spconv_grid_init(_lib.ptr(grid), cells, _lib.stream()), "lidar_spconv_grid_init")
+            ent = self.grids[key] = [grid, None, 0, None, None]
+        return ent
+
+    @staticmethod
+    def _join(ent):
+        """the grid may last have been touched on another stream (rulebook stream vs the caller's): order after it"""
+        if ent[4] is not None:
+            torch.cuda.current_stream(ent[0].device).wait_event(ent[4])
+
+    @staticmethod
+    def _mark(ent):
+        ev = torch.cuda.Event()
+        ev.record(torch.cuda.current_stream(ent[0].device))
+        ent[4] = ev
+        ent[0].record_stream(torch.cuda.current_stream(ent[0].device))
+
+    def _rows(self, ent, coords, n, shape, mode):
+        D, H, W = shape
+        _lib.check(_lib.lib().lidar_spconv_grid_rows(_lib.ptr(coords), n, None, D, H, W, _lib.ptr(ent[0]), mode, _lib.stream()),
+                   "lidar_spconv_grid_rows")
+
+    def _wipe(self, ent, shape):
+        if ent[1] is not None and ent[2] > 0:
+            self._rows(ent, ent[1], ent[2], shape, 1)
+        ent[1], ent[2], ent[3] = None, 0, None
+
+    def loaded(self, indices, batch, shape, token):
+        """-> the level's grid holding the rows of `indices` (scattered now unless this forward already did), or None"""
+        ent = self._entry(indices.device, batch, shape)
+        if ent is None:
+            return None
+        self._join(ent)
+        if ent[3] != (token, indices.data_ptr(), indices.shape[0]):
+            self._wipe(ent, shape)
+            keep = indices.clone()                                      # the cells written, for the wipe: never the caller's buffer
+            self._rows(ent, keep, keep.shape[0], shape, 0)
+            ent[1], ent[2], ent[3] = keep, keep.shape[0], (token, indices.data_ptr(), indices.shape[0])
+        self._mark(ent)
+        return ent[0]
+
+    def emptied(self, device, batch, shape):
+        ent = self._entry(device, batch, shape)
+        if ent is None:
+            return None
+        self._join(ent)
+        self._wipe(ent, shape)
+        self._mark(ent)
+        return ent
+
+    def adopt_outputs(self, ent, out_indices, shape, token):
+        """after lidar_spconv_grid_outputs: the grid holds candidate ids at exactly the cells of out_indices -> write the rows"""
+        self._join(ent)
+        self._rows(ent, out_indices, out_indices.shape[0], shape, 2)
+        ent[1], ent[2], ent[3] = out_indices, out_indices.shape[0], (token, out_indices.data_ptr(), out_indices.shape[0])
+        self._mark(ent)
+        return ent[0]
+
+
+GRIDS = GridPool()
+
+
+def _grid_token(indice_dict):
+    """one token per forward: lives in the rulebook dict that travels with the tensors"""
+    if indice_dict is None:
+        return GRIDS.new_token()
+    t = indice_dict.get("__grid_token__")
+    if t is None:
+        t = indice_dict["__grid_token__"] = {"token": GRIDS.new_token()}
+    return t["token"]
+
+
+def _geom_args(spatial_shape, ksize, stride, padding):
+    return [int(v) for v in (*spatial_shape, *ksize, *stride, *padding)]
+
+
+def subm_rulebook(indices, spatial_shape, ksize, batch_size=None, indice_dict=None):
+    """-> nbr (N, K) int32.  outputs == inputs.  With batch_size given the table is read off the level's dense index grid
+    (GridPool); otherwise (or when the grid would not fit the budget) a coordinate hash table is built for it."""
     _lib.require_cuda(indices)
     n = indices.shape[0]
     K = ksize[0] * ksize[1] * ksize[2]
     nbr = torch.empty((n, K), dtype=torch.int32, device=indices.device)
     if n == 0:
         return nbr
-    table, cap = _hash_table(indices, spatial_shape)
     D, H, W = spatial_shape
+    grid = GRIDS.loaded(indices, batch_size, spatial_shape, _grid_token(indice_dict)) if batch_size else None
+    if grid is not None:
+        pad = [k // 2 for k in ksize]
+        _lib.check(_lib.lib().lidar_spconv_grid_table(_lib.ptr(indices), n, *_geom_args(spatial_shape, ksize, (1, 1, 1), pad),
+                                                      _lib.ptr(grid), _lib.ptr(nbr), _lib.stream()), "lidar_spconv_grid_table")
+        return nbr
+    table, cap = _hash_table(indices, spatial_shape)
     _lib.check(_lib.lib().lidar_spconv_subm_table(_lib.ptr(indices), n, D, H, W, ksize[0], ksize[1], ksize[2], _lib.ptr(table), cap,
                                                   _lib.ptr(nbr), _lib.stream()), "lidar_spconv_subm_table")
     return nbr
 
 
-def conv_rulebook_begin(indices, batch_size, spatial_shape, ksize, stride, padding):
+def conv_rulebook_begin(indices, batch_size, spatial_shape, ksize, stride, padding, indice_dict=None):
     """Phase 1 of the SparseConv3d rulebook: enqueue the search for the unique output sites and an asynchronous copy of
     their count to pinned host memory.  Returns the pending state for conv_rulebook_finish; work enqueued on the stream
     after this call (e.g. the SubM table of the same level) overlaps the host's wait for the count."""
@@ -46,20 +156,33 @@ def conv_rulebook_begin(indices, batch_size, spatial_shape, ksize, stride, paddi
     n = indices.shape[0]
     K = ksize[0] * ksize[1] * ksize[2]
     dev = indices.device
-    st = {"n": n, "K": K, "dev": dev, "ksize": list(ksize), "stride": list(stride)}
+    st = {"n": n, "K": K, "dev": dev, "ksize": list(ksize), "stride": list(stride), "padding": list(padding), "indices": indices,
+          "shape": list(spatial_shape), "out_shape": get_conv_output_size(spatial_shape, ksize, stride, padding), "grid": None}
     if n == 0:
         return st
     bound = n
     for k, s in zip(ksize, stride):
         bound *= -(-k // s)
     bound = min(bound, n * K)
-    wsb = L.lidar_spconv_conv_table_workspace_bytes(n, *ksize, *stride)
-    ws = torch.empty(wsb, dtype=torch.uint8, device=dev)          # lives until finish (several rulebooks may be in flight)
     out_idx = torch.empty((bound, 4), dtype=torch.int32, device=dev)
     num = torch.empty((1,), dtype=torch.int32, device=dev)
     D, H, W = spatial_shape
-    _lib.check(L.lidar_spconv_conv_outputs(_lib.ptr(indices), n, batch_size, D, H, W, *ksize, *stride, *padding, _lib.ptr(out_idx), bound,
-                                           _lib.ptr(num), _lib.ptr(ws), wsb, _lib.stream()), "lidar_spconv_conv_outputs")
+    token = _grid_token(indice_dict)
+    gin = GRIDS.loaded(indices, batch_size, spatial_shape, token)
+    gout = GRIDS.emptied(dev, batch_size, st["out_shape"]) if gin is not None else None
+    if gin is not None and gout is not None and n * K <= 0x3FFFFFFF:
+        wsb = L.lidar_spconv_grid_outputs_workspace_bytes(n, K)
+        ws = torch.empty(wsb, dtype=torch.uint8, device=dev)
+        _lib.check(L.lidar_spconv_grid_outputs(_lib.ptr(indices), n, *_geom_args(spatial_shape, ksize, stride, padding), _lib.ptr(gout[0]),
+                                               _lib.ptr(out_idx), _lib.ptr(num), _lib.ptr(ws), wsb, _lib.stream()),
+                   "lidar_spconv_grid_outputs")
+        GridPool._mark(gout)
+        st.update(grid=(gin, gout, token, batch_size))
+    else:
+        wsb = L.lidar_spconv_conv_table_workspace_bytes(n, *ksize, *stride)
+        ws = torch.empty(wsb, dtype=torch.uint8, device=dev)          # lives until finish (several rulebooks may be in flight)
+        _lib.check(L.lidar_spconv_conv_outputs(_lib.ptr(indices), n, batch_size, D, H, W, *ksize, *stride, *padding, _lib.ptr(out_idx), bound,
+                                               _lib.ptr(num), _lib.ptr(ws), wsb, _lib.stream()), "lidar_spconv_conv_outputs")
     num_host = torch.empty((1,), dtype=torch.int32, pin_memory=True)
     num_host.copy_(num, non_blocking=True)
     ev = torch.cuda.Event()
@@ -78,14 +201,25 @@ def conv_rulebook_finish(st):
     n_out = int(st["num_host"][0])
     nbr = torch.empty((n_out, K), dtype=torch.int32, device=dev)
     nbr_t = torch.empty((n, K), dtype=torch.int32, device=dev)
-    _lib.check(_lib.lib().lidar_spconv_conv_tables(n, *st["ksize"], *st["stride"], n_out, _lib.ptr(nbr), _lib.ptr(nbr_t), _lib.ptr(st["ws"]),
-                                                   st["wsb"], _lib.stream()), "lidar_spconv_conv_tables")
-    return st["out_idx"][:n_out].clone(), nbr, nbr_t
+    out_indices = st["out_idx"][:n_out].clone()
+    L = _lib.lib()
+    if st["grid"] is not None:
+        gin, gout, token, _ = st["grid"]
+        geom = _geom_args(st["shape"], st["ksize"], st["stride"], st["padding"])
+        go = GRIDS.adopt_outputs(gout, out_indices, st["out_shape"], token)       # the output level's grid: rows instead of candidates
+        _lib.check(L.lidar_spconv_grid_table(_lib.ptr(out_indices), n_out, *geom, _lib.ptr(gin), _lib.ptr(nbr), _lib.stream()),
+                   "lidar_spconv_grid_table")
+        _lib.check(L.lidar_spconv_grid_table_t(_lib.ptr(st["indices"]), n, *geom, _lib.ptr(go), _lib.ptr(nbr_t), _lib.stream()),
+                   "lidar_spconv_grid_table_t")
+        return out_indices, nbr, nbr_t
+    _lib.check(L.lidar_spconv_conv_tables(n, *st["ksize"], *st["stride"], n_out, _lib.ptr(nbr), _lib.ptr(nbr_t), _lib.ptr(st["ws"]),
+                                          st["wsb"], _lib.stream()), "lidar_spconv_conv_tables")
+    return out_indices, nbr, nbr_t
 
 
-def conv_rulebook(indices, batch_size, spatial_shape, ksize, stride, padding):
+def conv_rulebook(indices, batch_size, spatial_shape, ksize, stride, padding, indice_dict=None):
     """-> out_indices (N_out, 4) int32, nbr (N_out, K), nbr_t (N_in, K).  One host read-back (N_out)."""
-    return conv_rulebook_finish(conv_rulebook_begin(indices, batch_size, spatial_shape, ksize, stride, padding))
+    return conv_rulebook_finish(conv_rulebook_begin(indices, batch_size, spatial_shape, ksize, stride, padding, indice_dict))
 
 
 def cached_mask_order(datas, key, table):

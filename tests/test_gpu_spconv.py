@@ -330,3 +330,50 @@ def test_input_layer_gemm(dev, cout, n_out, K, p_valid):
     full = ops.indice_conv_fused(f_d, nbr_d, w_d, b_d, r_d, True, None)
     np.testing.assert_allclose(full.cpu().double().numpy(), torch.relu(ref + b.double() + res.double()).numpy(), rtol=0, atol=1e-4)
     assert torch.equal(full, ops.indice_conv_fused(f_d, nbr_d, w_d, b_d, r_d, True, None))      # deterministic
+
+
+def test_dense_grid_rulebooks_equal_hash_rulebooks(dev):
+    """The dense-index-grid builder (csrc/rulebook_grid.hip through ops.GridPool) must produce the SAME tensors as the hash-table
+    builder — output sites in the same first-touch order, identical nbr / nbr_t / SubM tables — for every geometry the reference
+    uses (spconv_backbone.py:76-116), over several forwards through the same persistent grids: a coordinate BUFFER that is
+    overwritten in place between forwards (what a voxeliser's output buffer does), shrinking and growing site counts, duplicate
+    coordinates, and a budget too small for the grid (fallback to the hash builder)."""
+    from lidardetection_amd.spconv import ops
+    geoms = [([9, 14, 16], [3, 3, 3], [2, 2, 2], [1, 1, 1]), ([5, 12, 10], [3, 3, 3], [2, 2, 2], [0, 1, 1]),
+             ([11, 8, 8], [3, 1, 1], [2, 1, 1], [0, 0, 0]), ([41, 60, 52], [3, 3, 3], [2, 2, 2], [1, 1, 1])]
+    B = 3
+    for shape, ks, st, pd in geoms:
+        cells = B * shape[0] * shape[1] * shape[2]
+        buf = torch.zeros((int(0.3 * cells), 4), dtype=torch.int32, device=dev)         # reused coordinate buffer
+        for rnd, frac in enumerate((0.3, 0.05, 0.2)):
+            n = int(frac * cells)
+            idx = _sites(100 * rnd + shape[0], B, shape, n)
+            if rnd == 2:
+                idx[5] = idx[3]                                                          # a duplicated coordinate: lowest row wins
+            buf[:n] = torch.from_numpy(idx).to(dev)
+            coords = buf[:n]
+            res = {}
+            for mode in ("grid", "hash"):
+                ops.GridPool.ENABLED = mode == "grid"
+                try:
+                    d = {}
+                    sub = ops.subm_rulebook(coords, shape, [3, 3, 3], B, d)
+                    out_idx, nbr, nbr_t = ops.conv_rulebook(coords, B, shape, ks, st, pd, d)
+                    oshape = ops.get_conv_output_size(shape, ks, st, pd)
+                    sub2 = ops.subm_rulebook(out_idx, oshape, [3, 3, 3], B, d)           # the next level, off the grid the conv left
+                finally:
+                    ops.GridPool.ENABLED = True
+                res[mode] = (sub, out_idx, nbr, nbr_t, sub2)
+            for a, b, what in zip(res["grid"], res["hash"], ("subm table", "output sites", "nbr", "nbr_t", "next-level subm table")):
+                assert torch.equal(a, b), (shape, ks, rnd, what)
+    # a grid over the budget is not used (and nothing breaks)
+    keep = ops.GridPool.MAX_BYTES_PER_GRID
+    ops.GridPool.MAX_BYTES_PER_GRID = 1024
+    try:
+        shape = [7, 9, 11]
+        coords = torch.from_numpy(_sites(3, B, shape, 200)).to(dev)
+        assert ops.GRIDS._entry(dev, B, shape) is None
+        a = ops.subm_rulebook(coords, shape, [3, 3, 3], B, {})
+    finally:
+        ops.GridPool.MAX_BYTES_PER_GRID = keep
+    assert torch.equal(a, ops.subm_rulebook(coords, shape, [3, 3, 3], B, {}))

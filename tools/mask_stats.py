@@ -18,6 +18,8 @@ with torch.no_grad():
     out = m(bd)
     idict = out["encoded_spconv_tensor"].indice_dict
     for key, d in idict.items():
+        if key == "__grid_token__":
+            continue
         for name in ("nbr", "nbr_t"):
             t = d[name]
             if name == "nbr_t" and d["subm"]:
