@@ -20,6 +20,19 @@ struct PfnParams {
 
 // lane = output channel.  One wave walks voxels v = wave_global, wave_global + nwaves, ...
 // C and DIST are template parameters so that the weight registers wt[] are statically indexed.
+// The walk is software-pipelined: a voxel costs two DEPENDENT memory round trips (its point count, then the occupied slots that
+// count selects) and ~100 instructions, so a wave that waits for each voxel in turn is idle 95 % of the time (77 us for 256 k
+// pillars).  Here the count / coordinates of voxel i + 2 and the occupied slots of voxel i + 1 are in flight while voxel i is
+// computed; sums and broadcasts use DPP / readlane (no LDS round trips).
+// sum of lanes 0..31 (lanes >= 32 hold zero), wave-uniform result
+__device__ __forceinline__ float pfn_sum32(float v) {
+    v += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0xB1, 0xf, 0xf, true));    // lane ^ 1
+    v += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x4E, 0xf, 0xf, true));    // lane ^ 2
+    v += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x141, 0xf, 0xf, true));   // mirror within 8
+    v += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x140, 0xf, 0xf, true));   // mirror within 16
+    return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), 0)) + __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), 16));
+}
+
 template <int C, bool DIST>
 __global__ __launch_bounds__(256) void pfn_kernel(const float *__restrict__ voxels, const void *__restrict__ num_points,
                                                   const void *__restrict__ coords, const float *__restrict__ weight /*(cout,nfeat)*/,
@@ -37,49 +50,66 @@ __global__ __launch_bounds__(256) void pfn_kernel(const float *__restrict__ voxe
     for (int k = 0; k < NF; ++k) wt[k] = chan ? weight[l * NF + k] : 0.f;
     const float sc = chan ? scale[l] : 0.f, sh = chan ? shift[l] : 0.f;
     const float pad_val = fmaxf(sh, 0.f);  // a zeroed (padded) row: relu(0*scale + shift)
-    for (int v = wave; v < nv; v += nwaves) {
-        int n;
-        float cz, cy, cx;
-        if (p.num_are_float) n = (int)((const float *)num_points)[v];
-        else n = ((const int *)num_points)[v];
-        if (p.coords_are_float) {
-            const float4 c = ((const float4 *)coords)[v];
-            cz = c.y; cy = c.z; cx = c.w;
-        } else {
-            const int4 c = ((const int4 *)coords)[v];
-            cz = (float)c.y; cy = (float)c.z; cx = (float)c.w;
+    struct Head { int n; float cz, cy, cx; };
+    auto load_head = [&](int v) {          // wave-uniform addresses: scalar-ish broadcast loads
+        Head h = {0, 0.f, 0.f, 0.f};
+        if (v < nv) {
+            h.n = p.num_are_float ? (int)((const float *)num_points)[v] : ((const int *)num_points)[v];
+            if (p.coords_are_float) {
+                const float4 c = ((const float4 *)coords)[v];
+                h.cz = c.y; h.cy = c.z; h.cx = c.w;
+            } else {
+                const int4 c = ((const int4 *)coords)[v];
+                h.cz = (float)c.y; h.cy = (float)c.z; h.cx = (float)c.w;
+            }
+            h.n = min(max(h.n, 0), p.P);
         }
-        n = min(max(n, 0), p.P);
-        // lanes 0..n-1 hold one point each (P <= 64)
-        float pt[C];
+        return h;
+    };
+    struct Pts { float v[C]; };
+    auto load_pts = [&](int v, int n) {    // lanes 0..n-1 hold one point each (P <= 64); the rest zero
+        Pts t;
 #pragma unroll
-        for (int k = 0; k < C; ++k) pt[k] = 0.f;
-        if (l < n) {
+        for (int k = 0; k < C; ++k) t.v[k] = 0.f;
+        if (v < nv && l < n) {
             const float *q = voxels + ((size_t)v * p.P + l) * C;
             if (C == 4) {
-                const float4 t = *reinterpret_cast<const float4 *>(q);
-                pt[0] = t.x; pt[1] = t.y; pt[2] = t.z; pt[3 % C] = t.w;
+                const float4 u = *reinterpret_cast<const float4 *>(q);
+                t.v[0] = u.x; t.v[1] = u.y; t.v[2] = u.z; t.v[3 % C] = u.w;
             } else {
 #pragma unroll
-                for (int k = 0; k < C; ++k) pt[k] = q[k];
+                for (int k = 0; k < C; ++k) t.v[k] = q[k];
             }
         }
+        return t;
+    };
+    Head ha = load_head(wave), hb = load_head(wave + nwaves);
+    Pts pa = load_pts(wave, ha.n);
+    for (int v = wave; v < nv; v += nwaves) {
+        const Head hc = load_head(v + 2 * nwaves);          // two voxels ahead: its count is here when its slots are requested
+        const Pts pb = load_pts(v + nwaves, hb.n);           // one voxel ahead
+        const int n = ha.n;
         // mean over the real points == sum over the padded row / n (padded rows are zero)
-        float sx = pt[0], sy = pt[1], sz = pt[2];
+        float sx, sy, sz;
+        if (p.P <= 32) {
+            sx = pfn_sum32(pa.v[0]); sy = pfn_sum32(pa.v[1]); sz = pfn_sum32(pa.v[2]);
+        } else {
+            sx = pa.v[0]; sy = pa.v[1]; sz = pa.v[2];
 #pragma unroll
-        for (int d = 32; d >= 1; d >>= 1) {
-            sx += __shfl_xor(sx, d, 64);
-            sy += __shfl_xor(sy, d, 64);
-            sz += __shfl_xor(sz, d, 64);
+            for (int d = 32; d >= 1; d >>= 1) {
+                sx += __shfl_xor(sx, d, 64);
+                sy += __shfl_xor(sy, d, 64);
+                sz += __shfl_xor(sz, d, 64);
+            }
         }
         const float fn = (float)n;
         const float mx = sx / fn, my = sy / fn, mz = sz / fn;
-        const float ox = cx * p.vx + p.xo, oy = cy * p.vy + p.yo, oz = cz * p.vz + p.zo;
+        const float ox = ha.cx * p.vx + p.xo, oy = ha.cy * p.vy + p.yo, oz = ha.cz * p.vz + p.zo;
         float best = (n < p.P) ? pad_val : -INFINITY;
-        for (int q = 0; q < n; ++q) {
+        for (int q = 0; q < n; ++q) {                        // q is wave-uniform: v_readlane broadcasts
             float f[C];
 #pragma unroll
-            for (int k = 0; k < C; ++k) f[k] = __shfl(pt[k], q, 64);
+            for (int k = 0; k < C; ++k) f[k] = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(pa.v[k]), q));
             float acc = 0.f;
 #pragma unroll
             for (int k = 0; k < C; ++k) acc = fmaf(f[k], wt[k], acc);
@@ -93,6 +123,116 @@ __global__ __launch_bounds__(256) void pfn_kernel(const float *__restrict__ voxe
             best = fmaxf(best, fmaxf(fmaf(acc, sc, sh), 0.f));
         }
         if (chan) out[(size_t)v * p.cout + l] = best;
+        ha = hb; hb = hc; pa = pb;
+    }
+}
+
+// P <= 32: TWO voxels per wave iteration — lanes 0..31 hold the points of voxel A, lanes 32..63 those of voxel B, so the count /
+// coordinate loads, the slot loads, the DPP row sums and the mean / pillar-centre arithmetic are issued once for both; only the
+// (point, channel) FMA loop runs per voxel.  The kernel is bound by instruction issue (one wave per voxel, ~110 instructions for
+// 1-2 points), not by its 77 MB of traffic: sharing the per-voxel overhead is what pays.  Same expressions per voxel as pfn_kernel.
+template <int C, bool DIST>
+__global__ __launch_bounds__(256) void pfn_pair_kernel(const float *__restrict__ voxels, const void *__restrict__ num_points,
+                                                       const void *__restrict__ coords, const float *__restrict__ weight,
+                                                       const float *__restrict__ scale, const float *__restrict__ shift,
+                                                       const int *__restrict__ nvox_dev, int nvox_host, PfnParams p,
+                                                       float *__restrict__ out) {
+    constexpr int NF = C + 6 + (DIST ? 1 : 0);
+    const int l = lane_id(), half = l >> 5, pl = l & 31;
+    const int nv = nvox_dev ? min(*nvox_dev, nvox_host) : nvox_host;
+    const int wave = (blockIdx.x * 256 + threadIdx.x) >> 6;
+    const int nwaves = (gridDim.x * 256) >> 6;
+    const bool chan = l < p.cout;
+    float wt[NF];
+#pragma unroll
+    for (int k = 0; k < NF; ++k) wt[k] = chan ? weight[l * NF + k] : 0.f;
+    const float sc = chan ? scale[l] : 0.f, sh = chan ? shift[l] : 0.f;
+    const float pad_val = fmaxf(sh, 0.f);
+    struct Head { int n; float cz, cy, cx; };                  // per lane: the voxel of this lane's half
+    auto load_head = [&](int pair) {
+        const int v = 2 * pair + half;
+        Head h = {0, 0.f, 0.f, 0.f};
+        if (v < nv) {
+            h.n = p.num_are_float ? (int)((const float *)num_points)[v] : ((const int *)num_points)[v];
+            if (p.coords_are_float) {
+                const float4 c = ((const float4 *)coords)[v];
+                h.cz = c.y; h.cy = c.z; h.cx = c.w;
+            } else {
+                const int4 c = ((const int4 *)coords)[v];
+                h.cz = (float)c.y; h.cy = (float)c.z; h.cx = (float)c.w;
+            }
+            h.n = min(max(h.n, 0), p.P);
+        }
+        return h;
+    };
+    struct Pts { float v[C]; };
+    auto load_pts = [&](int pair, int n) {
+        const int v = 2 * pair + half;
+        Pts t;
+#pragma unroll
+        for (int k = 0; k < C; ++k) t.v[k] = 0.f;
+        if (v < nv && pl < n) {
+            const float *q = voxels + ((size_t)v * p.P + pl) * C;
+            if (C == 4) {
+                const float4 u = *reinterpret_cast<const float4 *>(q);
+                t.v[0] = u.x; t.v[1] = u.y; t.v[2] = u.z; t.v[3 % C] = u.w;
+            } else {
+#pragma unroll
+                for (int k = 0; k < C; ++k) t.v[k] = q[k];
+            }
+        }
+        return t;
+    };
+    auto row_sum16 = [](float v) {                              // sum of each 16-lane row, in all of its lanes
+        v += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0xB1, 0xf, 0xf, true));
+        v += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x4E, 0xf, 0xf, true));
+        v += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x141, 0xf, 0xf, true));
+        v += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x140, 0xf, 0xf, true));
+        return v;
+    };
+    auto rl = [](float v, int lane) { return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), lane)); };
+    const int npairs = (nv + 1) >> 1;
+    Head ha = load_head(wave), hb = load_head(wave + nwaves);
+    Pts pa = load_pts(wave, ha.n);
+    for (int pr = wave; pr < npairs; pr += nwaves) {
+        const Head hc = load_head(pr + 2 * nwaves);             // two pairs ahead: the counts are here when their slots are requested
+        const Pts pb = load_pts(pr + nwaves, hb.n);             // one pair ahead
+        // both voxels at once, on the lanes of their halves: sums -> means, pillar centre
+        const float rx = row_sum16(pa.v[0]), ry = row_sum16(pa.v[1]), rz = row_sum16(pa.v[2]);
+        const float hx = half ? rl(rx, 32) + rl(rx, 48) : rl(rx, 0) + rl(rx, 16);
+        const float hy = half ? rl(ry, 32) + rl(ry, 48) : rl(ry, 0) + rl(ry, 16);
+        const float hz = half ? rl(rz, 32) + rl(rz, 48) : rl(rz, 0) + rl(rz, 16);
+        const float fn = (float)ha.n;
+        const float vmx = hx / fn, vmy = hy / fn, vmz = hz / fn;
+        const float vox = ha.cx * p.vx + p.xo, voy = ha.cy * p.vy + p.yo, voz = ha.cz * p.vz + p.zo;
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+            const int v = 2 * pr + h;
+            if (v >= nv) break;                                  // wave-uniform
+            const int b0 = 32 * h;
+            const int n = __builtin_amdgcn_readlane(ha.n, b0);
+            const float mx = rl(vmx, b0), my = rl(vmy, b0), mz = rl(vmz, b0);
+            const float ox = rl(vox, b0), oy = rl(voy, b0), oz = rl(voz, b0);
+            float best = (n < p.P) ? pad_val : -INFINITY;
+            for (int q = 0; q < n; ++q) {                        // wave-uniform: v_readlane broadcasts
+                float f[C];
+#pragma unroll
+                for (int k = 0; k < C; ++k) f[k] = rl(pa.v[k], b0 + q);
+                float acc = 0.f;
+#pragma unroll
+                for (int k = 0; k < C; ++k) acc = fmaf(f[k], wt[k], acc);
+                acc = fmaf(f[0] - mx, wt[C + 0], acc);
+                acc = fmaf(f[1] - my, wt[C + 1], acc);
+                acc = fmaf(f[2] - mz, wt[C + 2], acc);
+                acc = fmaf(f[0] - ox, wt[C + 3], acc);
+                acc = fmaf(f[1] - oy, wt[C + 4], acc);
+                acc = fmaf(f[2] - oz, wt[C + 5], acc);
+                if (DIST) acc = fmaf(sqrtf(f[0] * f[0] + f[1] * f[1] + f[2] * f[2]), wt[NF - 1], acc);
+                best = fmaxf(best, fmaxf(fmaf(acc, sc, sh), 0.f));
+            }
+            if (chan) out[(size_t)v * p.cout + l] = best;
+        }
+        ha = hb; hb = hc; pa = pb;
     }
 }
 
@@ -100,6 +240,15 @@ template <int C>
 static void pfn_launch(int blocks, hipStream_t s, bool dist, const float *voxels, const void *num_points,
                        const void *coords, const float *weight, const float *scale, const float *shift,
                        const int *nvd, int nv, PfnParams p, float *out) {
+    if (p.P <= 32) {       // two voxels per wave iteration
+        if (dist)
+            hipLaunchKernelGGL((pfn_pair_kernel<C, true>), dim3(blocks), dim3(256), 0, s, voxels, num_points, coords, weight, scale,
+                               shift, nvd, nv, p, out);
+        else
+            hipLaunchKernelGGL((pfn_pair_kernel<C, false>), dim3(blocks), dim3(256), 0, s, voxels, num_points, coords, weight, scale,
+                               shift, nvd, nv, p, out);
+        return;
+    }
     if (dist)
         hipLaunchKernelGGL((pfn_kernel<C, true>), dim3(blocks), dim3(256), 0, s, voxels, num_points, coords, weight, scale,
                            shift, nvd, nv, p, out);

@@ -166,6 +166,37 @@ def test_pillar_vfe_vs_reference_golden(dev, golden_dir):
     np.testing.assert_allclose(mv.cpu().numpy(), g["mean_features"], rtol=0, atol=1e-6)
 
 
+@pytest.mark.parametrize("P,C,V,with_distance", [(32, 4, 1001, False), (20, 4, 77, True), (40, 5, 333, False), (32, 5, 1, True), (64, 4, 129, False)])
+def test_pillar_vfe_kernels_vs_oracle(dev, P, C, V, with_distance):
+    """both PFN kernels — two voxels per wave iteration (P <= 32) and one (P <= 64) — against the torch-CPU restatement of
+    PillarVFE / PFNLayer (oracle/pp_oracle.py, pinned by the reference golden above): odd voxel counts (a half-empty last pair),
+    full and single-point pillars, 5 point features, with_distance, a device-side voxel count smaller than the buffer; 1e-4."""
+    r = np.random.default_rng(P * 100 + C)
+    num = r.integers(1, P + 1, V).astype(np.int32)
+    num[:3] = [1, P, 2][:min(3, V)]
+    vox = np.zeros((V, P, C), np.float32)
+    coords = np.stack([r.integers(0, 2, V), np.zeros(V, np.int64), r.integers(0, 496, V), r.integers(0, 432, V)], 1).astype(np.int32)
+    for v in range(V):
+        ctr = np.array([coords[v, 3] * 0.16 + 0.08, coords[v, 2] * 0.16 - 39.6, -1.0] + [0.5] * (C - 3), np.float32)
+        vox[v, :num[v]] = ctr + r.normal(0, 0.05, (num[v], C)).astype(np.float32)
+    nf = C + 6 + int(with_distance)
+    w = (r.standard_normal((64, nf)) * 0.3).astype(np.float32)
+    gamma, beta = r.uniform(0.5, 1.5, 64).astype(np.float32), (r.standard_normal(64) * 0.2).astype(np.float32)
+    mean, var = (r.standard_normal(64) * 0.1).astype(np.float32), r.uniform(0.5, 1.5, 64).astype(np.float32)
+    t = lambda a: torch.from_numpy(a).to(dev)
+    scale, shift = pillar_ops.fold_bn(t(gamma), t(beta), t(mean), t(var), 1e-3)
+    pad = 5                                                               # rows past the device-side count must be ignored
+    voxd = torch.cat([t(vox), torch.full((pad, P, C), 7.0, device=dev)], 0)
+    numd = torch.cat([t(num), torch.full((pad,), P, dtype=torch.int32, device=dev)], 0)
+    cd = torch.cat([t(coords), torch.zeros((pad, 4), dtype=torch.int32, device=dev)], 0)
+    out = pillar_ops.pillar_vfe(voxd, numd, cd, t(w), scale, shift, synth.PP_VOXEL, synth.PP_RANGE, with_distance=with_distance,
+                                num_voxels_dev=torch.tensor([V], dtype=torch.int32, device=dev))
+    ref = pp_oracle.pillar_vfe(torch.from_numpy(vox), torch.from_numpy(num).float(), torch.from_numpy(coords).float(), torch.from_numpy(w),
+                               torch.from_numpy(gamma), torch.from_numpy(beta), torch.from_numpy(mean), torch.from_numpy(var),
+                               synth.PP_VOXEL, synth.PP_RANGE, eps=1e-3, with_distance=with_distance)
+    np.testing.assert_allclose(out[:V].cpu().numpy(), ref.numpy(), rtol=0, atol=1e-4)
+
+
 def test_pillar_scatter_vs_reference_golden(dev, golden_dir):
     g = np.load(os.path.join(golden_dir, "pp_modules.npz"))
     shp = tuple(int(x) for x in g["canvas_shape"])
