@@ -134,6 +134,8 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-frames", type=int, default=8)
     ap.add_argument("--no-extra", action="store_true", help="skip the SECOND / sparse-GEMM / NMS / PFN side measurements")
+    ap.add_argument("--no-full-rewrite", action="store_true", help="skip the extra steps that time the non-resident voxeliser path "
+                    "(profiles: keeps the per-kernel averages of the timed path unmixed)")
     ap.add_argument("--dry-run", action="store_true", help="N-rank plumbing only, CPU / gloo, no kernels (tests)")
     ap.add_argument("--stages", action="store_true", help="also print per-stage GPU times (stderr)")
     args = ap.parse_args()
@@ -195,7 +197,7 @@ def main():
     # the same bracket with the resident-output mode switched off (every call rewrites the whole padded buffer — what a caller
     # that hands over fresh buffers gets), measured inside full steps AFTER the timed region
     contract_ms = None
-    if getattr(model, "resident_voxels", False):
+    if getattr(model, "resident_voxels", False) and not args.no_full_rewrite:
         model.resident_voxels = False
         with torch.no_grad():
             evc = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(max(args.steps // 2, 5))]

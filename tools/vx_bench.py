@@ -16,6 +16,7 @@ ap.add_argument("--cloud", default="uniform")
 ap.add_argument("--iters", type=int, default=100)
 ap.add_argument("--batch", type=int, default=16)
 ap.add_argument("--algos", default="1,3,2")
+ap.add_argument("--resident", action="store_true", help="resident output buffer (include/lidar_hip.h algo 4)")
 ap.add_argument("--flush", action="store_true", help="stream 1 GiB through the caches before every call (the state the voxeliser "
                 "finds inside a detector step: points, workspace and output buffer in HBM, not in L2 / Infinity Cache)")
 a = ap.parse_args()
@@ -29,12 +30,12 @@ for algo in [int(x) for x in a.algos.split(",")]:
     vz = BatchVoxelizer(synth.PP_VOXEL, synth.PP_RANGE, 32, 16000, algo=algo)
     out = vz.alloc_outputs(a.batch, dev)
     for _ in range(5):
-        vz(pts, offs, max(sizes), out=out)
+        vz(pts, offs, max(sizes), out=out, resident=a.resident)
     torch.cuda.synchronize()
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     e0.record()
     for _ in range(a.iters):
-        vz(pts, offs, max(sizes), out=out)
+        vz(pts, offs, max(sizes), out=out, resident=a.resident)
     e1.record()
     torch.cuda.synchronize()
     ms = e0.elapsed_time(e1) / a.iters
@@ -44,12 +45,12 @@ for algo in [int(x) for x in a.algos.split(",")]:
         for k, (x0, x1) in enumerate(evs):
             junk.fill_(float(k))
             x0.record()
-            vz(pts, offs, max(sizes), out=out)
+            vz(pts, offs, max(sizes), out=out, resident=a.resident)
             x1.record()
         torch.cuda.synchronize()
         ms = float(np.median([x0.elapsed_time(x1) for x0, x1 in evs]))
         del junk
     rows = int(out["voxel_offsets"][-1])
     alg = 16 * sum(sizes) + rows * (32 * 4 * 4 + 20)
-    print(f"algo {algo} cloud {a.cloud}{' (cold caches, event bracket per call)' if a.flush else ''}: {ms*1e3:.1f} us/launch, rows {rows}, {alg/ms/1e6:.0f} GB/s algorithmic "
+    print(f"algo {algo}{' resident' if a.resident else ''} cloud {a.cloud}{' (cold caches, event bracket per call)' if a.flush else ''}: {ms*1e3:.1f} us/launch, rows {rows}, {alg/ms/1e6:.0f} GB/s algorithmic "
           f"({alg/ms/1e6/8000*100:.1f}% of 8 TB/s)")
