@@ -225,13 +225,21 @@ int lidar_spconv_conv_tables(int n, int kD, int kH, int kW, int sD, int sH, int 
  *   lidar_spconv_grid_table    nbr (n_out, K): SubM (stride 1, padding k / 2, out_indices = the input rows) or regular forward
  *   lidar_spconv_grid_table_t  nbr_t (n, K) of a regular convolution, from the OUTPUT level's grid
  *   lidar_spconv_grid_outputs  unique output sites in first-touch order -> out_indices, *num_out (device); grid_out (empty on
- *                              entry) is left holding candidate ids: follow with lidar_spconv_grid_rows(out_indices, mode 2) */
+ *                              entry) is left holding candidate ids: follow with lidar_spconv_grid_rows(out_indices, mode 2)
+ * Capacity-sized tensors (no host read-back of *num_out): a row whose batch index is negative is a PADDING row — no neighbours
+ * (tables hold -1), reaches no output, never scattered.  lidar_spconv_grid_pad_rows turns rows [min(*num_dev, cap), cap) of
+ * out_indices into padding rows; `limit` of the table builders = row count of the tensor the looked-up grid holds (grid values
+ * >= limit read as "no row"; <= 0: no limit), so a capacity that turns out too small yields wrong tables, never wild row ids.
+ *   lidar_spconv_transpose_table  nbr_t (n_in, K), pre-filled with -1 by the caller, from nbr (n_out, K) alone:
+ *                              nbr[j][k] == i  <=>  nbr_t[i][k] == j (equals grid_table_t when input coordinates are unique) */
 int lidar_spconv_grid_init(int *grid, size_t cells, void *stream);
 int lidar_spconv_grid_rows(const int *indices, int n, const int *n_dev, int D, int H, int W, int *grid, int mode, void *stream);
 int lidar_spconv_grid_table(const int *out_indices, int n_out, int D, int H, int W, int kD, int kH, int kW, int sD, int sH, int sW,
-                            int pD, int pH, int pW, const int *grid_in, int *nbr, void *stream);
+                            int pD, int pH, int pW, const int *grid_in, int limit, int *nbr, void *stream);
 int lidar_spconv_grid_table_t(const int *indices, int n, int D, int H, int W, int kD, int kH, int kW, int sD, int sH, int sW, int pD,
-                              int pH, int pW, const int *grid_out, int *nbr_t, void *stream);
+                              int pH, int pW, const int *grid_out, int limit, int *nbr_t, void *stream);
+int lidar_spconv_grid_pad_rows(int *out_indices, const int *num_dev, int cap, void *stream);
+int lidar_spconv_transpose_table(const int *nbr, int n_out, int K, int n_in, int *nbr_t, void *stream);
 size_t lidar_spconv_grid_outputs_workspace_bytes(int n, int K);
 int lidar_spconv_grid_outputs(const int *indices, int n, int D, int H, int W, int kD, int kH, int kW, int sD, int sH, int sW, int pD,
                               int pH, int pW, int *grid_out, int *out_indices, int *num_out, void *ws, size_t ws_bytes,

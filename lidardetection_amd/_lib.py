@@ -56,8 +56,10 @@ SIGNATURES = {
     "lidar_spconv_conv_tables": (i32, [i32, i32, i32, i32, i32, i32, i32, i32, vp, vp, vp, sz, vp]),
     "lidar_spconv_grid_init": (i32, [vp, sz, vp]),
     "lidar_spconv_grid_rows": (i32, [vp, i32, vp, i32, i32, i32, vp, i32, vp]),
-    "lidar_spconv_grid_table": (i32, [vp, i32, i32, i32, i32, i32, i32, i32, i32, i32, i32, i32, i32, i32, vp, vp, vp]),
-    "lidar_spconv_grid_table_t": (i32, [vp, i32, i32, i32, i32, i32, i32, i32, i32, i32, i32, i32, i32, i32, vp, vp, vp]),
+    "lidar_spconv_grid_table": (i32, [vp, i32, i32, i32, i32, i32, i32, i32, i32, i32, i32, i32, i32, i32, vp, i32, vp, vp]),
+    "lidar_spconv_grid_table_t": (i32, [vp, i32, i32, i32, i32, i32, i32, i32, i32, i32, i32, i32, i32, i32, vp, i32, vp, vp]),
+    "lidar_spconv_grid_pad_rows": (i32, [vp, vp, i32, vp]),
+    "lidar_spconv_transpose_table": (i32, [vp, i32, i32, i32, vp, vp]),
     "lidar_spconv_grid_outputs_workspace_bytes": (sz, [i32, i32]),
     "lidar_spconv_grid_outputs": (i32, [vp, i32, i32, i32, i32, i32, i32, i32, i32, i32, i32, i32, i32, i32, vp, vp, vp, vp, sz, vp]),
     "lidar_spconv_implicit_gemm": (i32, [vp, vp, i32, i32, i32, i32, vp, vp, vp, vp]),

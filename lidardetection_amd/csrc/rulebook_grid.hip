@@ -47,8 +47,10 @@ __global__ void rg_scatter_rows_kernel(const int *__restrict__ indices, int n, c
 }
 
 // forward table of a SubM or regular convolution, output-stationary: nbr[j][k] = row at input site o * s - p + k, or -1
+// A row whose batch index is negative is a PADDING row (capacity-sized tensors, see lidar_spconv_grid_pad_rows): it has no
+// neighbours, reaches no output and is never scattered.  limit: values >= it are not rows of the looked-up tensor (-> -1).
 __global__ void rg_table_kernel(const int *__restrict__ out_indices, int n_out, RgGeom g, const int *__restrict__ grid_in,
-                                int *__restrict__ nbr) {
+                                int limit, int *__restrict__ nbr) {
     const long long e = (long long)blockIdx.x * blockDim.x + threadIdx.x;
     if (e >= (long long)n_out * g.K) return;
     const int j = (int)(e / g.K), k = (int)(e - (long long)j * g.K);
@@ -56,9 +58,9 @@ __global__ void rg_table_kernel(const int *__restrict__ out_indices, int n_out, 
     const int4 c = reinterpret_cast<const int4 *>(out_indices)[j];
     const int z = c.y * g.sD - g.pD + kz, y = c.z * g.sH - g.pH + ky, x = c.w * g.sW - g.pW + kx;
     int r = -1;
-    if (z >= 0 && z < g.D && y >= 0 && y < g.H && x >= 0 && x < g.W) {
+    if (c.x >= 0 && z >= 0 && z < g.D && y >= 0 && y < g.H && x >= 0 && x < g.W) {
         const int v = grid_in[rg_cell(c.x, z, y, x, g.D, g.H, g.W)];
-        r = (v == RG_EMPTY) ? -1 : v;
+        r = (v >= limit) ? -1 : v;
     }
     nbr[e] = r;
 }
@@ -74,17 +76,33 @@ __device__ __forceinline__ bool rg_out_of(const RgGeom &g, int z, int y, int x, 
 
 // transposed table: nbr_t[i][k] = output row reached from input i through offset k, or -1
 __global__ void rg_table_t_kernel(const int *__restrict__ indices, int n, RgGeom g, const int *__restrict__ grid_out,
-                                  int *__restrict__ nbr_t) {
+                                  int limit, int *__restrict__ nbr_t) {
     const long long e = (long long)blockIdx.x * blockDim.x + threadIdx.x;
     if (e >= (long long)n * g.K) return;
     const int i = (int)(e / g.K), k = (int)(e - (long long)i * g.K);
     const int4 c = reinterpret_cast<const int4 *>(indices)[i];
     int oz, oy, ox, r = -1;
-    if (rg_out_of(g, c.y, c.z, c.w, k, oz, oy, ox)) {
+    if (c.x >= 0 && rg_out_of(g, c.y, c.z, c.w, k, oz, oy, ox)) {
         const int v = grid_out[rg_cell(c.x, oz, oy, ox, g.oD, g.oH, g.oW)];
-        r = (v == RG_EMPTY) ? -1 : v;
+        r = (v >= limit) ? -1 : v;
     }
     nbr_t[e] = r;
+}
+
+// the same table from the forward table alone (no grid): nbr[j][k] == i  <=>  nbr_t[i][k] == j.  nbr_t arrives filled with -1.
+__global__ void rg_transpose_table_kernel(const int *__restrict__ nbr, long long n_entries, int K, int n_in, int *__restrict__ nbr_t) {
+    const long long e = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (e >= n_entries) return;
+    const int i = nbr[e];
+    if (i < 0 || i >= n_in) return;
+    const int j = (int)(e / K), k = (int)(e - (long long)j * K);
+    nbr_t[(long long)i * K + k] = j;
+}
+
+// rows [min(*num, cap), cap) of a capacity-sized coordinate tensor -> padding rows (all -1)
+__global__ void rg_pad_rows_kernel(int *__restrict__ out_indices, const int *__restrict__ num, int cap) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < cap && i >= *num) reinterpret_cast<int4 *>(out_indices)[i] = make_int4(-1, -1, -1, -1);
 }
 
 // ---- unique output sites of a regular convolution, numbered in first-touch order of the (input row, offset) scan:
@@ -97,29 +115,35 @@ __global__ void rg_candidates_kernel(const int *__restrict__ indices, int n, RgG
     const int i = (int)(e / g.K), k = (int)(e - (long long)i * g.K);
     const int4 c = reinterpret_cast<const int4 *>(indices)[i];
     int oz, oy, ox;
-    if (rg_out_of(g, c.y, c.z, c.w, k, oz, oy, ox)) atomicMin(grid_out + rg_cell(c.x, oz, oy, ox, g.oD, g.oH, g.oW), (int)e);
+    if (c.x >= 0 && rg_out_of(g, c.y, c.z, c.w, k, oz, oy, ox)) atomicMin(grid_out + rg_cell(c.x, oz, oy, ox, g.oD, g.oH, g.oW), (int)e);
 }
 
 #define RG_TPB 1024
-__device__ __forceinline__ int rg_owner_flag(const int *__restrict__ indices, long long e, long long nc, const RgGeom &g,
-                                             const int *__restrict__ grid_out, int4 &oc) {
-    if (e >= nc) return 0;
+// does candidate e own its output cell?  (oc = that cell's coordinates when it is in bounds at all)
+__device__ __forceinline__ bool rg_candidate_cell(const int *__restrict__ indices, long long e, long long nc, const RgGeom &g, int4 &oc) {
+    if (e >= nc) return false;
     const int i = (int)(e / g.K), k = (int)(e - (long long)i * g.K);
     const int4 c = reinterpret_cast<const int4 *>(indices)[i];
     int oz, oy, ox;
-    if (!rg_out_of(g, c.y, c.z, c.w, k, oz, oy, ox)) return 0;
+    if (c.x < 0 || !rg_out_of(g, c.y, c.z, c.w, k, oz, oy, ox)) return false;
     oc = make_int4(c.x, oz, oy, ox);
-    return grid_out[rg_cell(c.x, oz, oy, ox, g.oD, g.oH, g.oW)] == (int)e;
+    return true;
 }
 
+// pass 2: owner flags (one ballot word per wave, kept for pass 4: no second random walk through the grid) + per-block counts
 __global__ __launch_bounds__(RG_TPB) void rg_count_kernel(const int *__restrict__ indices, int n, RgGeom g,
-                                                          const int *__restrict__ grid_out, int *__restrict__ block_sums) {
+                                                          const int *__restrict__ grid_out, int *__restrict__ block_sums,
+                                                          unsigned long long *__restrict__ owner_bits) {
     __shared__ int s_w[16];
     const long long e = (long long)blockIdx.x * RG_TPB + threadIdx.x;
     int4 oc;
-    const int f = rg_owner_flag(indices, e, (long long)n * g.K, g, grid_out, oc);
-    const int c = __popcll(__ballot(f));
-    if ((threadIdx.x & 63) == 0) s_w[threadIdx.x >> 6] = c;
+    bool f = rg_candidate_cell(indices, e, (long long)n * g.K, g, oc);
+    if (f) f = grid_out[rg_cell(oc.x, oc.y, oc.z, oc.w, g.oD, g.oH, g.oW)] == (int)e;
+    const unsigned long long bal = __ballot(f);
+    if ((threadIdx.x & 63) == 0) {
+        s_w[threadIdx.x >> 6] = __popcll(bal);
+        owner_bits[e >> 6] = bal;
+    }
     __syncthreads();
     if (threadIdx.x == 0) {
         int a = 0;
@@ -151,16 +175,16 @@ __global__ __launch_bounds__(1024) void rg_scan_sums_kernel(int *__restrict__ bl
 }
 
 __global__ __launch_bounds__(RG_TPB) void rg_assign_kernel(const int *__restrict__ indices, int n, RgGeom g,
-                                                           const int *__restrict__ grid_out, const int *__restrict__ block_sums,
-                                                           int *__restrict__ out_indices) {
+                                                           const unsigned long long *__restrict__ owner_bits,
+                                                           const int *__restrict__ block_sums, int *__restrict__ out_indices) {
     __shared__ int s_w[16];
     const long long e = (long long)blockIdx.x * RG_TPB + threadIdx.x;
-    int4 oc = make_int4(0, 0, 0, 0);
-    const int f = rg_owner_flag(indices, e, (long long)n * g.K, g, grid_out, oc);
-    const unsigned long long bal = __ballot(f);
+    const unsigned long long bal = owner_bits[e >> 6];
     if ((threadIdx.x & 63) == 0) s_w[threadIdx.x >> 6] = __popcll(bal);
     __syncthreads();
-    if (f) {
+    if ((bal >> (threadIdx.x & 63)) & 1ull) {
+        int4 oc = make_int4(0, 0, 0, 0);
+        rg_candidate_cell(indices, e, (long long)n * g.K, g, oc);
         int r = block_sums[blockIdx.x] + __popcll(bal & lanemask_lt());
         for (int k = 0; k < (int)(threadIdx.x >> 6); ++k) r += s_w[k];
         reinterpret_cast<int4 *>(out_indices)[r] = oc;
@@ -197,31 +221,33 @@ LIDAR_EXPORT int lidar_spconv_grid_rows(const int *indices, int n, const int *n_
 }
 
 // forward table: SubM (stride 1, padding k / 2, out_indices = the input rows) or regular convolution; grid_in = input level
+// limit: number of rows of the tensor held by grid_in (grid values >= it read as "no row"; pass INT_MAX-like 0x7FFFFFFF for none)
 LIDAR_EXPORT int lidar_spconv_grid_table(const int *out_indices, int n_out, int D, int H, int W, int kD, int kH, int kW, int sD,
-                                         int sH, int sW, int pD, int pH, int pW, const int *grid_in, int *nbr, void *stream) {
+                                         int sH, int sW, int pD, int pH, int pW, const int *grid_in, int limit, int *nbr, void *stream) {
     RgGeom g;
     if (n_out < 0 || !rg_geom(g, D, H, W, kD, kH, kW, sD, sH, sW, pD, pH, pW)) return LIDAR_ERR_ARG;
     if (n_out == 0) return LIDAR_OK;
     if (!out_indices || !grid_in || !nbr) return LIDAR_ERR_ARG;
     hipLaunchKernelGGL(rg_table_kernel, dim3(divup((long long)n_out * g.K, 256)), dim3(256), 0, (hipStream_t)stream, out_indices, n_out,
-                       g, grid_in, nbr);
+                       g, grid_in, limit > 0 ? limit : RG_EMPTY, nbr);
     return lidar_check_launch("lidar_spconv_grid_table");
 }
 
 // transposed table nbr_t (n, K) of a regular convolution; grid_out = output level (rows scattered)
 LIDAR_EXPORT int lidar_spconv_grid_table_t(const int *indices, int n, int D, int H, int W, int kD, int kH, int kW, int sD, int sH,
-                                           int sW, int pD, int pH, int pW, const int *grid_out, int *nbr_t, void *stream) {
+                                           int sW, int pD, int pH, int pW, const int *grid_out, int limit, int *nbr_t, void *stream) {
     RgGeom g;
     if (n < 0 || !rg_geom(g, D, H, W, kD, kH, kW, sD, sH, sW, pD, pH, pW)) return LIDAR_ERR_ARG;
     if (n == 0) return LIDAR_OK;
     if (!indices || !grid_out || !nbr_t) return LIDAR_ERR_ARG;
     hipLaunchKernelGGL(rg_table_t_kernel, dim3(divup((long long)n * g.K, 256)), dim3(256), 0, (hipStream_t)stream, indices, n, g,
-                       grid_out, nbr_t);
+                       grid_out, limit > 0 ? limit : RG_EMPTY, nbr_t);
     return lidar_check_launch("lidar_spconv_grid_table_t");
 }
 
 LIDAR_EXPORT size_t lidar_spconv_grid_outputs_workspace_bytes(int n, int K) {
-    return align_up(((size_t)(n > 0 ? n : 1) * (K > 0 ? K : 1) / RG_TPB + 2) * 4, 256) + 256;
+    const size_t nc = (size_t)(n > 0 ? n : 1) * (K > 0 ? K : 1);
+    return align_up((nc / RG_TPB + 2) * 4, 256) + align_up((nc / 64 + 16) * 8, 256) + 256;
 }
 
 // unique output sites of SparseConv3d: out_indices (>= n * prod ceil(k / s) rows, 4) in first-touch order, *num_out (device).
@@ -240,9 +266,32 @@ LIDAR_EXPORT int lidar_spconv_grid_outputs(const int *indices, int n, int D, int
     if (ws_bytes < lidar_spconv_grid_outputs_workspace_bytes(n, g.K)) return LIDAR_ERR_WORKSPACE;
     int *block_sums = (int *)ws;
     const int nblocks = divup(nc, RG_TPB);
+    unsigned long long *owner_bits = (unsigned long long *)((char *)ws + align_up(((size_t)nc / RG_TPB + 2) * 4, 256));
     hipLaunchKernelGGL(rg_candidates_kernel, dim3(divup(nc, 256)), dim3(256), 0, s, indices, n, g, grid_out);
-    hipLaunchKernelGGL(rg_count_kernel, dim3(nblocks), dim3(RG_TPB), 0, s, indices, n, g, grid_out, block_sums);
+    hipLaunchKernelGGL(rg_count_kernel, dim3(nblocks), dim3(RG_TPB), 0, s, indices, n, g, grid_out, block_sums, owner_bits);
     hipLaunchKernelGGL(rg_scan_sums_kernel, dim3(1), dim3(1024), 0, s, block_sums, nblocks, num_out);
-    hipLaunchKernelGGL(rg_assign_kernel, dim3(nblocks), dim3(RG_TPB), 0, s, indices, n, g, grid_out, block_sums, out_indices);
+    hipLaunchKernelGGL(rg_assign_kernel, dim3(nblocks), dim3(RG_TPB), 0, s, indices, n, g, owner_bits, block_sums, out_indices);
     return lidar_check_launch("lidar_spconv_grid_outputs");
+}
+
+// rows [min(*num_dev, cap), cap) of out_indices (cap, 4) -> padding rows (batch index -1): a capacity-sized coordinate tensor
+// whose true row count lives on the device.  Padding rows have no neighbours (tables hold -1), reach no output and are never
+// scattered into a grid, so every kernel of this file can run on the capacity without reading the count.
+LIDAR_EXPORT int lidar_spconv_grid_pad_rows(int *out_indices, const int *num_dev, int cap, void *stream) {
+    if (cap < 0) return LIDAR_ERR_ARG;
+    if (cap == 0) return LIDAR_OK;
+    if (!out_indices || !num_dev) return LIDAR_ERR_ARG;
+    hipLaunchKernelGGL(rg_pad_rows_kernel, dim3(divup(cap, 256)), dim3(256), 0, (hipStream_t)stream, out_indices, num_dev, cap);
+    return lidar_check_launch("lidar_spconv_grid_pad_rows");
+}
+
+// transposed table from the forward table: nbr (n_out, K) -> nbr_t (n_in, K), which the CALLER has filled with -1.
+// Equals lidar_spconv_grid_table_t / lidar_spconv_conv_tables' nbr_t when the input coordinates are unique.
+LIDAR_EXPORT int lidar_spconv_transpose_table(const int *nbr, int n_out, int K, int n_in, int *nbr_t, void *stream) {
+    if (n_out < 0 || n_in < 0 || K <= 0) return LIDAR_ERR_ARG;
+    if (n_out == 0 || n_in == 0) return LIDAR_OK;
+    if (!nbr || !nbr_t) return LIDAR_ERR_ARG;
+    const long long ne = (long long)n_out * K;
+    hipLaunchKernelGGL(rg_transpose_table_kernel, dim3(divup(ne, 256)), dim3(256), 0, (hipStream_t)stream, nbr, ne, K, n_in, nbr_t);
+    return lidar_check_launch("lidar_spconv_transpose_table");
 }

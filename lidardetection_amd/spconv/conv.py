@@ -95,7 +95,8 @@ class SparseConvolution(SparseModule):
         if datas is None:
             if pending is None:
                 pending = self.begin_rulebook(indices, spatial_shape, batch_size, indice_dict)
-            out_indices, nbr, nbr_t = ops.conv_rulebook_finish(pending)
+            out_indices, nbr, nbr_t = ops.conv_rulebook_finish(pending, indice_dict.get("__spec__"),
+                                                               need_t=not indice_dict.get("__inference__", False))
             datas = {"subm": False, "nbr": nbr, "nbr_t": nbr_t, "in_indices": indices, "out_indices": out_indices,
                      "in_spatial_shape": spatial_shape, "out_spatial_shape": out_shape}
             if self.indice_key is not None:
@@ -109,10 +110,11 @@ class SparseConvolution(SparseModule):
                 and ops.sorted_gemm_supported(datas["nbr"].shape[1], self.in_channels, self.out_channels)):
             _schedule_mask_order(datas, "order", datas["nbr"])
 
-    def _resolve(self, input):
+    def _resolve(self, input, need_bwd=True):
         """-> (indices, out_indices, out_shape, fwd_table, bwd_table, flip, datas) for this layer on `input` (rulebook built
         or fetched through indice_key); tables are None for a 1x1 convolution; datas = the rulebook dict used (returned,
-        not kept on the module: a module may be entered again before an earlier call has finished)."""
+        not kept on the module: a module may be entered again before an earlier call has finished).  need_bwd=False: the
+        caller will not read bwd_table (inference), so a transposed table the builder skipped is not made up now."""
         indices = input.indices
         spatial_shape, batch_size = input.spatial_shape, input.batch_size
         if indices.dtype != torch.int32:
@@ -124,7 +126,7 @@ class SparseConvolution(SparseModule):
         if self.inverse:
             assert datas is not None and self.indice_key is not None, "inverse conv needs the rulebook of its paired conv"
             assert datas["out_indices"].shape[0] == indices.shape[0], "inverse conv input does not match the paired conv's output"
-            return indices, datas["in_indices"], datas["in_spatial_shape"], datas["nbr_t"], datas["nbr"], False, datas
+            return indices, datas["in_indices"], datas["in_spatial_shape"], ops.ensure_table_t(datas), datas["nbr"], False, datas
         if self.subm:
             if datas is None:
                 nbr = ops.subm_rulebook(indices, spatial_shape, self.kernel_size, batch_size, input.indice_dict)
@@ -141,7 +143,7 @@ class SparseConvolution(SparseModule):
                      "in_spatial_shape": spatial_shape, "out_spatial_shape": out_shape}
             if self.indice_key is not None:
                 input.indice_dict[self.indice_key] = datas
-        return indices, datas["out_indices"], out_shape, datas["nbr"], datas["nbr_t"], False, datas
+        return indices, datas["out_indices"], out_shape, datas["nbr"], (ops.ensure_table_t(datas) if need_bwd else None), False, datas
 
     def forward(self, input):
         assert isinstance(input, SparseConvTensor)
@@ -183,7 +185,7 @@ class SparseConvolution(SparseModule):
         Equals the unfused module sequence to fp32 rounding (one re-associated multiply)."""
         assert isinstance(input, SparseConvTensor)
         assert bn is None or (not bn.training and bn.track_running_stats), "BatchNorm must be in eval mode to be folded"
-        indices, out_indices, out_shape, fwd_table, _, _, datas = self._resolve(input)
+        indices, out_indices, out_shape, fwd_table, _, _, datas = self._resolve(input, need_bwd=False)
         w, b = self._folded(bn)
         feats = input.features.detach().contiguous()
         if fwd_table is None:

@@ -4,6 +4,7 @@ from collections import OrderedDict
 import torch
 from torch import nn
 
+from . import ops
 from .tensor import SparseConvTensor
 
 
@@ -152,7 +153,7 @@ def _begin_first_strided(module, indices, spatial_shape, batch_size, indice_dict
 def _hand_tables_to(stream, indice_dict):
     """tables are allocated on the rulebook stream and read on the feature stream: tell the caching allocator"""
     for name, datas in indice_dict.items():
-        if name == "__grid_token__":
+        if name.startswith("__"):
             continue
         for key in ("nbr", "nbr_t", "in_indices", "out_indices"):
             t = datas.get(key)
@@ -160,7 +161,58 @@ def _hand_tables_to(stream, indice_dict):
                 t.record_stream(stream)
 
 
-def run_stages_pipelined(stages, x):
+def _trim_padding(outs, idict, true_rows):
+    """capacity-sized tensors of a finished forward -> exact ones (prefix views: padding rows sit at the tail)"""
+    def cut(t):
+        n = true_rows.get(t.data_ptr()) if torch.is_tensor(t) else None
+        return t if n is None or n >= t.shape[0] else t[:n]
+    for x in outs:
+        n = true_rows.get(x.indices.data_ptr())
+        if n is not None and n < x.indices.shape[0]:
+            x.features, x.indices = x.features[:n], x.indices[:n]
+    for name, datas in idict.items():
+        if name.startswith("__"):
+            continue
+        n_in, n_out = true_rows.get(datas["in_indices"].data_ptr()), true_rows.get(datas["out_indices"].data_ptr())
+        if n_in is None and n_out is None:
+            continue
+        if n_out is not None:
+            datas["nbr"] = datas["nbr"][:n_out]
+        if datas.get("nbr_t") is not None and n_in is not None:
+            datas["nbr_t"] = datas["nbr_t"][:n_in]
+        if datas["subm"]:
+            datas["nbr_t"] = datas["nbr"]
+        datas["in_indices"], datas["out_indices"] = cut(datas["in_indices"]), cut(datas["out_indices"])
+        datas.pop("order", None)                 # the row orders cover the padding rows too: recomputed if anyone asks again
+        datas.pop("order_t", None)
+
+
+def run_stages_pipelined(stages, x, speculate=True):
+    """Inference over a list of stages (modules run back to back): -> the output of every stage.
+    The rulebooks depend on coordinates alone, so stage s+1's tables are built on a second stream WHILE stage s's GEMMs run.
+    No host read-back happens inside the forward: tables of the strided convolutions are sized from what the same
+    convolution produced last time (ops._finish_speculative: capacity + padding rows), and the true output counts are checked
+    ONCE after the last launch has been enqueued; the outputs are then trimmed to their exact row counts.  A count that
+    exceeded its capacity (or a first call, which has no history) runs the exact path, one read-back per strided convolution."""
+    if speculate and ops.SPECULATE:
+        entry = (x.features, x.indices, dict(x.indice_dict))
+        spec = x.indice_dict["__spec__"] = ops.new_speculation()
+        x.indice_dict["__inference__"] = True
+        outs = _run_stages_pipelined(stages, x)
+        true_rows, over = ops.resolve_speculation(spec)
+        x.indice_dict.pop("__spec__", None)
+        if not over:
+            _trim_padding(outs, x.indice_dict, true_rows)
+            return outs
+        ops.GRIDS.reset()                        # candidate ids beyond a capacity are still in a grid: start from clean ones
+        x.features, x.indices = entry[0], entry[1]
+        x.indice_dict.clear()
+        x.indice_dict.update(entry[2])
+    x.indice_dict["__inference__"] = True
+    return _run_stages_pipelined(stages, x)
+
+
+def _run_stages_pipelined(stages, x):
     """Inference over a list of stages (modules run back to back): -> the output of every stage.
     The rulebooks depend on coordinates alone, so stage s+1's tables are built on a second stream WHILE stage s's GEMMs run:
     the host starts the next stage's output-site search, enqueues this stage's feature launches, and only then blocks on the

@@ -41,6 +41,11 @@ class GridPool:
         self.counter += 1
         return self.counter
 
+    def reset(self):
+        """forget every grid (a forward was abandoned half-way: cells may hold values nobody will wipe); new ones are
+        allocated and initialised on demand"""
+        self.grids.clear()
+
     def _entry(self, device, batch, shape):
         key = (str(device), int(batch), *[int(v) for v in shape])
         ent = self.grids.get(key)
@@ -139,7 +144,7 @@ def subm_rulebook(indices, spatial_shape, ksize, batch_size=None, indice_dict=No
     if grid is not None:
         pad = [k // 2 for k in ksize]
         _lib.check(_lib.lib().lidar_spconv_grid_table(_lib.ptr(indices), n, *_geom_args(spatial_shape, ksize, (1, 1, 1), pad),
-                                                      _lib.ptr(grid), _lib.ptr(nbr), _lib.stream()), "lidar_spconv_grid_table")
+                                                      _lib.ptr(grid), n, _lib.ptr(nbr), _lib.stream()), "lidar_spconv_grid_table")
         return nbr
     table, cap = _hash_table(indices, spatial_shape)
     _lib.check(_lib.lib().lidar_spconv_subm_table(_lib.ptr(indices), n, D, H, W, ksize[0], ksize[1], ksize[2], _lib.ptr(table), cap,
@@ -157,7 +162,8 @@ def conv_rulebook_begin(indices, batch_size, spatial_shape, ksize, stride, paddi
     K = ksize[0] * ksize[1] * ksize[2]
     dev = indices.device
     st = {"n": n, "K": K, "dev": dev, "ksize": list(ksize), "stride": list(stride), "padding": list(padding), "indices": indices,
-          "shape": list(spatial_shape), "out_shape": get_conv_output_size(spatial_shape, ksize, stride, padding), "grid": None}
+          "shape": list(spatial_shape), "out_shape": get_conv_output_size(spatial_shape, ksize, stride, padding), "grid": None,
+          "hint_key": (str(dev), int(batch_size), *_geom_args(spatial_shape, ksize, stride, padding))}
     if n == 0:
         return st
     bound = n
@@ -187,34 +193,119 @@ def conv_rulebook_begin(indices, batch_size, spatial_shape, ksize, stride, paddi
     num_host.copy_(num, non_blocking=True)
     ev = torch.cuda.Event()
     ev.record(torch.cuda.current_stream(dev))
-    st.update(ws=ws, wsb=wsb, out_idx=out_idx, num=num, num_host=num_host, ev=ev)
+    st.update(ws=ws, wsb=wsb, out_idx=out_idx, num=num, num_host=num_host, ev=ev, bound=bound)
     return st
 
 
-def conv_rulebook_finish(st):
-    """Phase 2: wait for the count only (not for later work on the stream), allocate and fill the tables."""
+# ---- capacity-sized rulebooks: no host read-back inside a forward ---------------------------------------------------------
+# The only thing the host ever needs from the output-site search is the NUMBER of output sites, to size the tables.  An
+# inference pipeline (modules.run_stages_pipelined) instead sizes them from what the same convolution produced last time
+# (outputs per input row, + headroom), marks the unused tail rows as padding rows on the device (batch index -1: no
+# neighbours, reach nothing, lidar_spconv_grid_pad_rows) and checks all counts ONCE at the end of the forward, when the GPU
+# still has the GEMMs to chew on.  A count above its capacity discards the forward and replays it on the exact path.
+_CAP_HINTS = {}              # geometry key -> output sites per input site seen last time
+CAP_HEADROOM, CAP_SLACK = 1.12, 2048
+SPECULATE = __import__("os").environ.get("LIDAR_SPCONV_SPECULATE", "1") != "0"
+
+
+def new_speculation():
+    """state of one forward: rows = {coords data_ptr: (estimated true rows, index of the pending count or None)}"""
+    return {"rows": {}, "pending": []}
+
+
+def _finish_speculative(st, spec, need_t):
+    hint = _CAP_HINTS.get(st["hint_key"])
+    if hint is None or st["grid"] is None:
+        return None
+    n, K, dev = st["n"], st["K"], st["dev"]
+    est_in, src = spec["rows"].get(st["indices"].data_ptr(), (float(n), None))
+    est_out = est_in * hint
+    cap = min(st["bound"], int(est_out * CAP_HEADROOM) + CAP_SLACK)
+    L = _lib.lib()
+    out_indices = st["out_idx"][:cap]                                   # a view of this rulebook's own buffer
+    _lib.check(L.lidar_spconv_grid_pad_rows(_lib.ptr(out_indices), _lib.ptr(st["num"]), cap, _lib.stream()), "lidar_spconv_grid_pad_rows")
+    gin, gout, token, _ = st["grid"]
+    geom = _geom_args(st["shape"], st["ksize"], st["stride"], st["padding"])
+    go = GRIDS.adopt_outputs(gout, out_indices, st["out_shape"], token)
+    nbr = torch.empty((cap, K), dtype=torch.int32, device=dev)
+    _lib.check(L.lidar_spconv_grid_table(_lib.ptr(out_indices), cap, *geom, _lib.ptr(gin), n, _lib.ptr(nbr), _lib.stream()),
+               "lidar_spconv_grid_table")
+    nbr_t = None
+    if need_t:
+        nbr_t = torch.empty((n, K), dtype=torch.int32, device=dev)
+        _lib.check(L.lidar_spconv_grid_table_t(_lib.ptr(st["indices"]), n, *geom, _lib.ptr(go), cap, _lib.ptr(nbr_t), _lib.stream()),
+                   "lidar_spconv_grid_table_t")
+    spec["pending"].append({"key": st["hint_key"], "num_host": st["num_host"], "ev": st["ev"], "cap": cap, "src": src, "n_in": n})
+    spec["rows"][out_indices.data_ptr()] = (est_out, len(spec["pending"]) - 1)
+    return out_indices, nbr, nbr_t
+
+
+def resolve_speculation(spec):
+    """Wait for the counts of this forward (one event: they are produced in order on one stream), refresh the hints.
+    -> (true row count per coords data_ptr, overflowed?)"""
+    pend = spec["pending"]
+    if not pend:
+        return {}, False
+    pend[-1]["ev"].synchronize()
+    over = False
+    for p in pend:
+        p["true"] = int(p["num_host"][0])
+        true_in = p["n_in"] if p["src"] is None else pend[p["src"]]["true"]
+        if true_in > 0:
+            _CAP_HINTS[p["key"]] = p["true"] / true_in
+        over = over or p["true"] > p["cap"]
+    return {ptr: pend[i]["true"] for ptr, (_, i) in spec["rows"].items() if i is not None}, over
+
+
+def conv_rulebook_finish(st, spec=None, need_t=True):
+    """Phase 2: allocate and fill the tables.  Exact path: wait for the count only (not for later work on the stream).
+    spec (new_speculation()): size by the capacity hint instead, no wait (see above); need_t=False: no transposed table
+    (inference never reads it; ensure_table_t builds it on demand)."""
     n, K, dev = st["n"], st["K"], st["dev"]
     if n == 0:
         return (torch.empty((0, 4), dtype=torch.int32, device=dev), torch.empty((0, K), dtype=torch.int32, device=dev),
                 torch.empty((0, K), dtype=torch.int32, device=dev))
+    if spec is not None and SPECULATE:
+        done = _finish_speculative(st, spec, need_t)
+        if done is not None:
+            return done
     st["ev"].synchronize()
     n_out = int(st["num_host"][0])
+    src = spec["rows"].get(st["indices"].data_ptr()) if spec is not None else None
+    true_in = n if src is None or src[1] is None else int(spec["pending"][src[1]]["num_host"][0])     # an earlier count of this stream
+    if true_in > 0:
+        _CAP_HINTS[st["hint_key"]] = n_out / true_in
     nbr = torch.empty((n_out, K), dtype=torch.int32, device=dev)
-    nbr_t = torch.empty((n, K), dtype=torch.int32, device=dev)
+    nbr_t = torch.empty((n, K), dtype=torch.int32, device=dev) if need_t else None
     out_indices = st["out_idx"][:n_out].clone()
     L = _lib.lib()
     if st["grid"] is not None:
         gin, gout, token, _ = st["grid"]
         geom = _geom_args(st["shape"], st["ksize"], st["stride"], st["padding"])
         go = GRIDS.adopt_outputs(gout, out_indices, st["out_shape"], token)       # the output level's grid: rows instead of candidates
-        _lib.check(L.lidar_spconv_grid_table(_lib.ptr(out_indices), n_out, *geom, _lib.ptr(gin), _lib.ptr(nbr), _lib.stream()),
+        _lib.check(L.lidar_spconv_grid_table(_lib.ptr(out_indices), n_out, *geom, _lib.ptr(gin), n, _lib.ptr(nbr), _lib.stream()),
                    "lidar_spconv_grid_table")
-        _lib.check(L.lidar_spconv_grid_table_t(_lib.ptr(st["indices"]), n, *geom, _lib.ptr(go), _lib.ptr(nbr_t), _lib.stream()),
-                   "lidar_spconv_grid_table_t")
+        if need_t:
+            _lib.check(L.lidar_spconv_grid_table_t(_lib.ptr(st["indices"]), n, *geom, _lib.ptr(go), n_out, _lib.ptr(nbr_t), _lib.stream()),
+                       "lidar_spconv_grid_table_t")
         return out_indices, nbr, nbr_t
+    if nbr_t is None:
+        nbr_t = torch.empty((n, K), dtype=torch.int32, device=dev)                # the hash builder fills both in one pass
     _lib.check(L.lidar_spconv_conv_tables(n, *st["ksize"], *st["stride"], n_out, _lib.ptr(nbr), _lib.ptr(nbr_t), _lib.ptr(st["ws"]),
                                           st["wsb"], _lib.stream()), "lidar_spconv_conv_tables")
     return out_indices, nbr, nbr_t
+
+
+def ensure_table_t(datas):
+    """the transposed table of a regular convolution's rulebook, built from the forward table when the builder skipped it"""
+    if datas.get("nbr_t") is None:
+        nbr = datas["nbr"]
+        n_in, K = datas["in_indices"].shape[0], nbr.shape[1]
+        nbr_t = torch.full((n_in, K), -1, dtype=torch.int32, device=nbr.device)
+        _lib.check(_lib.lib().lidar_spconv_transpose_table(_lib.ptr(nbr), nbr.shape[0], K, n_in, _lib.ptr(nbr_t), _lib.stream()),
+                   "lidar_spconv_transpose_table")
+        datas["nbr_t"] = nbr_t
+    return datas["nbr_t"]
 
 
 def conv_rulebook(indices, batch_size, spatial_shape, ksize, stride, padding, indice_dict=None):

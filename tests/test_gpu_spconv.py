@@ -377,3 +377,92 @@ def test_dense_grid_rulebooks_equal_hash_rulebooks(dev):
     finally:
         ops.GridPool.MAX_BYTES_PER_GRID = keep
     assert torch.equal(a, ops.subm_rulebook(coords, shape, [3, 3, 3], B, {}))
+
+
+def test_padding_rows_and_transposed_table(dev):
+    """Capacity-sized coordinate tensors (csrc/rulebook_grid.hip): rows with batch index -1 appended to a tensor change nothing
+    for the real rows (same SubM table, same output sites in the same order, same nbr / nbr_t) and have no neighbours themselves;
+    lidar_spconv_transpose_table rebuilds nbr_t from nbr alone."""
+    from lidardetection_amd import _lib
+    from lidardetection_amd.spconv import ops
+    B, shape, ks, st, pd = 2, [9, 14, 16], [3, 3, 3], [2, 2, 2], [1, 1, 1]
+    n = 900
+    coords = torch.from_numpy(_sites(5, B, shape, n)).to(dev)
+    padded = torch.cat([coords, torch.full((137, 4), -1, dtype=torch.int32, device=dev)])
+    d0, d1 = {}, {}
+    sub0 = ops.subm_rulebook(coords, shape, [3, 3, 3], B, d0)
+    out0, nbr0, nbrt0 = ops.conv_rulebook(coords, B, shape, ks, st, pd, d0)
+    sub1 = ops.subm_rulebook(padded, shape, [3, 3, 3], B, d1)
+    out1, nbr1, nbrt1 = ops.conv_rulebook(padded, B, shape, ks, st, pd, d1)
+    assert torch.equal(sub1[:n], sub0) and bool((sub1[n:] == -1).all())
+    assert torch.equal(out1, out0) and torch.equal(nbr1, nbr0)
+    assert torch.equal(nbrt1[:n], nbrt0) and bool((nbrt1[n:] == -1).all())
+    datas = {"nbr": nbr0, "nbr_t": None, "in_indices": coords}
+    assert torch.equal(ops.ensure_table_t(datas), nbrt0)
+    # pad_rows: rows beyond the device count become padding rows, the others stay
+    buf = coords.clone()
+    num = torch.tensor([700], dtype=torch.int32, device=dev)
+    _lib.check(_lib.lib().lidar_spconv_grid_pad_rows(_lib.ptr(buf), _lib.ptr(num), n, _lib.stream()), "pad")
+    assert torch.equal(buf[:700], coords[:700]) and bool((buf[700:] == -1).all())
+
+
+def test_speculative_capacity_forward_is_exact_and_recovers_from_overflow(dev):
+    """run_stages_pipelined without host read-backs (capacity-sized tables + padding rows, counts checked once at the end):
+    every stage output equals the exact path bit for bit; a capacity that turns out too small (hints shrunk by hand) is
+    detected, the forward is replayed on the exact path, and the persistent grids are clean afterwards."""
+    from lidardetection_amd import pillar_ops, spconv, synth
+    from lidardetection_amd.pcdet.models.backbones_3d import spconv_backbone
+    from lidardetection_amd.pcdet.utils.cfg import AttrDict
+    from lidardetection_amd.spconv import ops
+    from lidardetection_amd.voxelizer import BatchVoxelizer
+    vox = BatchVoxelizer(synth.SEC_VOXEL, synth.SEC_RANGE, 5, 16000)
+    torch.manual_seed(3)
+    m = spconv_backbone.VoxelBackBone8x(AttrDict(), 4, [1408, 1600, 40]).to(dev).eval()
+    stages = [getattr(m, nm) for nm in ("conv_input", "conv1", "conv2", "conv3", "conv4", "conv_out")]
+
+    def inputs(seed, nf):
+        o = vox.voxelize_frames([synth.cloud_ring(seed + f) for f in range(nf)], device=dev)
+        return pillar_ops.mean_vfe(o["voxels"], o["voxel_num_points"]), o["voxel_coords"].int()
+
+    def run(feats, coords, nf, speculate):
+        with torch.no_grad():
+            x = spconv.SparseConvTensor(feats, coords, m.sparse_shape, nf)
+            outs = spconv.run_stages_pipelined(stages, x, speculate=speculate)
+        return outs, x.indice_dict
+
+    def same(got, want):
+        for a, b in zip(got[0], want[0]):
+            assert torch.equal(a.indices, b.indices) and torch.equal(a.features, b.features)
+        for key, d in want[1].items():
+            if key.startswith("__"):
+                continue
+            assert torch.equal(got[1][key]["nbr"], d["nbr"]) and torch.equal(got[1][key]["out_indices"], d["out_indices"])
+
+    used = []
+    orig = ops._finish_speculative
+    ops._finish_speculative = lambda *a: (used.append(1), orig(*a))[1]
+    try:
+        ops._CAP_HINTS.clear()
+        fa, ca = inputs(4000, 3)
+        want_a = run(fa, ca, 3, False)
+        assert not used and ops._CAP_HINTS                    # the exact path leaves hints behind
+        same(run(fa, ca, 3, True), want_a)
+        assert len(used) == 4                                 # four strided convolutions, none waited for
+        fb, cb = inputs(5000, 3)                              # other clouds through the same hints and grids
+        want_b = run(fb, cb, 3, False)
+        same(run(fb, cb, 3, True), want_b)
+        for k in list(ops._CAP_HINTS):
+            ops._CAP_HINTS[k] *= 0.25                         # capacities far too small: must be noticed and replayed
+        same(run(fa, ca, 3, True), want_a)
+        same(run(fb, cb, 3, True), want_b)                    # hints re-learnt, grids clean
+        same(run(fa, ca, 3, True), want_a)
+        # the transposed table an inference forward skipped is produced on demand and equals the builder's
+        got = run(fa, ca, 3, True)
+        full = {}
+        spconv.prebuild_rulebooks(stages, ca.contiguous(), m.sparse_shape, 3, full)
+        for key, d in full.items():
+            if not key.startswith("__") and not d["subm"]:
+                assert got[1][key]["nbr_t"] is None and torch.equal(got[1][key]["nbr"], d["nbr"])
+                assert torch.equal(ops.ensure_table_t(dict(got[1][key])), d["nbr_t"])
+    finally:
+        ops._finish_speculative = orig
