@@ -15,20 +15,20 @@ _SIDE_STREAMS = {}
 
 def _schedule_mask_order(datas, key, table):
     """Inference: compute the mask order of a freshly built table on a side stream (tiny, latency-bound kernels) so it
-    overlaps the remaining rulebook builds; consumers wait on the recorded event (forward_fused)."""
+    overlaps the remaining rulebook builds; consumers wait on the recorded event (forward_fused).  The outputs are allocated
+    on the current stream and the kernels handed the side stream's raw handle (no stream switch on the host)."""
     dev = table.device
     main = torch.cuda.current_stream(dev)
     side = _SIDE_STREAMS.get(dev)
     if side is None:
         side = _SIDE_STREAMS[dev] = torch.cuda.Stream(dev, priority=-1)        # short, latency-critical kernels: ahead of the GEMMs
     side.wait_stream(main)                      # the table is produced on the main stream
-    table.record_stream(side)
-    with torch.cuda.stream(side):
-        masks, perm = ops.mask_order(table)
+    import ctypes
+    masks, perm = ops.mask_order(table, ctypes.c_void_p(side.cuda_stream))
     ev = torch.cuda.Event()
     ev.record(side)
-    masks.record_stream(main)
-    perm.record_stream(main)
+    for t in (table, masks, perm):
+        t.record_stream(side)
     datas[key] = [masks, perm, ev]
 
 
@@ -106,9 +106,11 @@ class SparseConvolution(SparseModule):
 
     def _maybe_schedule_order(self, datas):
         """called right after this layer built a new table inside a prebuild pass"""
-        if (datas["nbr"].is_cuda and datas["nbr"].shape[0] > 0
-                and ops.sorted_gemm_supported(datas["nbr"].shape[1], self.in_channels, self.out_channels)):
-            _schedule_mask_order(datas, "order", datas["nbr"])
+        nbr = datas["nbr"]
+        if nbr.is_cuda and nbr.shape[0] > 0 and nbr.shape[1] <= 31 and (
+                self.indice_key is not None                 # shared table: a later layer of the level will want the order
+                or ops.sorted_gemm_supported(nbr.shape[1], self.in_channels, self.out_channels)):
+            _schedule_mask_order(datas, "order", nbr)
 
     def _resolve(self, input, need_bwd=True):
         """-> (indices, out_indices, out_shape, fwd_table, bwd_table, flip, datas) for this layer on `input` (rulebook built

@@ -153,8 +153,9 @@ def _begin_first_strided(module, indices, spatial_shape, batch_size, indice_dict
 def _hand_tables_to(stream, indice_dict):
     """tables are allocated on the rulebook stream and read on the feature stream: tell the caching allocator"""
     for name, datas in indice_dict.items():
-        if name.startswith("__"):
+        if name.startswith("__") or datas.get("__handed__") is stream:
             continue
+        datas["__handed__"] = stream
         for key in ("nbr", "nbr_t", "in_indices", "out_indices"):
             t = datas.get(key)
             if torch.is_tensor(t) and t.is_cuda:
@@ -230,24 +231,27 @@ def _run_stages_pipelined(stages, x):
     rb.wait_stream(feat)                         # the coordinates are produced on the feature stream
     indices.record_stream(rb)
     bs, idict = x.batch_size, x.indice_dict
-    with torch.cuda.stream(rb):
+    outs = []
+    try:                                         # plain set_stream calls: the context manager costs the host ~10 us a time
+        torch.cuda.set_stream(rb)
         nxt = prebuild_rulebooks(stages[0], indices, x.spatial_shape, bs, idict)
         ready = torch.cuda.Event()
         ready.record(rb)
-    _hand_tables_to(feat, idict)
-    outs = []
-    for s, stage in enumerate(stages):
-        pend = None
-        if s + 1 < len(stages):
-            with torch.cuda.stream(rb):
+        _hand_tables_to(feat, idict)
+        for s, stage in enumerate(stages):
+            pend = None
+            if s + 1 < len(stages):
                 pend = _begin_first_strided(stages[s + 1], nxt[0], nxt[1], bs, idict)
-        feat.wait_event(ready)
-        x = stage(x)
-        outs.append(x)
-        if s + 1 < len(stages):
-            with torch.cuda.stream(rb):
+            torch.cuda.set_stream(feat)
+            feat.wait_event(ready)
+            x = stage(x)
+            outs.append(x)
+            torch.cuda.set_stream(rb)
+            if s + 1 < len(stages):
                 nxt = prebuild_rulebooks(stages[s + 1], nxt[0], nxt[1], bs, idict, pend)
                 ready = torch.cuda.Event()
                 ready.record(rb)
-            _hand_tables_to(feat, idict)
+                _hand_tables_to(feat, idict)
+    finally:
+        torch.cuda.set_stream(feat)
     return outs

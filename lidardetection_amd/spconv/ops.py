@@ -43,7 +43,8 @@ class GridPool:
 
     def reset(self):
         """forget every grid (a forward was abandoned half-way: cells may hold values nobody will wipe); new ones are
-        allocated and initialised on demand"""
+        allocated and initialised on demand.  Rare: waits for the device, the old grids may still be in use on any stream."""
+        torch.cuda.synchronize()
         self.grids.clear()
 
     def _entry(self, device, batch, shape):
@@ -60,16 +61,16 @@ class GridPool:
 
     @staticmethod
     def _join(ent):
-        """the grid may last have been touched on another stream (rulebook stream vs the caller's): order after it"""
-        if ent[4] is not None:
-            torch.cuda.current_stream(ent[0].device).wait_event(ent[4])
+        """the grid may last have been touched on another stream (rulebook stream vs the caller's): order after everything
+        queued there.  Same stream as last time (the steady state: one rulebook stream) -> nothing to do, no event."""
+        if ent[4] is not None and ent[4][0] != _lib.stream().value:
+            torch.cuda.current_stream(ent[0].device).wait_stream(ent[4][1])
 
     @staticmethod
     def _mark(ent):
-        ev = torch.cuda.Event()
-        ev.record(torch.cuda.current_stream(ent[0].device))
-        ent[4] = ev
-        ent[0].record_stream(torch.cuda.current_stream(ent[0].device))
+        sid = _lib.stream().value
+        if ent[4] is None or ent[4][0] != sid:
+            ent[4] = (sid, torch.cuda.current_stream(ent[0].device))
 
     def _rows(self, ent, coords, n, shape, mode):
         D, H, W = shape
@@ -152,6 +153,19 @@ def subm_rulebook(indices, spatial_shape, ksize, batch_size=None, indice_dict=No
     return nbr
 
 
+_PINNED = {"buf": None, "next": 0}
+
+
+def _pinned_slot():
+    """one int32 of pinned host memory for an asynchronous count read-back (a ring of 4096 slots: a slot comes round again
+    thousands of rulebooks later, long after its count was read)"""
+    if _PINNED["buf"] is None:
+        _PINNED["buf"] = torch.zeros((4096,), dtype=torch.int32).pin_memory()
+    i = _PINNED["next"]
+    _PINNED["next"] = (i + 1) % 4096
+    return _PINNED["buf"][i:i + 1]
+
+
 def conv_rulebook_begin(indices, batch_size, spatial_shape, ksize, stride, padding, indice_dict=None):
     """Phase 1 of the SparseConv3d rulebook: enqueue the search for the unique output sites and an asynchronous copy of
     their count to pinned host memory.  Returns the pending state for conv_rulebook_finish; work enqueued on the stream
@@ -189,7 +203,7 @@ def conv_rulebook_begin(indices, batch_size, spatial_shape, ksize, stride, paddi
         ws = torch.empty(wsb, dtype=torch.uint8, device=dev)          # lives until finish (several rulebooks may be in flight)
         _lib.check(L.lidar_spconv_conv_outputs(_lib.ptr(indices), n, batch_size, D, H, W, *ksize, *stride, *padding, _lib.ptr(out_idx), bound,
                                                _lib.ptr(num), _lib.ptr(ws), wsb, _lib.stream()), "lidar_spconv_conv_outputs")
-    num_host = torch.empty((1,), dtype=torch.int32, pin_memory=True)
+    num_host = _pinned_slot()
     num_host.copy_(num, non_blocking=True)
     ev = torch.cuda.Event()
     ev.record(torch.cuda.current_stream(dev))
@@ -351,21 +365,21 @@ def sorted_gemm_supported(K, Cin, Cout):
 _MG_WS = {}
 
 
-def _mask_group_workspace(n, device):
-    """persistent workspace of lidar_spconv_mask_group for the CURRENT stream (its slot table must be empty between calls and two
+def _mask_group_workspace(n, device, stream):
+    """persistent workspace of lidar_spconv_mask_group for ONE stream (its slot table must be empty between calls and two
     streams must not share one): grown with headroom, initialised once per buffer"""
     L = _lib.lib()
     need = int(L.lidar_spconv_mask_group_workspace_bytes(n))
-    key = (str(device), int(_lib.stream().value or 0))
+    key = (device.index, int(stream.value or 0))
     ws = _MG_WS.get(key)
     if ws is None or ws.numel() < need:
         ws = torch.empty(need + need // 4, dtype=torch.uint8, device=device)
-        _lib.check(L.lidar_spconv_mask_group_init(_lib.ptr(ws), ws.numel(), _lib.stream()), "lidar_spconv_mask_group_init")
+        _lib.check(L.lidar_spconv_mask_group_init(_lib.ptr(ws), ws.numel(), stream), "lidar_spconv_mask_group_init")
         _MG_WS[key] = ws
     return ws
 
 
-def mask_order(nbr):
+def mask_order(nbr, stream=None):
     """(n_out, K <= 31) neighbour table -> (row offset bit masks, a row order that groups equal masks, similar masks adjacent).
     Visiting rows in that order puts equal masks into the same MFMA tiles, so tiles stop multiplying padding rows and whole
     offsets drop out per workgroup (include/lidar_hip.h: lidar_spconv_mask_group, lidar_spconv_implicit_gemm_sorted)."""
@@ -373,9 +387,10 @@ def mask_order(nbr):
     masks = torch.empty(n_out, dtype=torch.int32, device=nbr.device)
     order = torch.empty(n_out, dtype=torch.int32, device=nbr.device)
     if n_out:
-        ws = _mask_group_workspace(n_out, nbr.device)
+        stream = _lib.stream() if stream is None else stream             # raw stream handle: the launches go there, whatever
+        ws = _mask_group_workspace(n_out, nbr.device, stream)            # torch's current stream is (the caller orders the rest)
         _lib.check(_lib.lib().lidar_spconv_mask_group(_lib.ptr(nbr), n_out, K, _lib.ptr(masks), _lib.ptr(order), _lib.ptr(ws), ws.numel(),
-                                                      _lib.stream()), "lidar_spconv_mask_group")
+                                                      stream), "lidar_spconv_mask_group")
     return masks, order
 
 

@@ -1,7 +1,6 @@
-"""Host-side (Python) profile of the fused SECOND sparse forward: where the interpreter spends its time per forward."""
-import cProfile, os, pstats, sys, time
+import os, sys, time, cProfile, pstats
 import torch
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.environ.get("GRAFT_REPO_ROOT", "/root/repo"))
 from lidardetection_amd import synth
 from lidardetection_amd.pcdet.models.backbones_3d import spconv_backbone, vfe
 from lidardetection_amd.pcdet.utils.cfg import AttrDict
@@ -12,19 +11,15 @@ o = BatchVoxelizer(synth.SEC_VOXEL, synth.SEC_RANGE, 5, 16000).voxelize_frames(f
 bd = {"voxels": o["voxels"], "voxel_num_points": o["voxel_num_points"], "voxel_coords": o["voxel_coords"], "batch_size": B}
 bd = vfe.MeanVFE(AttrDict(), 4)(bd)
 m = spconv_backbone.VoxelBackBone8x(AttrDict(), 4, [1408, 1600, 40]).to(dev).eval()
-N = 20
 with torch.no_grad():
     for _ in range(5): m(dict(bd))
     torch.cuda.synchronize()
-    t = time.perf_counter()
-    for _ in range(N): m(dict(bd))
-    t_enq = (time.perf_counter() - t) / N
-    torch.cuda.synchronize()
-    t_all = (time.perf_counter() - t) / N
-    print(f"per forward: host returns after {t_enq * 1e3:.2f} ms, GPU done after {t_all * 1e3:.2f} ms")
-    pr = cProfile.Profile(); pr.enable()
-    for _ in range(N): m(dict(bd))
-    torch.cuda.synchronize()
+    pr = cProfile.Profile()
+    pr.enable()
+    for _ in range(50):
+        m(dict(bd))
     pr.disable()
-st = pstats.Stats(pr); st.sort_stats("tottime")
-st.print_stats(22)
+    torch.cuda.synchronize()
+st = pstats.Stats(pr)
+st.sort_stats("tottime").print_stats(35)
+st.sort_stats("cumtime").print_stats(45)
