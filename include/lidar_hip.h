@@ -142,6 +142,12 @@ int lidar_ball_query_stack(int B, int M, float radius, int nsample, const float 
 int lidar_group_points_stack(int B, int M, int C, int nsample, const float *features, const int *features_batch_cnt,
                              const int *idx, const int *idx_batch_cnt, float *out, void *stream);
 /* group_points_grad_wrapper_stack (group_points_gpu.cu:15-45): grad_features (N, C) zero-filled by the caller */
+/* Row-major grouping for the inference path of StackSAModuleMSG (pointnet2_stack/pointnet2_modules.py:58-92): out (M, nsample,
+ * stride) with row (m, s) = [xyz[idx] - new_xyz[m] if use_xyz | features[idx] | zeros up to stride]; idx is the RAW result of
+ * lidar_ball_query_stack (-1 in column 0 = empty ball -> zero rows, as QueryAndGroup zeroes them, pointnet2_utils.py:146-152). */
+int lidar_group_rows_stack(int B, int M, int C, int nsample, int use_xyz, int stride, const float *xyz, const float *new_xyz,
+                           const float *features, const int *features_batch_cnt, const int *idx, const int *idx_batch_cnt,
+                           float *out, void *stream);
 int lidar_group_points_grad_stack(int B, int M, int C, int N, int nsample, const float *grad_out, const int *idx,
                                   const int *idx_batch_cnt, const int *features_batch_cnt, float *grad_features,
                                   void *stream);

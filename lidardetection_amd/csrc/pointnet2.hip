@@ -228,6 +228,52 @@ LIDAR_EXPORT int lidar_group_points_stack(int B, int M, int C, int nsample, cons
     return lidar_check_launch("lidar_group_points_stack");
 }
 
+// Row-major grouping for the inference path of a set-abstraction scale: out (M, ns, stride) with row (m, s) =
+// [xyz[idx] - new_xyz[m] (when use_xyz) | features[idx] | zero padding up to stride], an all-zero row set for an empty ball
+// (ball query's marker: idx[m][0] < 0).  What QueryAndGroup builds (pointnet2_stack/pointnet2_utils.py:119-155) transposed:
+// the shared MLP then runs as plain row-major GEMMs over (M * ns) rows instead of a 1x1 convolution over a strided
+// (C, M, ns) view, every row is read and written as one contiguous run, and the (M, C, ns) tensor never exists.
+__global__ __launch_bounds__(256) void group_rows_stack_kernel(int B, int M, int C, int ns, int use_xyz, int stride,
+                                                               const float *__restrict__ xyz, const float *__restrict__ new_xyz,
+                                                               const float *__restrict__ feat, const int *__restrict__ feat_cnt,
+                                                               const int *__restrict__ idx, const int *__restrict__ idx_cnt,
+                                                               float *__restrict__ out) {
+    __shared__ int s_start;
+    const int m = blockIdx.x, t = threadIdx.x;
+    if (t == 0) {
+        int bs, st, nn;
+        pn_batch_of(idx_cnt, B, m, feat_cnt, bs, st, nn);
+        s_start = st;
+    }
+    __syncthreads();
+    const int start = s_start, X = use_xyz ? 3 : 0, Ct = X + C;
+    const int *row = idx + (size_t)m * ns;
+    const bool empty = row[0] < 0;
+    float *o = out + (size_t)m * ns * stride;
+    for (int e = t; e < ns * stride; e += 256) {
+        const int s = e / stride, c = e - s * stride;
+        float v = 0.f;
+        if (!empty && c < Ct) {
+            const size_t r = (size_t)start + row[s];
+            v = c < X ? xyz[r * 3 + c] - new_xyz[(size_t)m * 3 + c] : feat[r * C + (c - X)];
+        }
+        o[e] = v;
+    }
+}
+
+// idx: the RAW ball-query result (-1 in column 0 marks an empty ball).  features may be null (C = 0, use_xyz required).
+LIDAR_EXPORT int lidar_group_rows_stack(int B, int M, int C, int nsample, int use_xyz, int stride, const float *xyz,
+                                        const float *new_xyz, const float *features, const int *features_batch_cnt, const int *idx,
+                                        const int *idx_batch_cnt, float *out, void *stream) {
+    if (B <= 0 || M < 0 || C < 0 || nsample <= 0 || stride < C + (use_xyz ? 3 : 0) || (C == 0 && !use_xyz)) return LIDAR_ERR_ARG;
+    if (M == 0) return LIDAR_OK;
+    if ((C > 0 && !features) || (use_xyz && (!xyz || !new_xyz)) || !features_batch_cnt || !idx || !idx_batch_cnt || !out)
+        return LIDAR_ERR_ARG;
+    hipLaunchKernelGGL(group_rows_stack_kernel, dim3(M), dim3(256), 0, (hipStream_t)stream, B, M, C, nsample, use_xyz, stride, xyz,
+                       new_xyz, features, features_batch_cnt, idx, idx_batch_cnt, out);
+    return lidar_check_launch("lidar_group_rows_stack");
+}
+
 // group_points_grad_kernel_stack (:15-45): grad_features (N, C) += grad_out (M, C, ns); atomics issued with
 // the channel on the lane (contiguous row segments of grad_features per wave instruction)
 __global__ __launch_bounds__(PN_TPB) void group_points_grad_stack_kernel(int B, int M, int C, int ns, const float *__restrict__ grad_out,

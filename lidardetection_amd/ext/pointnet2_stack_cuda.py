@@ -27,6 +27,15 @@ def group_points_wrapper(B, M, C, nsample, features, features_batch_cnt, idx, id
     return 1
 
 
+def group_rows_wrapper(B, M, C, nsample, use_xyz, stride, xyz, new_xyz, features, features_batch_cnt, idx, idx_batch_cnt, out):
+    """not in the reference's module: (M, nsample, stride) row-major groups for the inference MLP (include/lidar_hip.h)"""
+    _lib.require_cuda(xyz, new_xyz, features, features_batch_cnt, idx, idx_batch_cnt, out)
+    _lib.check(_lib.lib().lidar_group_rows_stack(B, M, C, nsample, int(bool(use_xyz)), stride, _p(xyz), _p(new_xyz), _p(features),
+                                                 _p(features_batch_cnt), _p(idx), _p(idx_batch_cnt), _p(out), _S()),
+               "lidar_group_rows_stack")
+    return 1
+
+
 def group_points_grad_wrapper(B, M, C, N, nsample, grad_out, idx, idx_batch_cnt, features_batch_cnt, grad_features):
     _lib.require_cuda(grad_out, idx, idx_batch_cnt, features_batch_cnt, grad_features)
     _lib.check(_lib.lib().lidar_group_points_grad_stack(B, M, C, N, nsample, _p(grad_out), _p(idx), _p(idx_batch_cnt),

@@ -35,8 +35,70 @@ class StackSAModuleMSG(nn.Module):
                 nn.init.ones_(layer.weight)
                 nn.init.zeros_(layer.bias)
 
+    def _folded_layers(self, k):
+        """scale k's shared MLP as row-major GEMM operands: [(W (Cin rounded up to 4, Cout), shift (Cout))] with the eval-mode
+        BatchNorm folded in; cached until a parameter changes"""
+        mods = list(self.mlps[k])
+        srcs = [t for m in mods for t in (getattr(m, 'weight', None), getattr(m, 'bias', None), getattr(m, 'running_mean', None),
+                                          getattr(m, 'running_var', None)) if t is not None]
+        key = tuple((t.data_ptr(), t._version) for t in srcs)
+        cache = self.__dict__.setdefault('_fold_cache', {})
+        if k not in cache or cache[k][0] != key:
+            layers = []
+            with torch.no_grad():
+                for conv, bn in zip(mods[0::3], mods[1::3]):
+                    scale = bn.weight / torch.sqrt(bn.running_var + bn.eps)
+                    w = conv.weight[:, :, 0, 0].t() * scale.view(1, -1)                       # (Cin, Cout)
+                    shift = bn.bias - bn.running_mean * scale
+                    if conv.bias is not None:
+                        shift = shift + conv.bias * scale
+                    pad = (-w.shape[0]) % 4
+                    if pad:
+                        w = torch.cat((w, w.new_zeros(pad, w.shape[1])), dim=0)
+                    layers.append((w.contiguous(), shift.contiguous()))
+            cache[k] = (key, layers)
+        return cache[k][1]
+
+    def _inference_ready(self, xyz):
+        if torch.is_grad_enabled() or self.training or self.pool_method != 'max_pool' or not xyz.is_cuda:
+            return False
+        for mlp in self.mlps:
+            mods = list(mlp)
+            if len(mods) % 3 or not all(isinstance(c, nn.Conv2d) and isinstance(b, nn.BatchNorm2d) and isinstance(a, nn.ReLU)
+                                        and not b.training and b.track_running_stats
+                                        for c, b, a in zip(mods[0::3], mods[1::3], mods[2::3])):
+                return False
+        return True
+
+    def forward_inference(self, xyz, xyz_batch_cnt, new_xyz, new_xyz_batch_cnt, features=None):
+        """The same result as forward() in eval mode, built for the GPU: groups are gathered ROW-major ((M * nsample, C) — one
+        contiguous run per neighbour, lidar_group_rows_stack), the shared MLP is a chain of plain GEMMs with BatchNorm folded
+        into the weights and the shift + ReLU applied in place, and the max runs over contiguous blocks of nsample rows.  The
+        (M, C, nsample) tensor of the reference layout and the 1x1 convolution over its strided view never exist."""
+        from .....ext import pointnet2_stack_cuda as native
+        C.require_contiguous(xyz, xyz_batch_cnt, new_xyz, new_xyz_batch_cnt)
+        n_batch, n_query = xyz_batch_cnt.shape[0], new_xyz.shape[0]
+        feats = None if features is None else features.contiguous()
+        width = 0 if feats is None else feats.shape[1]
+        per_scale = []
+        for k, grouper in enumerate(self.groupers):
+            layers = self._folded_layers(k)
+            idx = C.zeros_i32((n_query, grouper.nsample), xyz.device)
+            native.ball_query_wrapper(n_batch, n_query, grouper.radius, grouper.nsample, new_xyz, new_xyz_batch_cnt, xyz,
+                                      xyz_batch_cnt, idx)
+            stride = layers[0][0].shape[0]
+            rows = C.empty_f32((n_query * grouper.nsample, stride), xyz.device)
+            native.group_rows_wrapper(n_batch, n_query, width, grouper.nsample, grouper.use_xyz, stride, xyz, new_xyz, feats,
+                                      xyz_batch_cnt, idx, new_xyz_batch_cnt, rows)
+            for w, shift in layers:
+                rows = torch.addmm(shift, rows, w).relu_()
+            per_scale.append(rows.view(n_query, grouper.nsample, -1).amax(dim=1))
+        return new_xyz, torch.cat(per_scale, dim=1)
+
     def forward(self, xyz, xyz_batch_cnt, new_xyz, new_xyz_batch_cnt, features=None, empty_voxel_set_zeros=True):
         """xyz (N, 3), features (N, C), new_xyz (M, 3) -> (new_xyz, (M, sum of the scales' last MLP widths))"""
+        if self._inference_ready(xyz) and new_xyz.shape[0] > 0:
+            return self.forward_inference(xyz, xyz_batch_cnt, new_xyz, new_xyz_batch_cnt, features)
         per_scale = []
         for grouper, mlp in zip(self.groupers, self.mlps):
             grouped, _ = grouper(xyz, xyz_batch_cnt, new_xyz, new_xyz_batch_cnt, features)      # (M, C, nsample)

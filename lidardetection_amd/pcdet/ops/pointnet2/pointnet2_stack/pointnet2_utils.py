@@ -26,7 +26,7 @@ class BallQuery(Function):
         pointnet2.ball_query_wrapper(xyz_batch_cnt.shape[0], n_query, radius, nsample, new_xyz, new_xyz_batch_cnt, xyz,
                                      xyz_batch_cnt, idx)
         nothing_found = idx[:, 0] == -1            # the kernel's marker for an empty ball
-        idx[nothing_found] = 0
+        idx.masked_fill_(nothing_found.unsqueeze(1), 0)       # == idx[nothing_found] = 0 without the host sync of mask indexing
         return idx, nothing_found
 
     @staticmethod
@@ -78,13 +78,13 @@ class QueryAndGroup(nn.Module):
         _check_counts('new_xyz', new_xyz, new_xyz_batch_cnt)
         idx, empty = ball_query(self.radius, self.nsample, xyz, xyz_batch_cnt, new_xyz, new_xyz_batch_cnt)
         offsets = grouping_operation(xyz, xyz_batch_cnt, idx, new_xyz_batch_cnt) - new_xyz.unsqueeze(-1)
-        offsets[empty] = 0
+        offsets.masked_fill_(empty.view(-1, 1, 1), 0)         # == offsets[empty] = 0, no host sync
         if features is None:
             if not self.use_xyz:
                 raise AssertionError('nothing to group: no features and use_xyz=False')
             return offsets, idx
         gathered = grouping_operation(features, xyz_batch_cnt, idx, new_xyz_batch_cnt)
-        gathered[empty] = 0
+        gathered.masked_fill_(empty.view(-1, 1, 1), 0)
         return (torch.cat((offsets, gathered), dim=1) if self.use_xyz else gathered), idx
 
 

@@ -255,7 +255,21 @@ def test_pvrcnn_kitti_bs8(dev):
         out = m(pts, offs, sizes)
     # same functions, same inputs — but the dense layers (MIOpen / hipBLASLt) may pick another kernel when the free workspace
     # differs between the two passes, so fp32 sums can differ in their last bits: counts and labels exact, values to 1e-4
-    assert torch.equal(out[3], fn) and torch.equal(out[2], fl)
-    dmax = float((out[0] - fb).abs().max())
-    print(f"assembled vs staged forward: max |box diff| {dmax:.2e}, max |score diff| {float((out[1] - fs).abs().max()):.2e}")
-    assert dmax <= 1e-4 * max(1.0, float(fb.abs().max())) and float((out[1] - fs).abs().max()) <= 1e-4
+    assert torch.equal(out[3], fn)
+    # (box sizes are exp() of a regression output: compared relative to their own magnitude; two RoIs whose scores differ
+    # in the last bit may swap places between the passes, so each frame's rows are put in a canonical order first)
+    def canon(boxes, scores, labels, n):
+        res = ([], [], [])
+        for f in range(boxes.shape[0]):
+            k = int(n[f])
+            order = torch.from_numpy(np.lexsort(np.round(boxes[f, :k].cpu().numpy()[:, :3].T, 2))).to(boxes.device)
+            for dst, t in zip(res, (boxes, scores, labels)):
+                dst.append(torch.cat([t[f, :k][order], t.new_zeros((boxes.shape[1] - k,) + t.shape[2:])]))
+        return [torch.stack(r) for r in res]
+    out = canon(out[0], out[1], out[2], fn)
+    fb, fs, fl = canon(fb, fs, fl, fn)
+    assert torch.equal(out[2], fl)
+    rel = float(((out[0] - fb).abs() / fb.abs().clamp(min=1.0)).max())
+    print(f"assembled vs staged forward: max box diff relative to max(1, |box|) {rel:.2e} (max |box| {float(fb.abs().max()):.2e}), "
+          f"max |score diff| {float((out[1] - fs).abs().max()):.2e}")
+    assert rel <= 1e-4 and float((out[1] - fs).abs().max()) <= 1e-4

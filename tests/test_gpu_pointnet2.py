@@ -183,6 +183,20 @@ def test_stack_set_abstraction_and_fp_modules_vs_oracle(dev):
         _, nf = sa(t(xyz), t(xc), t(new), t(nc), t(feat))
     assert nf.shape == (len(new), 48)
     _close(nf.cpu().numpy(), sa_oracle.stack_sa_msg(sa, xyz, xc, new, nc, feat), "StackSAModuleMSG")
+    # no_grad + eval took the row-major inference path (forward_inference: lidar_group_rows_stack + GEMM chain); the
+    # reference-layout path (autograd on) must agree with it and with the replay, with and without features / use_xyz
+    with torch.no_grad():
+        assert sa._inference_ready(t(xyz))
+    assert not sa._inference_ready(t(xyz))
+    _, nf_ref = sa(t(xyz), t(xc), t(new), t(nc), t(feat))
+    _close(nf_ref.detach().cpu().numpy(), sa_oracle.stack_sa_msg(sa, xyz, xc, new, nc, feat), "StackSAModuleMSG, reference layout")
+    sa_x = _perturb_bn(smod.StackSAModuleMSG(radii=[0.8], nsamples=[16], mlps=[[0, 16, 24]]).to(dev), 5)       # xyz only
+    sa_f = _perturb_bn(smod.StackSAModuleMSG(radii=[1.6], nsamples=[8], mlps=[[8, 16]], use_xyz=False).to(dev), 6)
+    with torch.no_grad():
+        _close(sa_x(t(xyz), t(xc), t(new), t(nc), None)[1].cpu().numpy(), sa_oracle.stack_sa_msg(sa_x, xyz, xc, new, nc, None),
+               "StackSAModuleMSG, xyz only")
+        _close(sa_f(t(xyz), t(xc), t(new), t(nc), t(feat))[1].cpu().numpy(), sa_oracle.stack_sa_msg(sa_f, xyz, xc, new, nc, feat),
+               "StackSAModuleMSG, use_xyz=False")
     fp = _perturb_bn(smod.StackPointnetFPModule(mlp=[48 + 8, 32]).to(dev), 2)
     with torch.no_grad():
         out = fp(t(xyz), t(xc), t(new), t(nc), unknown_feats=t(feat), known_feats=nf)
