@@ -46,3 +46,13 @@ def pool_over_samples(x, method):
 def inverse_distance_weights(dist, eps=1e-8):
     inv = 1.0 / (dist + eps)
     return inv / inv.sum(dim=-1, keepdim=True)
+
+
+def addmm_act(shift, x, w, relu=True):
+    """x @ w + shift (, ReLU): one library GEMM, with the bias + ReLU epilogue fused when torch exposes it"""
+    if relu:
+        fused = getattr(torch, "_addmm_activation", None)
+        if fused is not None:
+            return fused(shift, x, w)
+        return torch.addmm(shift, x, w).relu_()
+    return torch.addmm(shift, x, w)

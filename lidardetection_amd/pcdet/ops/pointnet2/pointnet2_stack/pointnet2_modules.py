@@ -91,7 +91,7 @@ class StackSAModuleMSG(nn.Module):
             native.group_rows_wrapper(n_batch, n_query, width, grouper.nsample, grouper.use_xyz, stride, xyz, new_xyz, feats,
                                       xyz_batch_cnt, idx, new_xyz_batch_cnt, rows)
             for w, shift in layers:
-                rows = torch.addmm(shift, rows, w).relu_()
+                rows = C.addmm_act(shift, rows, w)
             per_scale.append(rows.view(n_query, grouper.nsample, -1).amax(dim=1))
         return new_xyz, torch.cat(per_scale, dim=1)
 

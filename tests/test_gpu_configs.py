@@ -227,6 +227,16 @@ def test_pvrcnn_kitti_bs8(dev):
         assert before.shape == (B * 2048, 640) and fused.shape == (B * 2048, 128)
         np.testing.assert_allclose(before[:2048, :256].cpu().numpy(), bf[0].cpu().numpy(), rtol=0, atol=0)     # the bev slice
         point_scores = torch.sigmoid(m.point_cls_layers(before)).max(dim=-1)[0]
+        # the folded GEMM chains the forward uses for the FC stacks (pvrcnn.DenseChain) vs the module sequences themselves
+        for name, x in (("point_cls_layers", before), ("vsa_point_feature_fusion", before)):
+            want = getattr(m, name)(x)
+            assert float((m._dense[name](x) - want).abs().max()) <= 1e-4 * max(1.0, float(want.abs().max())), name
+        xs = torch.randn(800, 6 ** 3 * 128, device=dev)
+        sh = m.shared_fc_layer(xs.unsqueeze(-1))                                  # the reference's (rows, C, 1) Conv1d form
+        assert float((m._dense["shared_fc_layer"](xs) - sh[:, :, 0]).abs().max()) <= 1e-4 * max(1.0, float(sh.abs().max()))
+        for name in ("cls_layers", "reg_layers"):
+            want = getattr(m, name)(sh)[:, :, 0]
+            assert float((m._dense[name](sh[:, :, 0].contiguous()) - want).abs().max()) <= 1e-4 * max(1.0, float(want.abs().max())), name
         # RoI-grid pooling: 100 x 216 grid points per frame against the 2 048 weighted keypoints, frame 0 vs the oracle
         grid = roi_grid_points(rois[0], m.grid_size).reshape(-1, 3).contiguous()
         assert grid.shape == (100 * 216, 3)

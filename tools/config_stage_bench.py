@@ -60,7 +60,9 @@ with torch.no_grad():
         mlp = m.roi_grid_pool_layer.mlps[0]
         gg = torch.cat([torch.zeros(g.shape[0], 3, 16, device=dev), g], 1)
         tm, _ = gpu_time(lambda: mlp(gg.permute(1, 0, 2).unsqueeze(0)).amax(-1))
-        print(f"  roi grid scale 0: ball query {tb:.3f} group {tg:.3f} MLP+max {tm:.3f} ms (M = {grid.shape[0]})", flush=True)
+        print(f"  roi grid scale 0, reference layout (M, C, ns): ball query {tb:.3f} group {tg:.3f} MLP+max {tm:.3f} ms (M = {grid.shape[0]})", flush=True)
+        tf, _ = gpu_time(lambda: m.roi_grid_pool_layer(xyz=kx, xyz_batch_cnt=kc, new_xyz=grid, new_xyz_batch_cnt=gc, features=fused.contiguous()))
+        print(f"  roi grid pooling as the forward runs it (row-major groups + folded GEMM chain, both scales): {tf:.3f} ms", flush=True)
         del m
         torch.cuda.empty_cache()
     if "multihead" in which:
