@@ -447,14 +447,17 @@ __global__ __launch_bounds__(256) void sc_implicit_gemm_kernel(const float *__re
 
 // Software-pipelined variant for Cin = 4*C4 in {16, 32, 64, 128} and Cout % 4 == 0: the gathered rows and W[k+1] are
 // fetched into registers while the MFMAs of offset k run out of LDS (global latency hidden behind the matrix pipe).
-template <int NT, int C4>
+// SL > 1: the input row is consumed in SL slices of 4*C4 channels, one LDS stage each (Cin total = SL * 4 * C4): for 128 input
+// channels the one-slice stage needs 130 KB of LDS and 276 registers (ONE workgroup per CU, one wave per SIMD); two 64-channel
+// slices fit twice.  Channels are still accumulated in ascending order per offset, so the sums do not change by a bit.
+template <int NT, int C4, int SL = 1>
 __global__ __launch_bounds__(256) void sc_implicit_gemm_pipe_kernel(const float *__restrict__ in, const int *__restrict__ nbr, int n_out,
                                                                     int K, int Cout, const float *__restrict__ Wt,
                                                                     const float *__restrict__ bias, const float *__restrict__ residual,
                                                                     int relu, float *__restrict__ out,
                                                                     const int *__restrict__ row_mask, const int *__restrict__ out_row) {
-    constexpr int Cin = C4 * 4, Cp = Cin + 1, CW = NT * 32, CW4 = CW / 4;
-    constexpr int NG = (32 * C4) / 64;                    // float4 gathers per lane per offset
+    constexpr int Cin = C4 * 4, Cp = Cin + 1, CW = NT * 32, CW4 = CW / 4, CinT = Cin * SL;
+    constexpr int NG = (32 * C4) / 64;                    // float4 gathers per lane per stage
     constexpr int NW = (Cin * CW4 + 255) / 256;           // float4 weight pieces per thread per offset
     extern __shared__ float s_mem[];
     float *s_w = s_mem;                                   // [Cin][CW]
@@ -496,30 +499,31 @@ __global__ __launch_bounds__(256) void sc_implicit_gemm_pipe_kernel(const float 
     // table entries are requested one offset ahead of the gathers that use them (two ahead of the MFMAs), so no wave waits
     // for a table load with nothing else in flight
     auto load_src = [&](int k) { return (myrow < n_out && k < K) ? nbr[(size_t)trow * K + k] : -1; };
-    auto fetch = [&](int k, const int src) {
+    auto fetch = [&](int k, int h, const int src) {       // stage (offset k, channel slice h)
         any_next = row_mask ? ((wave_mask >> k) & 1u) != 0u : __ballot(src >= 0) != 0ull;
 #pragma unroll
         for (int u = 0; u < NG; ++u) {
             const int e = u * 64 + l, r = e / C4, c = e - r * C4;
             const int sr = __shfl(src, r, 64);
             g[u] = make_float4(0.f, 0.f, 0.f, 0.f);
-            if (any_next && sr >= 0) g[u] = reinterpret_cast<const float4 *>(in + (size_t)sr * Cin)[c];
+            if (any_next && sr >= 0) g[u] = reinterpret_cast<const float4 *>(in + (size_t)sr * CinT + h * Cin)[c];
         }
 #pragma unroll
         for (int q = 0; q < NW; ++q) {
             const int e = q * 256 + t, ci = e / CW4, q4 = e - ci * CW4;
             wr[q] = make_float4(0.f, 0.f, 0.f, 0.f);
-            if (e < Cin * CW4 && q4 < Co4) wr[q] = reinterpret_cast<const float4 *>(Wt + ((size_t)k * Cin + ci) * Cout)[q4];
+            if (e < Cin * CW4 && q4 < Co4) wr[q] = reinterpret_cast<const float4 *>(Wt + ((size_t)k * CinT + h * Cin + ci) * Cout)[q4];
         }
     };
-    int k = next_k(-1);
-    int src_ahead = load_src(k);
+    int k = next_k(-1), h = 0;
+    int src_cur = load_src(k), src_ahead = -1;            // table entries of the offset being fetched / of the one after it
     if (k < K) {
-        fetch(k, src_ahead);
+        fetch(k, 0, src_cur);
         src_ahead = load_src(next_k(k));
     }
     for (; k < K;) {
-        const int kn = next_k(k);
+        int kn = k, hn = h + 1;                           // the stage after this one
+        if (hn == SL) { kn = next_k(k); hn = 0; }
         const bool any = any_next;
         __syncthreads();                                  // LDS of the previous offset is no longer read
         // a workgroup-uniform "somebody needs W[k]" is not known per wave: every wave stores its W pieces whenever IT has work;
@@ -541,8 +545,11 @@ __global__ __launch_bounds__(256) void sc_implicit_gemm_pipe_kernel(const float 
         }
         __syncthreads();
         if (kn < K) {                                     // in flight while the MFMAs below run
-            fetch(kn, src_ahead);
-            src_ahead = load_src(next_k(kn));
+            if (kn != k) {
+                src_cur = src_ahead;
+                src_ahead = load_src(next_k(kn));
+            }
+            fetch(kn, hn, src_cur);
         }
         if (any) {
 #pragma unroll 4
@@ -556,6 +563,7 @@ __global__ __launch_bounds__(256) void sc_implicit_gemm_pipe_kernel(const float 
             }
         }
         k = kn;
+        h = hn;
     }
     const int last = n_out - 1;                           // n_out >= 1 (checked by the launcher)
     // fused epilogue: (+ bias) (+ residual) (ReLU); sorted tables scatter rows.  Output row indices and residual values are
@@ -695,16 +703,21 @@ static int sc_gemm_launch(const float *in_features, const int *nbr, int n_out, i
     if (!in_features || !nbr || !weight || !out_features) return LIDAR_ERR_ARG;
     hipStream_t s = (hipStream_t)stream;
     const int nt = divup(Cout, 32);
-    const size_t lds = ((size_t)Cin * nt * 32 + (size_t)4 * 32 * (Cin + 1)) * sizeof(float);
+    const int cin_stage = (Cin == 128 && (Cout & 3) == 0) ? 64 : Cin;     // 128 input channels: two 64-channel stages per offset
+    const size_t lds = ((size_t)cin_stage * nt * 32 + (size_t)4 * 32 * (cin_stage + 1)) * sizeof(float);
     const dim3 grid(divup(n_out, IG_ROWS));
 #define IGP(NT, C4) hipLaunchKernelGGL((sc_implicit_gemm_pipe_kernel<NT, C4>), grid, dim3(256), lds, s, in_features, nbr, n_out, K, Cout, weight, bias, residual, relu, out_features, row_mask, out_row)
+#define IGP2(NT, C4) hipLaunchKernelGGL((sc_implicit_gemm_pipe_kernel<NT, C4, 2>), grid, dim3(256), lds, s, in_features, nbr, n_out, K, Cout, weight, bias, residual, relu, out_features, row_mask, out_row)
     const bool pipe = (Cout & 3) == 0 && (Cin == 16 || Cin == 32 || Cin == 64 || Cin == 128);
     if ((row_mask || out_row) && (!pipe || K > 32 || !row_mask || !out_row)) return LIDAR_ERR_ARG;
     if (pipe) {
         const int c4 = Cin / 4;
 #define IGP_NT(C4) switch (nt) { case 1: IGP(1, C4); break; case 2: IGP(2, C4); break; case 3: IGP(3, C4); break; default: IGP(4, C4); break; }
-        if (c4 == 4) { IGP_NT(4) } else if (c4 == 8) { IGP_NT(8) } else if (c4 == 16) { IGP_NT(16) } else { IGP_NT(32) }
+        if (c4 == 4) { IGP_NT(4) } else if (c4 == 8) { IGP_NT(8) } else if (c4 == 16) { IGP_NT(16) } else {
+            switch (nt) { case 1: IGP2(1, 16); break; case 2: IGP2(2, 16); break; case 3: IGP2(3, 16); break; default: IGP2(4, 16); break; }
+        }
 #undef IGP_NT
+#undef IGP2
         return lidar_check_launch("lidar_spconv_implicit_gemm(pipe)");
     }
 #undef IGP
