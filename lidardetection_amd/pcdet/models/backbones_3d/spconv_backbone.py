@@ -111,7 +111,17 @@ class _VoxelBackBoneBase(nn.Module):
             # inference (eval mode: one fused launch per layer, the host is far ahead of the GPU): the next stage's rulebooks
             # are built on a second stream under this stage's GEMMs.  With train-mode BatchNorm under no_grad the feature pass
             # is launch-bound and the interleaving delays the rulebook chain (6.4 vs 5.5 ms), so that case keeps the prebuilt pass.
-            taps = dict(zip(_STAGE_ORDER, spconv.run_stages_pipelined(stages, x)))
+            cap = int(getattr(self, 'graph_capacity', 0) or 0)
+            if cap >= x.indices.shape[0]:
+                # opt-in (not in the reference): the whole forward replayed as one captured hipGraph over inputs padded to
+                # `graph_capacity` rows (spconv.GraphedStages); outputs are exact but live in the graph's memory until the next call
+                key = (x.batch_size, cap, x.features.shape[1], str(x.features.device))
+                graphs = self.__dict__.setdefault('_graphs', {})
+                if key not in graphs:
+                    graphs[key] = spconv.GraphedStages(stages, x.spatial_shape, x.batch_size, x.features.shape[1], cap, x.features.device)
+                taps = dict(zip(_STAGE_ORDER, graphs[key](x.features, x.indices)))
+            else:
+                taps = dict(zip(_STAGE_ORDER, spconv.run_stages_pipelined(stages, x)))
             x = taps[_STAGE_ORDER[-1]]
         else:
             spconv.prebuild_rulebooks(stages, x.indices.contiguous(), x.spatial_shape, x.batch_size, x.indice_dict)

@@ -13,7 +13,8 @@ torch.nn.functional.conv3d and a brute-force rulebook (tests/test_gpu_spconv.py)
 from .conv import SparseConv3d, SparseConvolution, SparseInverseConv3d, SubMConv3d
 from .modules import SparseModule, SparseSequential, prebuild_rulebooks, run_stages_pipelined
 from .tensor import SparseConvTensor
+from .graphed import GraphedStages
 from . import ops, utils
 
 __all__ = ["SparseConvTensor", "SparseModule", "SparseSequential", "SparseConvolution", "SubMConv3d", "SparseConv3d",
-           "SparseInverseConv3d", "prebuild_rulebooks", "run_stages_pipelined", "ops", "utils"]
+           "SparseInverseConv3d", "prebuild_rulebooks", "run_stages_pipelined", "GraphedStages", "ops", "utils"]

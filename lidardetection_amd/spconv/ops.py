@@ -41,6 +41,17 @@ class GridPool:
         self.counter += 1
         return self.counter
 
+    def holds_rows(self):
+        return any(ent[2] > 0 for ent in self.grids.values())
+
+    def wipe_all(self):
+        """every grid back to all-empty, on the current stream (a captured forward must begin and end with clean grids)"""
+        for key, ent in self.grids.items():
+            if ent[2] > 0:
+                self._join(ent)
+                self._wipe(ent, key[2:])
+                self._mark(ent)
+
     def reset(self):
         """forget every grid (a forward was abandoned half-way: cells may hold values nobody will wipe); new ones are
         allocated and initialised on demand.  Rare: waits for the device, the old grids may still be in use on any stream."""
@@ -235,6 +246,8 @@ def _finish_speculative(st, spec, need_t):
     est_in, src = spec["rows"].get(st["indices"].data_ptr(), (float(n), None))
     est_out = est_in * hint
     cap = min(st["bound"], int(est_out * CAP_HEADROOM) + CAP_SLACK)
+    if "caps" in spec:                                                  # frozen capacities (a captured graph): by position
+        cap = min(st["bound"], spec["caps"][len(spec["pending"])])
     L = _lib.lib()
     out_indices = st["out_idx"][:cap]                                   # a view of this rulebook's own buffer
     _lib.check(L.lidar_spconv_grid_pad_rows(_lib.ptr(out_indices), _lib.ptr(st["num"]), cap, _lib.stream()), "lidar_spconv_grid_pad_rows")
@@ -249,18 +262,22 @@ def _finish_speculative(st, spec, need_t):
         nbr_t = torch.empty((n, K), dtype=torch.int32, device=dev)
         _lib.check(L.lidar_spconv_grid_table_t(_lib.ptr(st["indices"]), n, *geom, _lib.ptr(go), cap, _lib.ptr(nbr_t), _lib.stream()),
                    "lidar_spconv_grid_table_t")
-    spec["pending"].append({"key": st["hint_key"], "num_host": st["num_host"], "ev": st["ev"], "cap": cap, "src": src, "n_in": n})
+    spec["pending"].append({"key": st["hint_key"], "num_host": st["num_host"], "ev": st["ev"], "cap": cap, "src": src,
+                            "n_in": n if src is None and st["indices"].data_ptr() not in spec["rows"] else int(est_in),
+                            "bound": st["bound"]})
     spec["rows"][out_indices.data_ptr()] = (est_out, len(spec["pending"]) - 1)
     return out_indices, nbr, nbr_t
 
 
-def resolve_speculation(spec):
-    """Wait for the counts of this forward (one event: they are produced in order on one stream), refresh the hints.
+def resolve_speculation(spec, wait=True):
+    """Wait for the counts of this forward (one event: they are produced in order on one stream; wait=False: the caller has
+    already synchronised), refresh the hints.
     -> (true row count per coords data_ptr, overflowed?)"""
     pend = spec["pending"]
     if not pend:
         return {}, False
-    pend[-1]["ev"].synchronize()
+    if wait:
+        pend[-1]["ev"].synchronize()
     over = False
     for p in pend:
         p["true"] = int(p["num_host"][0])
@@ -286,7 +303,8 @@ def conv_rulebook_finish(st, spec=None, need_t=True):
     st["ev"].synchronize()
     n_out = int(st["num_host"][0])
     src = spec["rows"].get(st["indices"].data_ptr()) if spec is not None else None
-    true_in = n if src is None or src[1] is None else int(spec["pending"][src[1]]["num_host"][0])     # an earlier count of this stream
+    true_in = n if src is None else (int(src[0]) if src[1] is None else int(spec["pending"][src[1]]["num_host"][0]))   # (an earlier
+                                                                                                                      # count of this stream)
     if true_in > 0:
         _CAP_HINTS[st["hint_key"]] = n_out / true_in
     nbr = torch.empty((n_out, K), dtype=torch.int32, device=dev)

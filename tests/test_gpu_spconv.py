@@ -466,3 +466,61 @@ def test_speculative_capacity_forward_is_exact_and_recovers_from_overflow(dev):
                 assert torch.equal(ops.ensure_table_t(dict(got[1][key])), d["nbr_t"])
     finally:
         ops._finish_speculative = orig
+
+
+def test_graphed_forward_equals_eager_forward(dev):
+    """spconv.GraphedStages: the whole VoxelBackBone8x inference forward captured as one hipGraph over capacity-padded inputs.
+    Every stage output (coordinates, order, feature bits) equals the eager exact path for inputs of different sizes replayed
+    through the same graph; a frozen capacity that is too small is noticed (exact-path answer, graph rebuilt); changed weights
+    rebuild the graph; an eager forward in between (which leaves its rows in the shared grids) does not disturb the replay."""
+    from lidardetection_amd import pillar_ops, spconv, synth
+    from lidardetection_amd.pcdet.models.backbones_3d import spconv_backbone
+    from lidardetection_amd.pcdet.utils.cfg import AttrDict
+    from lidardetection_amd.voxelizer import BatchVoxelizer
+    vox = BatchVoxelizer(synth.SEC_VOXEL, synth.SEC_RANGE, 5, 16000)
+    torch.manual_seed(5)
+    m = spconv_backbone.VoxelBackBone8x(AttrDict(), 4, [1408, 1600, 40]).to(dev).eval()
+    stages = [getattr(m, nm) for nm in ("conv_input", "conv1", "conv2", "conv3", "conv4", "conv_out")]
+    B = 3
+
+    def inputs(seed, keep=1.0):
+        o = vox.voxelize_frames([synth.cloud_ring(seed + f)[:int(keep * 20000)] for f in range(B)], device=dev)
+        return pillar_ops.mean_vfe(o["voxels"], o["voxel_num_points"]), o["voxel_coords"].int()
+
+    def eager(f, c):
+        with torch.no_grad():
+            return spconv.run_stages_pipelined(stages, spconv.SparseConvTensor(f, c, m.sparse_shape, B), speculate=False)
+
+    def same(got, want):
+        assert len(got) == len(want)
+        for a, b in zip(got, want):
+            assert a.spatial_shape == b.spatial_shape and torch.equal(a.indices, b.indices) and torch.equal(a.features, b.features)
+
+    g = spconv.GraphedStages(stages, m.sparse_shape, B, 4, 3 * 16000, dev)
+    cases = [inputs(6000), inputs(6100, 0.6), inputs(6200), inputs(6000)]
+    for f, c in cases:
+        same(g(f, c), eager(f, c))
+    assert g.replays == len(cases) and g.fallbacks == 0
+    f, c = cases[1]
+    same(eager(f, c), eager(f, c))                                 # an eager forward leaves rows in the grids ...
+    same(g(*cases[2]), eager(*cases[2]))                           # ... and the replay still starts from clean ones
+    # capacities far too small for this input: detected, answered by the exact path, graph rebuilt with more room
+    g2 = spconv.GraphedStages(stages, m.sparse_shape, B, 4, 3 * 16000, dev, headroom=1.0)
+    small = inputs(6300, 0.25)
+    same(g2(*small), eager(*small))                                # captured on a small cloud: small frozen capacities
+    same(g2(*cases[0]), eager(*cases[0]))
+    assert g2.fallbacks == 1
+    same(g2(*cases[0]), eager(*cases[0]))                          # rebuilt
+    assert g2.fallbacks == 1
+    # new weights -> new graph (the captured launches hold the old folded weights' addresses)
+    with torch.no_grad():
+        for p in m.parameters():
+            p.mul_(1.25)
+    want = eager(*cases[2])
+    assert not torch.equal(want[-1].features, g.outs[-1].features[:want[-1].features.shape[0]])
+    same(g(*cases[2]), want)
+    # and through the backbone module's opt-in switch
+    m.graph_capacity = 3 * 16000
+    with torch.no_grad():
+        out = m({"voxel_features": cases[0][0], "voxel_coords": cases[0][1], "batch_size": B})
+    same([out["encoded_spconv_tensor"]], [eager(*cases[0])[-1]])

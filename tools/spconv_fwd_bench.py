@@ -14,7 +14,8 @@ bd = {"voxels": o["voxels"], "voxel_num_points": o["voxel_num_points"], "voxel_c
 bd = vfe.MeanVFE(AttrDict(), 4)(bd)
 for cls in (spconv_backbone.VoxelBackBone8x, spconv_backbone.VoxelResBackBone8x):
     m = cls(AttrDict(), 4, [1408, 1600, 40]).to(dev).eval()
-    for label, ctx in (("module sequence", torch.enable_grad), ("fused inference", torch.no_grad)):
+    for label, ctx in (("module sequence", torch.enable_grad), ("fused inference", torch.no_grad), ("one hipGraph", torch.no_grad)):
+        m.graph_capacity = B * 16000 if label == "one hipGraph" else 0
         with ctx():
             for _ in range(3): m(dict(bd))
             e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
