@@ -139,17 +139,6 @@ def prebuild_rulebooks(module, indices, spatial_shape, batch_size, indice_dict, 
 _RULEBOOK_STREAMS = {}
 
 
-def _begin_first_strided(module, indices, spatial_shape, batch_size, indice_dict):
-    """starts the output-site search of `module`'s first table-building convolution when that is a strided one"""
-    for conv in _sparse_convs(module):
-        if conv.conv1x1:
-            continue
-        if conv.subm or conv.inverse or not conv.needs_new_rulebook(indice_dict) or indices.shape[0] == 0:
-            return None
-        return {id(conv): conv.begin_rulebook(indices, spatial_shape, batch_size, indice_dict)}
-    return None
-
-
 def _hand_tables_to(stream, indice_dict):
     """tables are allocated on the rulebook stream and read on the feature stream: tell the caching allocator"""
     for name, datas in indice_dict.items():
@@ -232,26 +221,30 @@ def _run_stages_pipelined(stages, x):
     indices.record_stream(rb)
     bs, idict = x.batch_size, x.indice_dict
     outs = []
+    ahead = int(__import__("os").environ.get("LIDAR_SPCONV_AHEAD", "1"))       # stages the rulebook stream is enqueued ahead of the features
     try:                                         # plain set_stream calls: the context manager costs the host ~10 us a time
         torch.cuda.set_stream(rb)
-        nxt = prebuild_rulebooks(stages[0], indices, x.spatial_shape, bs, idict)
-        ready = torch.cuda.Event()
-        ready.record(rb)
-        _hand_tables_to(feat, idict)
+        ready, built, nxt = [], 0, (indices, x.spatial_shape)
+
+        def build_next():
+            nonlocal built, nxt
+            nxt = prebuild_rulebooks(stages[built], nxt[0], nxt[1], bs, idict)
+            ev = torch.cuda.Event()
+            ev.record(rb)
+            ready.append(ev)
+            built += 1
+            _hand_tables_to(feat, idict)
+
+        while built < min(len(stages), 1 + ahead):
+            build_next()
         for s, stage in enumerate(stages):
-            pend = None
-            if s + 1 < len(stages):
-                pend = _begin_first_strided(stages[s + 1], nxt[0], nxt[1], bs, idict)
             torch.cuda.set_stream(feat)
-            feat.wait_event(ready)
+            feat.wait_event(ready[s])
             x = stage(x)
             outs.append(x)
             torch.cuda.set_stream(rb)
-            if s + 1 < len(stages):
-                nxt = prebuild_rulebooks(stages[s + 1], nxt[0], nxt[1], bs, idict, pend)
-                ready = torch.cuda.Event()
-                ready.record(rb)
-                _hand_tables_to(feat, idict)
+            if built < len(stages):
+                build_next()
     finally:
         torch.cuda.set_stream(feat)
     return outs
