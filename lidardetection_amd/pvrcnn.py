@@ -296,9 +296,20 @@ class PVRCNNKitti(SECONDKitti):
     @torch.no_grad()
     def forward(self, points, point_offsets, sizes):
         """points (sum N, 4), point_offsets (B+1) i32 device, sizes = the same frame sizes as a host list"""
+        # furthest-point sampling needs the raw points only and occupies one CU per frame for ~2 ms: it runs on a side stream
+        # under the trunk (sparse + BEV backbone, which fill the other CUs) instead of after it
+        dev = points.device
+        cur = torch.cuda.current_stream(dev)
+        side = self.__dict__.get("_kp_stream")
+        if side is None:
+            side = self.__dict__["_kp_stream"] = torch.cuda.Stream(dev)
+        side.wait_stream(cur)
+        with torch.cuda.stream(side):
+            kp = self.keypoints(points, point_offsets, sizes)
         multi_scale, bev, head = self.trunk(points, point_offsets)
         rois, roi_scores, roi_labels, _, _ = self.proposals(head)
-        kp = self.keypoints(points, point_offsets, sizes)
+        cur.wait_stream(side)
+        kp.record_stream(cur)
         before, fused = self.set_abstraction(points, sizes, kp, multi_scale, bev)
         point_scores = torch.sigmoid(self._dense["point_cls_layers"](before)).max(dim=-1)[0]
         rcnn_cls, boxes = self.roi_head(rois, kp, fused, point_scores)
