@@ -138,6 +138,11 @@ const void *lidar_nms_mask_ptr(void *ws, int batch, int n_max);
  * idx (M, nsample) zero-filled by the caller; an empty ball gets idx[.,0] = -1 */
 int lidar_ball_query_stack(int B, int M, float radius, int nsample, const float *new_xyz, const int *new_xyz_batch_cnt,
                            const float *xyz, const int *xyz_batch_cnt, int *idx, void *stream);
+/* two radii over the same centres / candidates in one pass (the scales of one StackSAModuleMSG): each idx_x equals what
+ * lidar_ball_query_stack returns for (radius_x, nsample_x); every squared distance is computed once */
+int lidar_ball_query_stack2(int B, int M, float radius_a, int nsample_a, float radius_b, int nsample_b, const float *new_xyz,
+                            const int *new_xyz_batch_cnt, const float *xyz, const int *xyz_batch_cnt, int *idx_a, int *idx_b,
+                            void *stream);
 /* group_points_wrapper_stack (group_points.cpp:31-69 fwd, group_points_gpu.cu:71-102): out (M, C, nsample) */
 int lidar_group_points_stack(int B, int M, int C, int nsample, const float *features, const int *features_batch_cnt,
                              const int *idx, const int *idx_batch_cnt, float *out, void *stream);

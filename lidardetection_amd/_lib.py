@@ -30,6 +30,7 @@ SIGNATURES = {
     "lidar_nms_batch_limited": (i32, [vp, vp, i32, i32, f32, i32, i32, vp, vp, vp, sz, vp]),
     "lidar_nms_mask_ptr": (vp, [vp, i32, i32]),
     "lidar_ball_query_stack": (i32, [i32, i32, f32, i32, vp, vp, vp, vp, vp, vp]),
+    "lidar_ball_query_stack2": (i32, [i32, i32, f32, i32, f32, i32, vp, vp, vp, vp, vp, vp, vp]),
     "lidar_group_points_stack": (i32, [i32, i32, i32, i32, vp, vp, vp, vp, vp, vp]),
     "lidar_group_rows_stack": (i32, [i32, i32, i32, i32, i32, i32, vp, vp, vp, vp, vp, vp, vp, vp]),
     "lidar_group_points_grad_stack": (i32, [i32, i32, i32, i32, i32, vp, vp, vp, vp, vp, vp]),

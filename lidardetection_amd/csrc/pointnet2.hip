@@ -50,24 +50,32 @@ __device__ __forceinline__ void pn_batch_of(const int *__restrict__ cnt, int B, 
 // (PV-RCNN has only 2 048 keypoints per frame: one thread per query leaves the GPU 1 % occupied).
 #define BQ_QPW 4                    // queries per wave, processed one after the other against each staged tile (2/4/8 measured: 4 best)
 #define BQ_QPB (4 * BQ_QPW)         // queries per 256-thread workgroup
-template <bool STACK>
-__global__ __launch_bounds__(PN_TPB) void ball_query_kernel(int B, int M, int N, float radius, int nsample,
-                                                            const float *__restrict__ new_xyz, const int *__restrict__ new_cnt,
-                                                            const float *__restrict__ xyz, const int *__restrict__ xyz_cnt,
-                                                            int *__restrict__ idx) {
+// NR radii in one pass (NR = 1 or 2): a multi-scale set-abstraction layer queries the same (centre, candidate) pairs once per
+// radius; here each squared distance is computed once and tested against every radius, each with its own hit list.
+template <bool STACK, int NR>
+__global__ __launch_bounds__(PN_TPB) void ball_query_kernel(int B, int M, int N, float radius_a, int nsample_a, float radius_b,
+                                                            int nsample_b, const float *__restrict__ new_xyz,
+                                                            const int *__restrict__ new_cnt, const float *__restrict__ xyz,
+                                                            const int *__restrict__ xyz_cnt, int *__restrict__ idx_a,
+                                                            int *__restrict__ idx_b) {
     __shared__ float s_x[PN_TILE], s_y[PN_TILE], s_z[PN_TILE];
     const int t = threadIdx.x, l = t & 63;
     const int wv = __builtin_amdgcn_readfirstlane(t >> 6);
     const int q0 = blockIdx.x * BQ_QPB;                       // first query (within the batch element for !STACK) of this block
     const size_t qbase = STACK ? 0 : (size_t)blockIdx.y * M;  // row offset of the batch element in new_xyz / idx
+    const float r2[2] = {radius_a * radius_a, radius_b * radius_b};
+    const int ns[2] = {nsample_a, nsample_b};
+    int *const out[2] = {idx_a, idx_b};
     // per-query state of this wave (wave-uniform)
-    int qb[BQ_QPW], cnt[BQ_QPW], first[BQ_QPW];
+    int qb[BQ_QPW], cnt[BQ_QPW][NR], first[BQ_QPW][NR];
     float qx[BQ_QPW], qy[BQ_QPW], qz[BQ_QPW];
     int b_lo = 0x7fffffff, b_hi = -1;
 #pragma unroll
     for (int i = 0; i < BQ_QPW; ++i) {
         const int q = q0 + wv * BQ_QPW + i;
-        cnt[i] = 0; first[i] = 0; qb[i] = -1;
+#pragma unroll
+        for (int r = 0; r < NR; ++r) { cnt[i][r] = 0; first[i][r] = 0; }
+        qb[i] = -1;
         qx[i] = qy[i] = qz[i] = 0.f;
         if (q < M) {
             if (STACK) {
@@ -91,7 +99,12 @@ __global__ __launch_bounds__(PN_TPB) void ball_query_kernel(int B, int M, int N,
             b_lo = b_hi = blockIdx.y;
         }
     }
-    const float r2 = radius * radius;
+    auto open_lists = [&](int i) {                            // does query i still collect hits for some radius?
+        bool o = false;
+#pragma unroll
+        for (int r = 0; r < NR; ++r) o = o || cnt[i][r] < ns[r];
+        return o;
+    };
     for (int bb = b_lo; bb <= b_hi; ++bb) {
         int bstart, bn;
         if (STACK) {
@@ -106,7 +119,7 @@ __global__ __launch_bounds__(PN_TPB) void ball_query_kernel(int B, int M, int N,
             const int tn = min(PN_TILE, bn - t0);
             bool wave_busy = false;
 #pragma unroll
-            for (int i = 0; i < BQ_QPW; ++i) wave_busy = wave_busy || (qb[i] == bb && cnt[i] < nsample);
+            for (int i = 0; i < BQ_QPW; ++i) wave_busy = wave_busy || (qb[i] == bb && open_lists(i));
             if (__syncthreads_or(wave_busy) == 0) break;      // every query of the block that uses this batch element is full
             for (int k = t; k < tn * 3; k += PN_TPB) {
                 const float v = xyz[((size_t)bstart + t0) * 3 + k];
@@ -116,21 +129,25 @@ __global__ __launch_bounds__(PN_TPB) void ball_query_kernel(int B, int M, int N,
             __syncthreads();
 #pragma unroll
             for (int i = 0; i < BQ_QPW; ++i) {
-                if (qb[i] != bb || cnt[i] >= nsample) continue;               // wave-uniform
-                int *o = idx + (qbase + q0 + wv * BQ_QPW + i) * (size_t)nsample;
+                if (qb[i] != bb || !open_lists(i)) continue;                  // wave-uniform
+                const size_t qrow = qbase + q0 + wv * BQ_QPW + i;
                 for (int k0 = 0; k0 < tn; k0 += 64) {
                     const int k = k0 + l;
                     const int kc = min(k, tn - 1);
                     const float d2 = pn_dist2(qx[i], qy[i], qz[i], s_x[kc], s_y[kc], s_z[kc]);
-                    const bool hit = (k < tn) && (d2 < r2);
-                    const unsigned long long bal = __ballot(hit);
-                    if (bal) {
-                        if (cnt[i] == 0) first[i] = t0 + k0 + __builtin_ctzll(bal);
-                        const int pos = cnt[i] + __popcll(bal & lanemask_lt());
-                        if (hit && pos < nsample) o[pos] = t0 + k;
-                        cnt[i] += __popcll(bal);
-                        if (cnt[i] >= nsample) break;
+#pragma unroll
+                    for (int r = 0; r < NR; ++r) {
+                        if (cnt[i][r] >= ns[r]) continue;                      // wave-uniform
+                        const bool hit = (k < tn) && (d2 < r2[r]);
+                        const unsigned long long bal = __ballot(hit);
+                        if (bal) {
+                            if (cnt[i][r] == 0) first[i][r] = t0 + k0 + __builtin_ctzll(bal);
+                            const int pos = cnt[i][r] + __popcll(bal & lanemask_lt());
+                            if (hit && pos < ns[r]) out[r][qrow * (size_t)ns[r] + pos] = t0 + k;
+                            cnt[i][r] += __popcll(bal);
+                        }
                     }
+                    if (!open_lists(i)) break;
                 }
             }
         }
@@ -140,11 +157,14 @@ __global__ __launch_bounds__(PN_TPB) void ball_query_kernel(int B, int M, int N,
     for (int i = 0; i < BQ_QPW; ++i) {
         const int q = q0 + wv * BQ_QPW + i;
         if (q >= M) continue;
-        int *o = idx + (qbase + q) * (size_t)nsample;
-        if (cnt[i] == 0) {
-            if (STACK && l == 0) o[0] = -1;
-        } else {
-            for (int p = cnt[i] + l; p < nsample; p += 64) o[p] = first[i];
+#pragma unroll
+        for (int r = 0; r < NR; ++r) {
+            int *o = out[r] + (qbase + q) * (size_t)ns[r];
+            if (cnt[i][r] == 0) {
+                if (STACK && l == 0) o[0] = -1;
+            } else {
+                for (int p = cnt[i][r] + l; p < ns[r]; p += 64) o[p] = first[i][r];
+            }
         }
     }
 }
@@ -155,9 +175,22 @@ LIDAR_EXPORT int lidar_ball_query_stack(int B, int M, float radius, int nsample,
     if (B <= 0 || M < 0 || nsample <= 0) return LIDAR_ERR_ARG;
     if (M == 0) return LIDAR_OK;
     if (!new_xyz || !new_xyz_batch_cnt || !xyz || !xyz_batch_cnt || !idx) return LIDAR_ERR_ARG;
-    hipLaunchKernelGGL(ball_query_kernel<true>, dim3(divup(M, BQ_QPB)), dim3(PN_TPB), 0, (hipStream_t)stream, B, M, 0,
-                       radius, nsample, new_xyz, new_xyz_batch_cnt, xyz, xyz_batch_cnt, idx);
+    hipLaunchKernelGGL((ball_query_kernel<true, 1>), dim3(divup(M, BQ_QPB)), dim3(PN_TPB), 0, (hipStream_t)stream, B, M, 0,
+                       radius, nsample, 0.f, 0, new_xyz, new_xyz_batch_cnt, xyz, xyz_batch_cnt, idx, (int *)nullptr);
     return lidar_check_launch("lidar_ball_query_stack");
+}
+
+// two radii over the same centres and candidates in one pass (StackSAModuleMSG's scales): idx_a (M, nsample_a), idx_b (M, nsample_b),
+// each exactly what lidar_ball_query_stack returns for its radius
+LIDAR_EXPORT int lidar_ball_query_stack2(int B, int M, float radius_a, int nsample_a, float radius_b, int nsample_b,
+                                         const float *new_xyz, const int *new_xyz_batch_cnt, const float *xyz,
+                                         const int *xyz_batch_cnt, int *idx_a, int *idx_b, void *stream) {
+    if (B <= 0 || M < 0 || nsample_a <= 0 || nsample_b <= 0) return LIDAR_ERR_ARG;
+    if (M == 0) return LIDAR_OK;
+    if (!new_xyz || !new_xyz_batch_cnt || !xyz || !xyz_batch_cnt || !idx_a || !idx_b) return LIDAR_ERR_ARG;
+    hipLaunchKernelGGL((ball_query_kernel<true, 2>), dim3(divup(M, BQ_QPB)), dim3(PN_TPB), 0, (hipStream_t)stream, B, M, 0,
+                       radius_a, nsample_a, radius_b, nsample_b, new_xyz, new_xyz_batch_cnt, xyz, xyz_batch_cnt, idx_a, idx_b);
+    return lidar_check_launch("lidar_ball_query_stack2");
 }
 
 LIDAR_EXPORT int lidar_ball_query_batch(int b, int n, int m, float radius, int nsample, const float *new_xyz,
@@ -165,8 +198,8 @@ LIDAR_EXPORT int lidar_ball_query_batch(int b, int n, int m, float radius, int n
     if (b <= 0 || n < 0 || m < 0 || nsample <= 0) return LIDAR_ERR_ARG;
     if (m == 0) return LIDAR_OK;
     if (!new_xyz || !xyz || !idx) return LIDAR_ERR_ARG;
-    hipLaunchKernelGGL(ball_query_kernel<false>, dim3(divup(m, BQ_QPB), b), dim3(PN_TPB), 0, (hipStream_t)stream, b, m, n,
-                       radius, nsample, new_xyz, (const int *)nullptr, xyz, (const int *)nullptr, idx);
+    hipLaunchKernelGGL((ball_query_kernel<false, 1>), dim3(divup(m, BQ_QPB), b), dim3(PN_TPB), 0, (hipStream_t)stream, b, m, n,
+                       radius, nsample, 0.f, 0, new_xyz, (const int *)nullptr, xyz, (const int *)nullptr, idx, (int *)nullptr);
     return lidar_check_launch("lidar_ball_query_batch");
 }
 

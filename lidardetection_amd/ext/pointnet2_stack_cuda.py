@@ -13,6 +13,15 @@ def ball_query_wrapper(B, M, radius, nsample, new_xyz, new_xyz_batch_cnt, xyz, x
     return 1
 
 
+def ball_query2_wrapper(B, M, radius_a, nsample_a, radius_b, nsample_b, new_xyz, new_xyz_batch_cnt, xyz, xyz_batch_cnt, idx_a, idx_b):
+    """not in the reference's module: two radii in one pass (include/lidar_hip.h: lidar_ball_query_stack2)"""
+    _lib.require_cuda(new_xyz, new_xyz_batch_cnt, xyz, xyz_batch_cnt, idx_a, idx_b)
+    _lib.check(_lib.lib().lidar_ball_query_stack2(B, M, float(radius_a), nsample_a, float(radius_b), nsample_b, _p(new_xyz),
+                                                  _p(new_xyz_batch_cnt), _p(xyz), _p(xyz_batch_cnt), _p(idx_a), _p(idx_b), _S()),
+               "lidar_ball_query_stack2")
+    return 1
+
+
 def furthest_point_sampling_wrapper(b, n, m, points, temp, idx):
     """sampling.cpp: points (b,n,3), temp (b,n) == 1e10, idx (b,m) int32."""
     _lib.require_cuda(points, temp, idx)

@@ -81,11 +81,17 @@ class StackSAModuleMSG(nn.Module):
         feats = None if features is None else features.contiguous()
         width = 0 if feats is None else feats.shape[1]
         per_scale = []
+        idxs = [C.zeros_i32((n_query, g.nsample), xyz.device) for g in self.groupers]
+        ga = self.groupers
+        for k in range(0, len(ga) - 1, 2):                   # scales in pairs: one pass over the (centre, candidate) distances
+            native.ball_query2_wrapper(n_batch, n_query, ga[k].radius, ga[k].nsample, ga[k + 1].radius, ga[k + 1].nsample, new_xyz,
+                                       new_xyz_batch_cnt, xyz, xyz_batch_cnt, idxs[k], idxs[k + 1])
+        if len(ga) % 2:
+            native.ball_query_wrapper(n_batch, n_query, ga[-1].radius, ga[-1].nsample, new_xyz, new_xyz_batch_cnt, xyz,
+                                      xyz_batch_cnt, idxs[-1])
         for k, grouper in enumerate(self.groupers):
             layers = self._folded_layers(k)
-            idx = C.zeros_i32((n_query, grouper.nsample), xyz.device)
-            native.ball_query_wrapper(n_batch, n_query, grouper.radius, grouper.nsample, new_xyz, new_xyz_batch_cnt, xyz,
-                                      xyz_batch_cnt, idx)
+            idx = idxs[k]
             stride = layers[0][0].shape[0]
             rows = C.empty_f32((n_query * grouper.nsample, stride), xyz.device)
             native.group_rows_wrapper(n_batch, n_query, width, grouper.nsample, grouper.use_xyz, stride, xyz, new_xyz, feats,

@@ -231,3 +231,23 @@ def test_batch_set_abstraction_and_fp_modules_vs_oracle(dev):
         out = bfp(t(bx), nx, t(bf), nfeat)
     assert out.shape == (B, 16, N)
     _close(out.cpu().numpy(), sa_oracle.batch_fp(bfp, bx, nx_o, bf, nfeat.cpu().numpy()), "PointnetFPModule")
+
+
+@pytest.mark.parametrize("ra,na,rb,nb", [(0.4, 16, 0.8, 16), (1.6, 32, 0.2, 8), (0.01, 4, 3.0, 64)])
+def test_ball_query_two_radii_in_one_pass(dev, ra, na, rb, nb):
+    """lidar_ball_query_stack2 (both scales of a StackSAModuleMSG in one pass over the distances) returns, for each radius,
+    exactly the single-radius result — the oracle's (ball_query_gpu.cu:16-66): same indices, same -1 markers, ragged batch
+    with an empty frame, a list that fills long before the other."""
+    from lidardetection_amd.ext import pointnet2_stack_cuda as native
+    xyz, xc, new, nc = _stack_scene(21)
+    new[7] += 60.0                                                   # nothing in reach of either radius
+    t = lambda a: torch.from_numpy(a).to(dev)
+    ia = torch.zeros((len(new), na), dtype=torch.int32, device=dev)
+    ib = torch.zeros((len(new), nb), dtype=torch.int32, device=dev)
+    native.ball_query2_wrapper(len(xc), len(new), ra, na, rb, nb, t(new), t(nc), t(xyz), t(xc), ia, ib)
+    for got, r, n in ((ia, ra, na), (ib, rb, nb)):
+        want = c_oracle.ball_query_stack(r, n, xyz, xc, new, nc)
+        got = got.cpu().numpy()
+        empty = want[:, 0] == -1
+        assert empty[7] and np.array_equal(got[:, 0] == -1, empty)
+        assert np.array_equal(got[~empty], want[~empty])
