@@ -153,6 +153,12 @@ int lidar_group_points_stack(int B, int M, int C, int nsample, const float *feat
 int lidar_group_rows_stack(int B, int M, int C, int nsample, int use_xyz, int stride, const float *xyz, const float *new_xyz,
                            const float *features, const int *features_batch_cnt, const int *idx, const int *idx_batch_cnt,
                            float *out, void *stream);
+/* The same layer with the first linear map moved in front of the gather (it commutes with it): table (N, H) =
+ * [xyz | features] @ W + b per SOURCE point, query_term (M, H) = new_xyz @ W_xyz per query (or null), and
+ * out (M, nsample, H) = relu(table[idx] - query_term[m]); an empty ball gives empty_row (H) = relu(b).  H % 4 == 0. */
+int lidar_group_rows_affine_stack(int B, int M, int H, int nsample, const float *table, const float *query_term,
+                                  const float *empty_row, const int *features_batch_cnt, const int *idx, const int *idx_batch_cnt,
+                                  float *out, void *stream);
 int lidar_group_points_grad_stack(int B, int M, int C, int N, int nsample, const float *grad_out, const int *idx,
                                   const int *idx_batch_cnt, const int *features_batch_cnt, float *grad_features,
                                   void *stream);

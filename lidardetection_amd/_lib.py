@@ -33,6 +33,7 @@ SIGNATURES = {
     "lidar_ball_query_stack2": (i32, [i32, i32, f32, i32, f32, i32, vp, vp, vp, vp, vp, vp, vp]),
     "lidar_group_points_stack": (i32, [i32, i32, i32, i32, vp, vp, vp, vp, vp, vp]),
     "lidar_group_rows_stack": (i32, [i32, i32, i32, i32, i32, i32, vp, vp, vp, vp, vp, vp, vp, vp]),
+    "lidar_group_rows_affine_stack": (i32, [i32, i32, i32, i32, vp, vp, vp, vp, vp, vp, vp, vp]),
     "lidar_group_points_grad_stack": (i32, [i32, i32, i32, i32, i32, vp, vp, vp, vp, vp, vp]),
     "lidar_furthest_point_sampling": (i32, [i32, i32, i32, vp, vp, vp, vp]),
     "lidar_three_nn_stack": (i32, [i32, i32, vp, vp, vp, vp, vp, vp, vp]),

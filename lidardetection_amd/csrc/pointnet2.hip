@@ -294,6 +294,58 @@ __global__ __launch_bounds__(256) void group_rows_stack_kernel(int B, int M, int
     }
 }
 
+// The first layer of the shared MLP commutes with the gather: [xyz[idx] - new_xyz[m] | features[idx]] @ W + b
+//   == ([xyz | features] @ W + b)[idx]  -  (new_xyz @ W_xyz)[m],
+// i.e. ONE small GEMM per source point (N rows) instead of one per (query, sample) pair (M * nsample rows, 170 x more for
+// PV-RCNN's RoI-grid pooling), after which the layer is a gather of H-wide rows, a per-query subtraction and the ReLU:
+//   out (M, ns, H) = relu(table[idx] - query_term[m]),   an empty ball (idx[m][0] < 0) -> empty_row (= relu(b): zero inputs).
+// H % 4 == 0; query_term may be null (use_xyz == False).
+__global__ __launch_bounds__(256) void group_rows_affine_stack_kernel(int B, int M, int H4, int ns, const float4 *__restrict__ table,
+                                                                      const float4 *__restrict__ query_term,
+                                                                      const float4 *__restrict__ empty_row,
+                                                                      const int *__restrict__ feat_cnt, const int *__restrict__ idx,
+                                                                      const int *__restrict__ idx_cnt, float4 *__restrict__ out) {
+    __shared__ int s_start;
+    const int m = blockIdx.x, t = threadIdx.x;
+    if (t == 0) {
+        int bs, st, nn;
+        pn_batch_of(idx_cnt, B, m, feat_cnt, bs, st, nn);
+        s_start = st;
+    }
+    __syncthreads();
+    const int start = s_start;
+    const int *row = idx + (size_t)m * ns;
+    const bool empty = row[0] < 0;
+    float4 *o = out + (size_t)m * ns * H4;
+    for (int e = t; e < ns * H4; e += 256) {
+        const int s = e / H4, c = e - s * H4;
+        float4 v;
+        if (empty) {
+            v = empty_row[c];
+        } else {
+            v = table[((size_t)start + row[s]) * H4 + c];
+            if (query_term) {
+                const float4 q = query_term[(size_t)m * H4 + c];
+                v.x -= q.x; v.y -= q.y; v.z -= q.z; v.w -= q.w;
+            }
+            v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f);
+        }
+        o[e] = v;
+    }
+}
+
+LIDAR_EXPORT int lidar_group_rows_affine_stack(int B, int M, int H, int nsample, const float *table, const float *query_term,
+                                               const float *empty_row, const int *features_batch_cnt, const int *idx,
+                                               const int *idx_batch_cnt, float *out, void *stream) {
+    if (B <= 0 || M < 0 || H <= 0 || (H & 3) || nsample <= 0) return LIDAR_ERR_ARG;
+    if (M == 0) return LIDAR_OK;
+    if (!table || !empty_row || !features_batch_cnt || !idx || !idx_batch_cnt || !out) return LIDAR_ERR_ARG;
+    hipLaunchKernelGGL(group_rows_affine_stack_kernel, dim3(M), dim3(256), 0, (hipStream_t)stream, B, M, H / 4, nsample,
+                       (const float4 *)table, (const float4 *)query_term, (const float4 *)empty_row, features_batch_cnt, idx,
+                       idx_batch_cnt, (float4 *)out);
+    return lidar_check_launch("lidar_group_rows_affine_stack");
+}
+
 // idx: the RAW ball-query result (-1 in column 0 marks an empty ball).  features may be null (C = 0, use_xyz required).
 LIDAR_EXPORT int lidar_group_rows_stack(int B, int M, int C, int nsample, int use_xyz, int stride, const float *xyz,
                                         const float *new_xyz, const float *features, const int *features_batch_cnt, const int *idx,

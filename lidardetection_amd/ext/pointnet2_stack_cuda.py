@@ -45,6 +45,15 @@ def group_rows_wrapper(B, M, C, nsample, use_xyz, stride, xyz, new_xyz, features
     return 1
 
 
+def group_rows_affine_wrapper(B, M, H, nsample, table, query_term, empty_row, features_batch_cnt, idx, idx_batch_cnt, out):
+    """not in the reference's module: relu(table[idx] - query_term[m]) rows (include/lidar_hip.h: lidar_group_rows_affine_stack)"""
+    _lib.require_cuda(table, query_term, empty_row, features_batch_cnt, idx, idx_batch_cnt, out)
+    _lib.check(_lib.lib().lidar_group_rows_affine_stack(B, M, H, nsample, _p(table), _p(query_term), _p(empty_row),
+                                                        _p(features_batch_cnt), _p(idx), _p(idx_batch_cnt), _p(out), _S()),
+               "lidar_group_rows_affine_stack")
+    return 1
+
+
 def group_points_grad_wrapper(B, M, C, N, nsample, grad_out, idx, idx_batch_cnt, features_batch_cnt, grad_features):
     _lib.require_cuda(grad_out, idx, idx_batch_cnt, features_batch_cnt, grad_features)
     _lib.check(_lib.lib().lidar_group_points_grad_stack(B, M, C, N, nsample, _p(grad_out), _p(idx), _p(idx_batch_cnt),

@@ -52,7 +52,7 @@ class StackSAModuleMSG(nn.Module):
                     shift = bn.bias - bn.running_mean * scale
                     if conv.bias is not None:
                         shift = shift + conv.bias * scale
-                    pad = (-w.shape[0]) % 4
+                    pad = (-w.shape[0]) % 4 if not layers else 0       # first layer only: the gathered rows' pitch
                     if pad:
                         w = torch.cat((w, w.new_zeros(pad, w.shape[1])), dim=0)
                     layers.append((w.contiguous(), shift.contiguous()))
@@ -89,14 +89,32 @@ class StackSAModuleMSG(nn.Module):
         if len(ga) % 2:
             native.ball_query_wrapper(n_batch, n_query, ga[-1].radius, ga[-1].nsample, new_xyz, new_xyz_batch_cnt, xyz,
                                       xyz_batch_cnt, idxs[-1])
+        src = None
         for k, grouper in enumerate(self.groupers):
             layers = self._folded_layers(k)
             idx = idxs[k]
-            stride = layers[0][0].shape[0]
-            rows = C.empty_f32((n_query * grouper.nsample, stride), xyz.device)
-            native.group_rows_wrapper(n_batch, n_query, width, grouper.nsample, grouper.use_xyz, stride, xyz, new_xyz, feats,
-                                      xyz_batch_cnt, idx, new_xyz_batch_cnt, rows)
-            for w, shift in layers:
+            w1, b1 = layers[0]
+            if w1.shape[1] % 4 == 0:
+                # layer 1 in front of the gather (it commutes with it): one GEMM row per SOURCE point instead of one per
+                # (query, sample) pair; the layer is then a gather of its output rows, a per-query term and the ReLU
+                if grouper.use_xyz:
+                    if src is None:
+                        src = xyz if feats is None else torch.cat((xyz, feats), dim=1)
+                    table = torch.addmm(b1, src, w1[:src.shape[1]])
+                    query_term = torch.mm(new_xyz, w1[:3])
+                else:
+                    table, query_term = torch.addmm(b1, feats, w1[:width]), None
+                rows = C.empty_f32((n_query * grouper.nsample, w1.shape[1]), xyz.device)
+                native.group_rows_affine_wrapper(n_batch, n_query, w1.shape[1], grouper.nsample, table, query_term,
+                                                 torch.relu(b1), xyz_batch_cnt, idx, new_xyz_batch_cnt, rows)
+                rest = layers[1:]
+            else:
+                stride = w1.shape[0]
+                rows = C.empty_f32((n_query * grouper.nsample, stride), xyz.device)
+                native.group_rows_wrapper(n_batch, n_query, width, grouper.nsample, grouper.use_xyz, stride, xyz, new_xyz, feats,
+                                          xyz_batch_cnt, idx, new_xyz_batch_cnt, rows)
+                rest = layers
+            for w, shift in rest:
                 rows = C.addmm_act(shift, rows, w)
             per_scale.append(rows.view(n_query, grouper.nsample, -1).amax(dim=1))
         return new_xyz, torch.cat(per_scale, dim=1)

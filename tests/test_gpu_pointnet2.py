@@ -197,6 +197,15 @@ def test_stack_set_abstraction_and_fp_modules_vs_oracle(dev):
                "StackSAModuleMSG, xyz only")
         _close(sa_f(t(xyz), t(xc), t(new), t(nc), t(feat))[1].cpu().numpy(), sa_oracle.stack_sa_msg(sa_f, xyz, xc, new, nc, feat),
                "StackSAModuleMSG, use_xyz=False")
+        # a first layer whose width is not a multiple of 4 takes the row-gather path (lidar_group_rows_stack) instead of the
+        # layer-1-before-the-gather path (lidar_group_rows_affine_stack)
+        sa_o = _perturb_bn(smod.StackSAModuleMSG(radii=[0.8], nsamples=[16], mlps=[[8, 6, 10]]).to(dev), 7)
+        _close(sa_o(t(xyz), t(xc), t(new), t(nc), t(feat))[1].cpu().numpy(), sa_oracle.stack_sa_msg(sa_o, xyz, xc, new, nc, feat),
+               "StackSAModuleMSG, odd first width")
+        # far from the origin the commuted first layer subtracts two large products: still inside the tolerance
+        far = np.array([60.0, -35.0, 1.0], np.float32)
+        _close(sa(t(xyz + far), t(xc), t(new + far), t(nc), t(feat))[1].cpu().numpy(),
+               sa_oracle.stack_sa_msg(sa, xyz + far, xc, new + far, nc, feat), "StackSAModuleMSG, 70 m from the origin")
     fp = _perturb_bn(smod.StackPointnetFPModule(mlp=[48 + 8, 32]).to(dev), 2)
     with torch.no_grad():
         out = fp(t(xyz), t(xc), t(new), t(nc), unknown_feats=t(feat), known_feats=nf)
