@@ -143,6 +143,13 @@ int lidar_ball_query_stack(int B, int M, float radius, int nsample, const float 
 int lidar_ball_query_stack2(int B, int M, float radius_a, int nsample_a, float radius_b, int nsample_b, const float *new_xyz,
                             const int *new_xyz_batch_cnt, const float *xyz, const int *xyz_batch_cnt, int *idx_a, int *idx_b,
                             void *stream);
+/* The same lists through a cell grid over the candidates (csrc/pointnet2.hip: one binning pass per batch element, then three cell
+ * rows per centre instead of every candidate; hits are put back into index order at the end).  N = rows of xyz; idx_b == NULL or
+ * radius_b <= 0: one radius; nsample <= 64.  ws: lidar_ball_query_grid_workspace_bytes(B, N), uninitialised. */
+size_t lidar_ball_query_grid_workspace_bytes(int B, int N);
+int lidar_ball_query_stack_grid(int B, int M, int N, float radius_a, int nsample_a, float radius_b, int nsample_b,
+                                const float *new_xyz, const int *new_xyz_batch_cnt, const float *xyz, const int *xyz_batch_cnt,
+                                int *idx_a, int *idx_b, void *ws, size_t ws_bytes, void *stream);
 /* group_points_wrapper_stack (group_points.cpp:31-69 fwd, group_points_gpu.cu:71-102): out (M, C, nsample) */
 int lidar_group_points_stack(int B, int M, int C, int nsample, const float *features, const int *features_batch_cnt,
                              const int *idx, const int *idx_batch_cnt, float *out, void *stream);

@@ -31,6 +31,8 @@ SIGNATURES = {
     "lidar_nms_mask_ptr": (vp, [vp, i32, i32]),
     "lidar_ball_query_stack": (i32, [i32, i32, f32, i32, vp, vp, vp, vp, vp, vp]),
     "lidar_ball_query_stack2": (i32, [i32, i32, f32, i32, f32, i32, vp, vp, vp, vp, vp, vp, vp]),
+    "lidar_ball_query_grid_workspace_bytes": (sz, [i32, i32]),
+    "lidar_ball_query_stack_grid": (i32, [i32, i32, i32, f32, i32, f32, i32, vp, vp, vp, vp, vp, vp, vp, sz, vp]),
     "lidar_group_points_stack": (i32, [i32, i32, i32, i32, vp, vp, vp, vp, vp, vp]),
     "lidar_group_rows_stack": (i32, [i32, i32, i32, i32, i32, i32, vp, vp, vp, vp, vp, vp, vp, vp]),
     "lidar_group_rows_affine_stack": (i32, [i32, i32, i32, i32, vp, vp, vp, vp, vp, vp, vp, vp]),

@@ -193,6 +193,242 @@ LIDAR_EXPORT int lidar_ball_query_stack2(int B, int M, float radius_a, int nsamp
     return lidar_check_launch("lidar_ball_query_stack2");
 }
 
+// ------------------------------------------------------------------ ball query through a cell grid (stack layout)
+// The kernels above test every (centre, candidate) pair of a batch element: 20 000 tests per centre where a 0.4 - 1.6 m ball
+// holds a few dozen points.  Here the candidates of each batch element are first binned into an x / y grid whose cells are at
+// least one (largest) radius wide — one workgroup per element: bounding box, LDS histogram, scan, scatter of (x, y, z, index) —
+// and a centre then tests only the three cell rows around it (each row's three cells are contiguous in the binned order).
+// Hits arrive in no particular index order, so "the first nsample in index order" (ball_query_gpu.cu:16-66) is restored at
+// the end: every hit's rank among the hits is counted and the nsample lowest indices are written in ascending order — the same
+// lists, the same -1 marker, the same first-hit padding as the exhaustive kernel (tests compare them element for element).
+// A point within r of a centre is at most one cell away in x and in y: the cell coordinate is a monotone function of the
+// coordinate and the cell width exceeds r by 0.1 % (rounding moves a quotient by ~1e-5 of a cell).
+#define BQG_DIM 128                                 // grid cells per axis at most (LDS histogram: 128 * 128 ints)
+#define BQG_CAP 128                                 // slots of a hit list (per centre and radius); cut down to nsample when nearly full
+struct BqgGrid { float xlo, ylo, inv, pad; int gw, gh, start, n; };   // per batch element (start / n: its rows in xyz)
+
+__device__ __forceinline__ int bqg_cell1(float v, float lo, float inv, int g) {
+    const float q = (v - lo) * inv;
+    return q >= 0.f ? min((int)q, g - 1) : 0;       // NaN -> 0
+}
+
+__global__ __launch_bounds__(1024) void bqg_build_kernel(int B, const float *__restrict__ xyz, const int *__restrict__ xyz_cnt,
+                                                         float cell_min, BqgGrid *__restrict__ grids, int *__restrict__ cell_start,
+                                                         float4 *__restrict__ binned) {
+    __shared__ int s_hist[BQG_DIM * BQG_DIM];
+    __shared__ float s_red[4][16];
+    __shared__ int s_wsum[16];
+    const int b = blockIdx.x, t = threadIdx.x, l = t & 63, wv = t >> 6;
+    int start = 0;
+    for (int k = 0; k < b; ++k) start += xyz_cnt[k];
+    const int n = xyz_cnt[b];
+    const float *P = xyz + (size_t)start * 3;
+    float xlo = 3.0e38f, xhi = -3.0e38f, ylo = 3.0e38f, yhi = -3.0e38f;
+    for (int k = t; k < n; k += 1024) {
+        const float x = P[(size_t)k * 3], y = P[(size_t)k * 3 + 1];
+        if (fabsf(x) < 1.0e30f) { xlo = fminf(xlo, x); xhi = fmaxf(xhi, x); }     // (NaN / inf stay out of the box)
+        if (fabsf(y) < 1.0e30f) { ylo = fminf(ylo, y); yhi = fmaxf(yhi, y); }
+    }
+#pragma unroll
+    for (int d = 32; d >= 1; d >>= 1) {
+        xlo = fminf(xlo, __shfl_xor(xlo, d, 64)); xhi = fmaxf(xhi, __shfl_xor(xhi, d, 64));
+        ylo = fminf(ylo, __shfl_xor(ylo, d, 64)); yhi = fmaxf(yhi, __shfl_xor(yhi, d, 64));
+    }
+    if (l == 0) { s_red[0][wv] = xlo; s_red[1][wv] = xhi; s_red[2][wv] = ylo; s_red[3][wv] = yhi; }
+    for (int k = t; k < BQG_DIM * BQG_DIM; k += 1024) s_hist[k] = 0;
+    __syncthreads();
+#pragma unroll
+    for (int q = 0; q < 16; ++q) {
+        xlo = fminf(xlo, s_red[0][q]); xhi = fmaxf(xhi, s_red[1][q]); ylo = fminf(ylo, s_red[2][q]); yhi = fmaxf(yhi, s_red[3][q]);
+    }
+    if (!(xhi >= xlo)) { xlo = 0.f; xhi = 0.f; }                                   // no finite point
+    if (!(yhi >= ylo)) { ylo = 0.f; yhi = 0.f; }
+    const float cell = fmaxf(cell_min, fmaxf(xhi - xlo, yhi - ylo) * (1.0f / (BQG_DIM - 1)));
+    const float inv = 1.0f / cell;
+    const int gw = min(BQG_DIM, (int)((xhi - xlo) * inv) + 1), gh = min(BQG_DIM, (int)((yhi - ylo) * inv) + 1);
+    auto cell_of = [&](int k) {
+        return bqg_cell1(P[(size_t)k * 3 + 1], ylo, inv, gh) * gw + bqg_cell1(P[(size_t)k * 3], xlo, inv, gw);
+    };
+    for (int k = t; k < n; k += 1024) atomicAdd(&s_hist[cell_of(k)], 1);
+    __syncthreads();
+    {   // exclusive scan of the BQG_DIM^2 counts: 16 per thread
+        int loc[16], sum = 0;
+#pragma unroll
+        for (int q = 0; q < 16; ++q) { loc[q] = s_hist[t * 16 + q]; sum += loc[q]; }
+        const int inc = wave_incl_scan(sum);
+        if (l == 63) s_wsum[wv] = inc;
+        __syncthreads();
+        int base = inc - sum;
+        for (int q = 0; q < wv; ++q) base += s_wsum[q];
+        int *cs = cell_start + (size_t)b * (BQG_DIM * BQG_DIM + 1);
+#pragma unroll
+        for (int q = 0; q < 16; ++q) {
+            cs[t * 16 + q] = base;
+            s_hist[t * 16 + q] = base;                                             // becomes the scatter cursor
+            base += loc[q];
+        }
+        if (t == 1023) cs[BQG_DIM * BQG_DIM] = base;
+    }
+    __syncthreads();
+    for (int k = t; k < n; k += 1024) {
+        const int pos = atomicAdd(&s_hist[cell_of(k)], 1);
+        binned[(size_t)start + pos] = make_float4(P[(size_t)k * 3], P[(size_t)k * 3 + 1], P[(size_t)k * 3 + 2], __int_as_float(k));
+    }
+    if (t == 0) grids[b] = BqgGrid{xlo, ylo, inv, 0.f, gw, gh, start, n};
+}
+
+// NR hit lists per wave in LDS.  Only the nsample LOWEST indices matter: whenever a list is about to outgrow its BQG_CAP slots
+// it is cut down to the nsample lowest, and from then on a hit must also lie below the highest index kept (`lim`) — in a dense
+// neighbourhood (hundreds of points inside the ball) almost every later hit is dropped by that one comparison.
+template <int NR>
+__global__ __launch_bounds__(256) void bqg_query_kernel(int B, int M, float radius_a, int nsample_a, float radius_b, int nsample_b,
+                                                        const float *__restrict__ new_xyz, const int *__restrict__ new_cnt,
+                                                        const BqgGrid *__restrict__ grids, const int *__restrict__ cell_start,
+                                                        const float4 *__restrict__ binned, int *__restrict__ idx_a,
+                                                        int *__restrict__ idx_b) {
+    __shared__ int s_hits[4][NR][BQG_CAP];
+    const int t = threadIdx.x, l = t & 63;
+    const int wv = __builtin_amdgcn_readfirstlane(t >> 6);
+    const float r2[2] = {radius_a * radius_a, radius_b * radius_b};
+    const int ns[2] = {nsample_a, nsample_b};
+    int *const out[2] = {idx_a, idx_b};
+    // rank of every entry among the H entries of list[] (indices are distinct); entries with rank < nsel go to dst[rank]
+    auto select_lowest = [&](const int *list, int H, int nsel, int *dst) {
+#pragma unroll
+        for (int u = 0; u < BQG_CAP / 64; ++u) {
+            const int i = u * 64 + l;
+            if (u * 64 >= H) break;                                                // wave-uniform
+            const int v = i < H ? list[i] : 0x7fffffff;
+            int rank = 0;
+            for (int j = 0; j < H; ++j) rank += (list[j] < v) ? 1 : 0;
+            if (i < H && rank < nsel) dst[rank] = v;
+        }
+    };
+    for (int qi = 0; qi < BQ_QPW; ++qi) {
+        const int q = (blockIdx.x * 4 + wv) * BQ_QPW + qi;                         // wave-uniform
+        if (q >= M) break;
+        int bs = 0, acc = new_cnt[0];
+        for (int k = 1; k < B; ++k) {
+            if (q < acc) break;
+            acc += new_cnt[k];
+            bs = k;
+        }
+        const BqgGrid g = grids[bs];
+        const float qx = new_xyz[(size_t)q * 3], qy = new_xyz[(size_t)q * 3 + 1], qz = new_xyz[(size_t)q * 3 + 2];
+        const int cx = bqg_cell1(qx, g.xlo, g.inv, g.gw), cy = bqg_cell1(qy, g.ylo, g.inv, g.gh);
+        const int *cs = cell_start + (size_t)bs * (BQG_DIM * BQG_DIM + 1);
+        // the (up to) three cell rows around the centre: ranges of the binned order, requested together
+        const int x0 = max(cx - 1, 0), x1 = min(cx + 1, g.gw - 1) + 1;
+        int p0[3], p1[3];
+#pragma unroll
+        for (int d = 0; d < 3; ++d) {
+            const int y = cy - 1 + d;
+            const bool ok = y >= 0 && y < g.gh;
+            const int yc = min(max(y, 0), g.gh - 1);
+            p0[d] = cs[yc * g.gw + x0];
+            p1[d] = ok ? cs[yc * g.gw + x1] : p0[d];
+        }
+        int cnt[NR], lim[NR];
+#pragma unroll
+        for (int r = 0; r < NR; ++r) { cnt[r] = 0; lim[r] = 0x7fffffff; }
+#pragma unroll
+        for (int d = 0; d < 3; ++d) {
+            for (int p = p0[d]; p < p1[d]; p += 64) {
+                const int k = p + l;
+                const float4 c = binned[(size_t)g.start + min(k, p1[d] - 1)];
+                const float d2 = pn_dist2(qx, qy, qz, c.x, c.y, c.z);
+                const int ci = __float_as_int(c.w);
+#pragma unroll
+                for (int r = 0; r < NR; ++r) {
+                    const bool hit = (k < p1[d]) && (d2 < r2[r]) && (ci < lim[r]);
+                    const unsigned long long bal = __ballot(hit);
+                    if (!bal) continue;
+                    int *list = s_hits[wv][r];
+                    if (hit) list[cnt[r] + __popcll(bal & lanemask_lt())] = ci;     // cnt <= BQG_CAP - 64 here: room for one batch
+                    cnt[r] += __popcll(bal);
+                    if (cnt[r] > BQG_CAP - 64) {                                   // cut down to the nsample lowest, tighten `lim`
+                        const int H = cnt[r], keep = min(H, ns[r]);
+                        int rk[BQG_CAP / 64], vv[BQG_CAP / 64];
+#pragma unroll
+                        for (int u = 0; u < BQG_CAP / 64; ++u) {
+                            const int i = u * 64 + l;
+                            rk[u] = -1;
+                            vv[u] = 0;
+                            if (i < H) {
+                                const int v = list[i];
+                                int rank = 0;
+                                for (int j = 0; j < H; ++j) rank += (list[j] < v) ? 1 : 0;
+                                vv[u] = v;
+                                rk[u] = rank < keep ? rank : -1;
+                            }
+                        }
+#pragma unroll
+                        for (int u = 0; u < BQG_CAP / 64; ++u)                       // (every rank was computed from the old list above)
+                            if (rk[u] >= 0) list[rk[u]] = vv[u];
+                        cnt[r] = keep;
+                        if (keep == ns[r]) lim[r] = list[keep - 1];                // ascending now: the highest index still of interest
+                    }
+                }
+            }
+        }
+#pragma unroll
+        for (int r = 0; r < NR; ++r) {
+            int *o = out[r] + (size_t)q * ns[r];
+            const int H = cnt[r];
+            if (H == 0) {
+                if (l == 0) o[0] = -1;
+                continue;
+            }
+            const int *list = s_hits[wv][r];
+            select_lowest(list, H, ns[r], o);
+            if (H < ns[r]) {                                                       // slots past the last hit repeat the first one
+                int lowest = 0x7fffffff;
+                for (int i = l; i < H; i += 64) lowest = min(lowest, list[i]);
+#pragma unroll
+                for (int d = 32; d >= 1; d >>= 1) lowest = min(lowest, __shfl_xor(lowest, d, 64));
+                for (int p = H + l; p < ns[r]; p += 64) o[p] = lowest;
+            }
+        }
+    }
+}
+
+LIDAR_EXPORT size_t lidar_ball_query_grid_workspace_bytes(int B, int N) {
+    return align_up((size_t)(B > 0 ? B : 1) * sizeof(BqgGrid), 256) +
+           align_up((size_t)(B > 0 ? B : 1) * (BQG_DIM * BQG_DIM + 1) * sizeof(int), 256) + align_up((size_t)(N > 0 ? N : 1) * 16, 256) + 256;
+}
+
+// lidar_ball_query_stack / _stack2 through a cell grid over the candidates (radius_b <= 0 or idx_b == NULL: one radius).
+// N = rows of xyz (sum of xyz_batch_cnt).  Same outputs as the exhaustive kernels; pays off from a few thousand candidates per
+// batch element.  ws: lidar_ball_query_grid_workspace_bytes(B, N), no initialisation needed.
+LIDAR_EXPORT int lidar_ball_query_stack_grid(int B, int M, int N, float radius_a, int nsample_a, float radius_b, int nsample_b,
+                                             const float *new_xyz, const int *new_xyz_batch_cnt, const float *xyz,
+                                             const int *xyz_batch_cnt, int *idx_a, int *idx_b, void *ws, size_t ws_bytes,
+                                             void *stream) {
+    const bool two = idx_b != nullptr && radius_b > 0.f;
+    if (B <= 0 || M < 0 || N < 0 || nsample_a <= 0 || (two && nsample_b <= 0) || !(radius_a > 0.f)) return LIDAR_ERR_ARG;
+    if (nsample_a > BQG_CAP - 64 || (two && nsample_b > BQG_CAP - 64)) return LIDAR_ERR_ARG;       // a list must hold nsample + one 64-lane batch
+    if (M == 0) return LIDAR_OK;
+    if (!new_xyz || !new_xyz_batch_cnt || !xyz || !xyz_batch_cnt || !idx_a || !ws) return LIDAR_ERR_ARG;
+    if (ws_bytes < lidar_ball_query_grid_workspace_bytes(B, N)) return LIDAR_ERR_WORKSPACE;
+    hipStream_t s = (hipStream_t)stream;
+    char *p = (char *)ws;
+    BqgGrid *grids = (BqgGrid *)p;
+    p += align_up((size_t)B * sizeof(BqgGrid), 256);
+    int *cell_start = (int *)p;
+    p += align_up((size_t)B * (BQG_DIM * BQG_DIM + 1) * sizeof(int), 256);
+    float4 *binned = (float4 *)p;
+    const float rmax = two ? fmaxf(radius_a, radius_b) : radius_a;
+    hipLaunchKernelGGL(bqg_build_kernel, dim3(B), dim3(1024), 0, s, B, xyz, xyz_batch_cnt, rmax * 1.001f, grids, cell_start, binned);
+    const dim3 grid(divup(M, 4 * BQ_QPW));
+    if (two)
+        hipLaunchKernelGGL((bqg_query_kernel<2>), grid, dim3(256), 0, s, B, M, radius_a, nsample_a, radius_b, nsample_b, new_xyz,
+                           new_xyz_batch_cnt, grids, cell_start, binned, idx_a, idx_b);
+    else
+        hipLaunchKernelGGL((bqg_query_kernel<1>), grid, dim3(256), 0, s, B, M, radius_a, nsample_a, 0.f, 0, new_xyz,
+                           new_xyz_batch_cnt, grids, cell_start, binned, idx_a, (int *)nullptr);
+    return lidar_check_launch("lidar_ball_query_stack_grid");
+}
+
 LIDAR_EXPORT int lidar_ball_query_batch(int b, int n, int m, float radius, int nsample, const float *new_xyz,
                                         const float *xyz, int *idx, void *stream) {
     if (b <= 0 || n < 0 || m < 0 || nsample <= 0) return LIDAR_ERR_ARG;

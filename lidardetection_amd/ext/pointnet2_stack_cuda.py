@@ -22,6 +22,21 @@ def ball_query2_wrapper(B, M, radius_a, nsample_a, radius_b, nsample_b, new_xyz,
     return 1
 
 
+def ball_query_grid_wrapper(B, M, radius_a, nsample_a, radius_b, nsample_b, new_xyz, new_xyz_batch_cnt, xyz, xyz_batch_cnt, idx_a, idx_b):
+    """not in the reference's module: the same lists as ball_query_wrapper / ball_query2_wrapper (idx_b None: one radius) through
+    a cell grid over the candidates (include/lidar_hip.h: lidar_ball_query_stack_grid)"""
+    from .. import workspace
+    _lib.require_cuda(new_xyz, new_xyz_batch_cnt, xyz, xyz_batch_cnt, idx_a, idx_b)
+    L = _lib.lib()
+    N = xyz.shape[0]
+    nbytes = L.lidar_ball_query_grid_workspace_bytes(B, N)
+    ws = workspace.get("ball_query_grid", nbytes, xyz.device)
+    _lib.check(L.lidar_ball_query_stack_grid(B, M, N, float(radius_a), nsample_a, float(radius_b or 0.0), nsample_b or 0, _p(new_xyz),
+                                             _p(new_xyz_batch_cnt), _p(xyz), _p(xyz_batch_cnt), _p(idx_a), _p(idx_b), _p(ws), nbytes,
+                                             _S()), "lidar_ball_query_stack_grid")
+    return 1
+
+
 def furthest_point_sampling_wrapper(b, n, m, points, temp, idx):
     """sampling.cpp: points (b,n,3), temp (b,n) == 1e10, idx (b,m) int32."""
     _lib.require_cuda(points, temp, idx)

@@ -11,6 +11,8 @@ from .. import _common as C
 
 
 class StackSAModuleMSG(nn.Module):
+    GRID_MIN_POINTS = 512          # candidates per batch element from which the inference path bins them into a cell grid
+
     def __init__(self, *, radii: List[float], nsamples: List[int], mlps: List[List[int]], use_xyz: bool = True,
                  pool_method='max_pool'):
         super().__init__()
@@ -83,12 +85,23 @@ class StackSAModuleMSG(nn.Module):
         per_scale = []
         idxs = [C.zeros_i32((n_query, g.nsample), xyz.device) for g in self.groupers]
         ga = self.groupers
-        for k in range(0, len(ga) - 1, 2):                   # scales in pairs: one pass over the (centre, candidate) distances
-            native.ball_query2_wrapper(n_batch, n_query, ga[k].radius, ga[k].nsample, ga[k + 1].radius, ga[k + 1].nsample, new_xyz,
-                                       new_xyz_batch_cnt, xyz, xyz_batch_cnt, idxs[k], idxs[k + 1])
+        # scales in pairs (one pass over the distances for both radii), through a cell grid over the candidates when there are
+        # enough of them per batch element to pay for the binning pass
+        use_grid = xyz.shape[0] >= self.GRID_MIN_POINTS * n_batch and max(g.nsample for g in ga) <= 64
+        for k in range(0, len(ga) - 1, 2):
+            if use_grid:
+                native.ball_query_grid_wrapper(n_batch, n_query, ga[k].radius, ga[k].nsample, ga[k + 1].radius, ga[k + 1].nsample,
+                                               new_xyz, new_xyz_batch_cnt, xyz, xyz_batch_cnt, idxs[k], idxs[k + 1])
+            else:
+                native.ball_query2_wrapper(n_batch, n_query, ga[k].radius, ga[k].nsample, ga[k + 1].radius, ga[k + 1].nsample,
+                                           new_xyz, new_xyz_batch_cnt, xyz, xyz_batch_cnt, idxs[k], idxs[k + 1])
         if len(ga) % 2:
-            native.ball_query_wrapper(n_batch, n_query, ga[-1].radius, ga[-1].nsample, new_xyz, new_xyz_batch_cnt, xyz,
-                                      xyz_batch_cnt, idxs[-1])
+            if use_grid:
+                native.ball_query_grid_wrapper(n_batch, n_query, ga[-1].radius, ga[-1].nsample, None, None, new_xyz,
+                                               new_xyz_batch_cnt, xyz, xyz_batch_cnt, idxs[-1], None)
+            else:
+                native.ball_query_wrapper(n_batch, n_query, ga[-1].radius, ga[-1].nsample, new_xyz, new_xyz_batch_cnt, xyz,
+                                          xyz_batch_cnt, idxs[-1])
         src = None
         for k, grouper in enumerate(self.groupers):
             layers = self._folded_layers(k)

@@ -260,3 +260,32 @@ def test_ball_query_two_radii_in_one_pass(dev, ra, na, rb, nb):
         empty = want[:, 0] == -1
         assert empty[7] and np.array_equal(got[:, 0] == -1, empty)
         assert np.array_equal(got[~empty], want[~empty])
+
+
+@pytest.mark.parametrize("ra,na,rb,nb", [(0.4, 16, 0.8, 16), (1.6, 32, None, None), (0.05, 4, 6.0, 64), (2.4, 8, 1.2, 33)])
+def test_ball_query_through_cell_grid(dev, ra, na, rb, nb):
+    """lidar_ball_query_stack_grid (candidates binned into an x / y cell grid, three cell rows per centre, hits put back into
+    index order by rank counting) returns exactly the exhaustive kernel's lists — the oracle's (ball_query_gpu.cu:16-66): ragged
+    batch with an empty frame, centres far outside the candidates' bounding box, a NaN candidate, a ball with more hits than
+    the 128-slot hit list holds (radius 6 m in the dense ring near the sensor -> the cut-down-and-tighten path, several times)."""
+    from lidardetection_amd.ext import pointnet2_stack_cuda as native
+    xyz, xc, new, nc = _stack_scene(33, sizes=(6000, 2500, 0, 4000), msizes=(500, 300, 0, 333))
+    new[7] += 90.0                                                   # far outside the grid: nothing in reach
+    new[11, :2] -= 300.0
+    xyz = xyz.copy()
+    xyz[17] = np.nan                                                 # never a hit, never a crash
+    t = lambda a: torch.from_numpy(a).to(dev)
+    ia = torch.zeros((len(new), na), dtype=torch.int32, device=dev)
+    ib = torch.zeros((len(new), nb), dtype=torch.int32, device=dev) if rb else None
+    native.ball_query_grid_wrapper(len(xc), len(new), ra, na, rb, nb, t(new), t(nc), t(xyz), t(xc), ia, ib)
+    for got, r, n in ((ia, ra, na), (ib, rb, nb)):
+        if got is None:
+            continue
+        want = c_oracle.ball_query_stack(r, n, xyz, xc, new, nc)
+        got = got.cpu().numpy()
+        empty = want[:, 0] == -1
+        assert empty[7] and empty[11] and np.array_equal(got[:, 0] == -1, empty)
+        assert np.array_equal(got[~empty], want[~empty]), (r, n)
+    if rb == 6.0:                                                    # the case meant to overflow the 128-slot hit list does
+        d2 = ((new[:500, None, :] - np.nan_to_num(xyz[None, :6000, :], nan=1e9)) ** 2).sum(-1)
+        assert int((d2 < 36.0).sum(1).max()) > 512
