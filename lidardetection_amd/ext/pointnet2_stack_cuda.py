@@ -3,11 +3,15 @@ from .. import _lib
 
 _S = _lib.stream
 _p = _lib.ptr
+GRID_MIN_POINTS = 512          # candidates per batch element from which ball queries go through the cell grid
 
 
 def ball_query_wrapper(B, M, radius, nsample, new_xyz, new_xyz_batch_cnt, xyz, xyz_batch_cnt, idx):
     """ball_query_wrapper_stack (ball_query.cpp:31-47): fills idx (M, nsample) int32 (zero-filled by the caller)."""
     _lib.require_cuda(new_xyz, new_xyz_batch_cnt, xyz, xyz_batch_cnt, idx)
+    if xyz.shape[0] >= GRID_MIN_POINTS * B and nsample <= 64 and radius > 0:
+        # enough candidates per batch element to pay for a binning pass: same lists through the cell grid
+        return ball_query_grid_wrapper(B, M, radius, nsample, None, None, new_xyz, new_xyz_batch_cnt, xyz, xyz_batch_cnt, idx, None)
     _lib.check(_lib.lib().lidar_ball_query_stack(B, M, float(radius), nsample, _p(new_xyz), _p(new_xyz_batch_cnt), _p(xyz),
                                                  _p(xyz_batch_cnt), _p(idx), _S()), "lidar_ball_query_stack")
     return 1

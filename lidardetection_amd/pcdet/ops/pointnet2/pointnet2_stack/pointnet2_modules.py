@@ -11,8 +11,6 @@ from .. import _common as C
 
 
 class StackSAModuleMSG(nn.Module):
-    GRID_MIN_POINTS = 512          # candidates per batch element from which the inference path bins them into a cell grid
-
     def __init__(self, *, radii: List[float], nsamples: List[int], mlps: List[List[int]], use_xyz: bool = True,
                  pool_method='max_pool'):
         super().__init__()
@@ -87,7 +85,7 @@ class StackSAModuleMSG(nn.Module):
         ga = self.groupers
         # scales in pairs (one pass over the distances for both radii), through a cell grid over the candidates when there are
         # enough of them per batch element to pay for the binning pass
-        use_grid = xyz.shape[0] >= self.GRID_MIN_POINTS * n_batch and max(g.nsample for g in ga) <= 64
+        use_grid = xyz.shape[0] >= native.GRID_MIN_POINTS * n_batch and max(g.nsample for g in ga) <= 64
         for k in range(0, len(ga) - 1, 2):
             if use_grid:
                 native.ball_query_grid_wrapper(n_batch, n_query, ga[k].radius, ga[k].nsample, ga[k + 1].radius, ga[k + 1].nsample,

@@ -29,8 +29,12 @@ def _stack_scene(seed, sizes=(3000, 1777, 0, 2500), msizes=(400, 300, 0, 333)):
     return xyz.astype(np.float32), np.array(sizes, np.int32), new, np.array(msizes, np.int32)
 
 
+@pytest.mark.parametrize("grid", [False, True])
 @pytest.mark.parametrize("radius,nsample", [(0.4, 16), (1.6, 32), (0.01, 8)])
-def test_ball_query_and_group_stack(dev, radius, nsample):
+def test_ball_query_and_group_stack(dev, radius, nsample, grid, monkeypatch):
+    """ball_query through both of its kernels (the public function picks by input size): exhaustive, and the cell grid"""
+    from lidardetection_amd.ext import pointnet2_stack_cuda as native
+    monkeypatch.setattr(native, "GRID_MIN_POINTS", 1 if grid else 1 << 30)
     xyz, xc, new, nc = _stack_scene(1)
     t = lambda a: torch.from_numpy(a).to(dev)
     idx_o = c_oracle.ball_query_stack(radius, nsample, xyz, xc, new, nc)
