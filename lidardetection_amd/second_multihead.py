@@ -161,22 +161,37 @@ class SECONDMultiHeadNuScenes(nn.Module):
         """-> per (head, class) column: sigmoid scores ranked by one top-k, their anchors decoded.
         scores (B, 10, pre), boxes (B, 10, pre, 9), counts (B, 10) i32 (#scores >= SCORE_THRESH among the top `pre`),
         labels (10,) the 1-based class of each column."""
-        sc_l, bx_l, lab = [], [], []
-        for (cls, box), anchors, labels in zip(head_out, self.head_anchors, self.head_label_indices):
+        # all ten (head, class) columns through ONE top-k, one gather of the encodings, one of the anchors and one decode (per
+        # column that is ~10 launches x 10 columns; the columns of one-class heads are padded to the longest with -2: below the
+        # -1 of a score under SCORE_THRESH, and k <= every column's true length, so padding is never ranked)
+        dev = head_out[0][0].device
+        B = head_out[0][0].shape[0]
+        n_max = max(cls.shape[1] for cls, _ in head_out)
+        n_cols = sum(cls.shape[2] for cls, _ in head_out)
+        k = min(self.nms_pre, min(cls.shape[1] for cls, _ in head_out))
+        masked = torch.full((B, n_cols, n_max), -2.0, dtype=torch.float32, device=dev)
+        col_off, lab, c0, off = [], [], 0, 0
+        for (cls, box), labels in zip(head_out, self.head_label_indices):
             prob = torch.sigmoid(cls)                                        # detector3d_template.py:210
-            k = min(self.nms_pre, prob.shape[1])
-            for c in range(prob.shape[2]):
-                col = prob[:, :, c]
-                masked = torch.where(col >= self.score_thresh, col, col.new_full((), -1.0))
-                top, idx = torch.topk(masked, k, dim=1)                      # sorted descending == nms_gpu's own sort
-                enc = torch.gather(box, 1, idx.unsqueeze(-1).expand(-1, -1, box.shape[2]))
-                sc_l.append(top)
-                bx_l.append(decode_sincos(enc, anchors[idx]))
-                lab.append(labels[c])
-        scores = torch.stack(sc_l, 1)
-        boxes = torch.stack(bx_l, 1)
+            n_h, c_h = prob.shape[1], prob.shape[2]
+            masked[:, c0:c0 + c_h, :n_h] = torch.where(prob >= self.score_thresh, prob, prob.new_full((), -1.0)).transpose(1, 2)
+            col_off += [off] * c_h
+            lab += list(labels)
+            c0 += c_h
+            off += n_h
+        scores, idx = torch.topk(masked, k, dim=2)                           # sorted descending == nms_gpu's own sort
+        gidx = idx + torch.tensor(col_off, device=dev).view(1, -1, 1)        # row in the heads' concatenated anchor order
+        boxes_all = torch.cat([box for _, box in head_out], dim=1)           # (B, sum n_h, 10)
+        anchors_all = self._anchors_cat()
+        enc = torch.gather(boxes_all, 1, gidx.view(B, -1, 1).expand(-1, -1, boxes_all.shape[2])).view(B, n_cols, k, -1)
+        boxes = decode_sincos(enc, anchors_all[gidx])
         counts = (scores >= self.score_thresh).sum(-1).to(torch.int32)
-        return scores, boxes, counts, torch.tensor(lab, device=scores.device)
+        return scores, boxes, counts, torch.tensor(lab, device=dev)
+
+    def _anchors_cat(self):
+        if self.__dict__.get("_anchors_all") is None:
+            self.__dict__["_anchors_all"] = torch.cat(self.head_anchors, 0)
+        return self.__dict__["_anchors_all"]
 
     def batched_class_nms(self, scores, boxes, counts):
         """all B x 10 candidate lists through ONE batched device NMS -> keep (B, 10, post) positions into the candidate lists
