@@ -18,9 +18,11 @@ B x 10 lists at once.  Outputs are padded to 83 per (frame, class) with a count.
 import numpy as np
 import torch
 import torch.nn as nn
+import torch.nn.functional as F
 
 from . import pillar_ops, synth
-from .bev_backbone import FoldedBEVBackbone, collect_params, params_key
+from .bev_backbone import FoldedBEVBackbone, bias_act_, collect_params, params_key
+from .bev_backbone import _fold as fold_bn
 from .ext import iou3d_nms_cuda
 from .pcdet.models.backbones_3d import spconv_backbone
 from .pcdet.utils.cfg import AttrDict
@@ -153,9 +155,52 @@ class SECONDMultiHeadNuScenes(nn.Module):
             self._bev = FoldedBEVBackbone(self.blocks, self.deblocks, [])
         return self._bev.features(canvas)                       # (B, 512, 128, 128) channels-last
 
-    def heads(self, spatial_2d):
+    def heads_reference_layout(self, spatial_2d):
+        """the module sequence as the reference runs it: shared conv, then 6 heads x 6 branches of conv/BN/ReLU/conv (144 launches)"""
         x = self.shared_conv(spatial_2d)
         return [h(x) for h in self.rpn_heads]                   # [(cls (B, n_h, c_h), box (B, n_h, 10))] per head
+
+    def _folded_heads(self):
+        """every branch's first 3x3 convolution reads the same 64-channel map: their 36 weight sets stacked give ONE convolution
+        64 -> 2304 (BatchNorm folded, shift + ReLU in one in-place pass: 1.4 ms instead of 2.1 ms + 72 BatchNorm / ReLU launches).
+        The 36 second convolutions (64 -> 2..12 channels) stay separate: as one grouped convolution they measured 2.8 ms
+        against 1.5 ms (tools/heads_conv_probe.py).  Cached until a parameter changes."""
+        srcs = self.__dict__.get("_heads_src")
+        if srcs is None:
+            srcs = self.__dict__["_heads_src"] = collect_params(self.shared_conv, self.rpn_heads)
+        key = params_key(srcs)
+        cache = self.__dict__.get("_heads_folded")
+        if cache is None or cache[0] != key:
+            with torch.no_grad():
+                ws, bs = fold_bn(self.shared_conv[0].weight, self.shared_conv[1], 0, self.shared_conv[0].bias)
+                w1, b1, second = [], [], []
+                for head in self.rpn_heads:
+                    for br in [head.conv_cls] + [head.conv_box[f"conv_{name}"] for name, _ in NUS_REG_LIST]:
+                        w, b = fold_bn(br[0].weight, br[1], 0, br[0].bias)
+                        w1.append(w)
+                        b1.append(b)
+                        second.append(br[3])
+                cl = lambda t: t.contiguous(memory_format=torch.channels_last)
+                cache = (key, cl(ws), bs, cl(torch.cat(w1, 0)), torch.cat(b1, 0).contiguous(), second)
+            self.__dict__["_heads_folded"] = cache
+        return cache[1:]
+
+    def heads(self, spatial_2d):
+        """same outputs as heads_reference_layout(): shared conv and all first-layer branch convolutions merged and folded"""
+        ws, bs, w1, b1, second = self._folded_heads()
+        x = bias_act_(F.conv2d(spatial_2d, ws, None, padding=1), bs, True)
+        y = bias_act_(F.conv2d(x, w1, None, padding=1), b1, True)
+        mid = w1.shape[0] // len(second)
+        z = [conv(y[:, g * mid:(g + 1) * mid]) for g, conv in enumerate(second)]
+        B, _, H, W = y.shape
+        out, g = [], 0
+        for head in self.rpn_heads:
+            cls, box = z[g], torch.cat(z[g + 1:g + 1 + len(NUS_REG_LIST)], dim=1)
+            g += 1 + len(NUS_REG_LIST)
+            box = box.view(B, head.A, head.code_size, H, W).permute(0, 1, 3, 4, 2).reshape(B, -1, head.code_size)
+            cls = cls.view(B, head.A, head.num_class, H, W).permute(0, 1, 3, 4, 2).reshape(B, -1, head.num_class)
+            out.append((cls, box))
+        return out
 
     def candidates(self, head_out):
         """-> per (head, class) column: sigmoid scores ranked by one top-k, their anchors decoded.

@@ -119,6 +119,11 @@ def test_second_multihead_nuscenes_bs4(dev):
         canvas = m.sparse_backbone(feats, coords)
         assert canvas.shape == (B, 256, 128, 128)
         head_out = m.heads(m.bev_features(canvas))
+        # the merged head convolutions (3 launches + 2 epilogues) vs the reference-shaped module sequence (144 launches)
+        for (c_f, b_f), (c_r, b_r) in zip(head_out, m.heads_reference_layout(m.bev_features(canvas))):
+            for got, want in ((c_f, c_r), (b_f, b_r)):
+                assert got.shape == want.shape
+                assert float((got - want).abs().max()) <= 1e-4 * max(1.0, float(want.abs().max())), "merged multi-head convolutions"
         scores, boxes, counts, labels = m.candidates(head_out)
         keep, num = m.batched_class_nms(scores, boxes, counts)
         out_boxes, out_scores, out_labels, valid = m.post_process(head_out)
