@@ -61,7 +61,9 @@ def bilinear_bev(bev_nhwc, x, y):
 def roi_grid_points(rois, grid_size):
     """rois (R, 7) -> global grid points (R, grid^3, 3) (pvrcnn_head.py:120-143)."""
     R = rois.shape[0]
-    idx = torch.ones((grid_size,) * 3, device=rois.device).nonzero().float()                  # (g^3, 3) [x, y, z] index
+    # (g^3, 3) [x, y, z] index == ones(g, g, g).nonzero() of the reference, built without its host sync (nonzero reads a count back)
+    ax = torch.arange(grid_size, device=rois.device, dtype=torch.float32)
+    idx = torch.stack(torch.meshgrid(ax, ax, ax, indexing="ij"), dim=-1).view(-1, 3)
     size = rois[:, 3:6].unsqueeze(1)
     local = (idx.unsqueeze(0) + 0.5) / grid_size * size - size / 2
     glob = common_utils.rotate_points_along_z(local.clone(), rois[:, 6]) + rois[:, 0:3].unsqueeze(1)
@@ -236,7 +238,9 @@ class PVRCNNKitti(SECONDKitti):
         for layer, name in zip(self.SA_layers, self.SA_layer_names):
             t = multi_scale[name]
             xyz = common_utils.get_voxel_centers(t.indices[:, 1:4], self.downsample[name], self.voxel_size, self.pc_range)
-            cnt = torch.bincount(t.indices[:, 0].long(), minlength=B).int()         # rows are grouped by frame, frames ascending
+            # rows per frame (rows are grouped by frame, frames ascending) — a comparison table instead of bincount, which
+            # reads its output size back to the host
+            cnt = (t.indices[:, 0:1] == torch.arange(B, device=dev, dtype=t.indices.dtype).view(1, B)).sum(0).int()
             _, f = layer(xyz=xyz.contiguous(), xyz_batch_cnt=cnt, new_xyz=new_xyz, new_xyz_batch_cnt=new_cnt,
                          features=t.features.contiguous())
             feats.append(f.view(B, K, -1))
