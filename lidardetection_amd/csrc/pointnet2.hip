@@ -204,6 +204,7 @@ LIDAR_EXPORT int lidar_ball_query_stack2(int B, int M, float radius_a, int nsamp
 // A point within r of a centre is at most one cell away in x and in y: the cell coordinate is a monotone function of the
 // coordinate and the cell width exceeds r by 0.1 % (rounding moves a quotient by ~1e-5 of a cell).
 #define BQG_DIM 128                                 // grid cells per axis at most (LDS histogram: 128 * 128 ints)
+#define BQG_QPW 1                                   // centres per wave (a centre in a dense spot takes many times longer than one in a sparse spot: one each balances best)
 #define BQG_CAP 128                                 // slots of a hit list (per centre and radius); cut down to nsample when nearly full
 struct BqgGrid { float xlo, ylo, inv, pad; int gw, gh, start, n; };   // per batch element (start / n: its rows in xyz)
 
@@ -304,8 +305,8 @@ __global__ __launch_bounds__(256) void bqg_query_kernel(int B, int M, float radi
             if (i < H && rank < nsel) dst[rank] = v;
         }
     };
-    for (int qi = 0; qi < BQ_QPW; ++qi) {
-        const int q = (blockIdx.x * 4 + wv) * BQ_QPW + qi;                         // wave-uniform
+    for (int qi = 0; qi < BQG_QPW; ++qi) {
+        const int q = (blockIdx.x * 4 + wv) * BQG_QPW + qi;                        // wave-uniform
         if (q >= M) break;
         int bs = 0, acc = new_cnt[0];
         for (int k = 1; k < B; ++k) {
@@ -419,7 +420,7 @@ LIDAR_EXPORT int lidar_ball_query_stack_grid(int B, int M, int N, float radius_a
     float4 *binned = (float4 *)p;
     const float rmax = two ? fmaxf(radius_a, radius_b) : radius_a;
     hipLaunchKernelGGL(bqg_build_kernel, dim3(B), dim3(1024), 0, s, B, xyz, xyz_batch_cnt, rmax * 1.001f, grids, cell_start, binned);
-    const dim3 grid(divup(M, 4 * BQ_QPW));
+    const dim3 grid(divup(M, 4 * BQG_QPW));
     if (two)
         hipLaunchKernelGGL((bqg_query_kernel<2>), grid, dim3(256), 0, s, B, M, radius_a, nsample_a, radius_b, nsample_b, new_xyz,
                            new_xyz_batch_cnt, grids, cell_start, binned, idx_a, idx_b);
