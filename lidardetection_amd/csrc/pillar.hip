@@ -197,6 +197,34 @@ __global__ __launch_bounds__(256) void pfn_pair_kernel(const float *__restrict__
     for (int pr = wave; pr < npairs; pr += nwaves) {
         const Head hc = load_head(pr + 2 * nwaves);             // two pairs ahead: the counts are here when their slots are requested
         const Pts pb = load_pts(pr + nwaves, hb.n);             // one pair ahead
+        const float vox = ha.cx * p.vx + p.xo, voy = ha.cy * p.vy + p.yo, voz = ha.cz * p.vz + p.zo;
+        if (__builtin_amdgcn_readlane(ha.n, 0) <= 1 && __builtin_amdgcn_readlane(ha.n, 32) <= 1) {
+            // both voxels hold at most ONE point (3 pairs in 5 on a 20k-point KITTI frame): the mean IS the point, so the three
+            // (point - mean) features are exactly zero and their products add exactly nothing — no row sums, no divisions
+#pragma unroll
+            for (int h = 0; h < 2; ++h) {
+                const int v = 2 * pr + h;
+                if (v >= nv) break;                              // wave-uniform
+                const int b0 = 32 * h;
+                float best = pad_val;                            // n <= 1 < P: padded slots exist
+                if (__builtin_amdgcn_readlane(ha.n, b0) == 1) {
+                    float f[C];
+#pragma unroll
+                    for (int k = 0; k < C; ++k) f[k] = rl(pa.v[k], b0);
+                    float acc = 0.f;
+#pragma unroll
+                    for (int k = 0; k < C; ++k) acc = fmaf(f[k], wt[k], acc);
+                    acc = fmaf(f[0] - rl(vox, b0), wt[C + 3], acc);
+                    acc = fmaf(f[1] - rl(voy, b0), wt[C + 4], acc);
+                    acc = fmaf(f[2] - rl(voz, b0), wt[C + 5], acc);
+                    if (DIST) acc = fmaf(sqrtf(f[0] * f[0] + f[1] * f[1] + f[2] * f[2]), wt[NF - 1], acc);
+                    best = fmaxf(best, fmaxf(fmaf(acc, sc, sh), 0.f));
+                }
+                if (chan) out[(size_t)v * p.cout + l] = best;
+            }
+            ha = hb; hb = hc; pa = pb;
+            continue;
+        }
         // both voxels at once, on the lanes of their halves: sums -> means, pillar centre
         const float rx = row_sum16(pa.v[0]), ry = row_sum16(pa.v[1]), rz = row_sum16(pa.v[2]);
         const float hx = half ? rl(rx, 32) + rl(rx, 48) : rl(rx, 0) + rl(rx, 16);
@@ -204,7 +232,6 @@ __global__ __launch_bounds__(256) void pfn_pair_kernel(const float *__restrict__
         const float hz = half ? rl(rz, 32) + rl(rz, 48) : rl(rz, 0) + rl(rz, 16);
         const float fn = (float)ha.n;
         const float vmx = hx / fn, vmy = hy / fn, vmz = hz / fn;
-        const float vox = ha.cx * p.vx + p.xo, voy = ha.cy * p.vy + p.yo, voz = ha.cz * p.vz + p.zo;
 #pragma unroll
         for (int h = 0; h < 2; ++h) {
             const int v = 2 * pr + h;
