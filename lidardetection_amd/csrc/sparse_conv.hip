@@ -1185,8 +1185,11 @@ __global__ void sc_wgrad_reduce_kernel(const float *__restrict__ part, int K, in
 }
 
 static int sc_wgrad_chunks(int n_out) {
-    int nch = divup(n_out, WGM_ROWS * 16);      // >= 16 row tiles per workgroup
-    return nch < 1 ? 1 : (nch > 32 ? 32 : nch);
+    // >= 8 row tiles per workgroup, at most 128 chunks: K x 128 workgroups of very unequal length (the centre offset is used by
+    // every row, the corners by a third) balance over the 512 resident slots; with 32 chunks of >= 16 tiles (864 workgroups, 1.7
+    // rounds) the slowest ones set the time: SECOND training step 18.8 -> 15.7 ms (64 x 8: 16.7, 256 x 4: 16.0)
+    int nch = divup(n_out, WGM_ROWS * 8);
+    return nch < 1 ? 1 : (nch > 128 ? 128 : nch);
 }
 
 LIDAR_EXPORT int lidar_spconv_wgrad_mfma_supported(int K, int Cin, int Cout) {
