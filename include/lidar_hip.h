@@ -166,6 +166,13 @@ int lidar_group_rows_stack(int B, int M, int C, int nsample, int use_xyz, int st
 int lidar_group_rows_affine_stack(int B, int M, int H, int nsample, const float *table, const float *query_term,
                                   const float *empty_row, const int *features_batch_cnt, const int *idx, const int *idx_batch_cnt,
                                   float *out, void *stream);
+/* A two-layer scale in one kernel: the gather above, the second layer on the matrix cores (W2 (H1, H2) row-major, b2) and the max
+ * over the samples — out (M, H2) = max_s relu(relu(table[idx] - query_term[m]) @ W2 + b2).  H1 in {16, 32, 64}, H2 <= 128,
+ * nsample in {8, 16, 32} (lidar_sa_layer2_max_supported). */
+int lidar_sa_layer2_max_supported(int H1, int H2, int nsample);
+int lidar_sa_layer2_max_stack(int B, int M, int H1, int H2, int nsample, const float *table, const float *query_term,
+                              const float *empty_row, const float *W2, const float *b2, const int *features_batch_cnt,
+                              const int *idx, const int *idx_batch_cnt, float *out, void *stream);
 int lidar_group_points_grad_stack(int B, int M, int C, int N, int nsample, const float *grad_out, const int *idx,
                                   const int *idx_batch_cnt, const int *features_batch_cnt, float *grad_features,
                                   void *stream);

@@ -36,6 +36,8 @@ SIGNATURES = {
     "lidar_group_points_stack": (i32, [i32, i32, i32, i32, vp, vp, vp, vp, vp, vp]),
     "lidar_group_rows_stack": (i32, [i32, i32, i32, i32, i32, i32, vp, vp, vp, vp, vp, vp, vp, vp]),
     "lidar_group_rows_affine_stack": (i32, [i32, i32, i32, i32, vp, vp, vp, vp, vp, vp, vp, vp]),
+    "lidar_sa_layer2_max_supported": (i32, [i32, i32, i32]),
+    "lidar_sa_layer2_max_stack": (i32, [i32, i32, i32, i32, i32, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp]),
     "lidar_group_points_grad_stack": (i32, [i32, i32, i32, i32, i32, vp, vp, vp, vp, vp, vp]),
     "lidar_furthest_point_sampling": (i32, [i32, i32, i32, vp, vp, vp, vp]),
     "lidar_three_nn_stack": (i32, [i32, i32, vp, vp, vp, vp, vp, vp, vp]),

@@ -15,6 +15,7 @@
 //     gathered feature rows and the (M, C, nsample) output are accessed with full 256-B wave transactions;
 //   * scatter-add backward passes issue float atomics as contiguous per-wave row segments.
 #include "common.h"
+#include <algorithm>
 #include <type_traits>
 
 #define PN_TPB 256
@@ -581,6 +582,131 @@ LIDAR_EXPORT int lidar_group_rows_affine_stack(int B, int M, int H, int nsample,
                        (const float4 *)table, (const float4 *)query_term, (const float4 *)empty_row, features_batch_cnt, idx,
                        idx_batch_cnt, (float4 *)out);
     return lidar_check_launch("lidar_group_rows_affine_stack");
+}
+
+// Two-layer scale in ONE kernel: the gather of layer-1 rows above, the second layer on the matrix cores and the max over the
+// samples, without the (M * ns, H1) and (M * ns, H2) intermediates ever reaching HBM:
+//   out[m] = max_s relu(relu(table[idx[m][s]] - query_term[m]) @ W2 + b2)            (empty ball: relu(relu(b1) @ W2 + b2))
+// A wave owns 32 (query, sample) rows = 32 / NS queries: it gathers them into its own LDS tile (no workgroup barrier in the loop:
+// W2 is staged once per workgroup and never changes), runs H1 / 2 steps of v_mfma_f32_32x32x2_f32 per 32 output columns, and
+// reduces the accumulator rows of each query (register subsets of the MFMA layout, then the two lane halves).
+// H1 = 4 * C4 in {16, 32, 64}, H2 <= NT * 32, NS in {8, 16, 32}.
+typedef float sa_f32x16 __attribute__((ext_vector_type(16)));
+template <int NT, int C4, int NS>
+__global__ __launch_bounds__(256) void sa_layer2_max_kernel(int B, int M, int H2, const float4 *__restrict__ table,
+                                                            const float4 *__restrict__ query_term,
+                                                            const float4 *__restrict__ empty_row, const float *__restrict__ W2,
+                                                            const float *__restrict__ b2, const int *__restrict__ feat_cnt,
+                                                            const int *__restrict__ idx, const int *__restrict__ idx_cnt,
+                                                            float *__restrict__ out) {
+    constexpr int H1 = C4 * 4, Cp = H1 + 1, CW = NT * 32, QW = 32 / NS, NG = (32 * C4) / 64, RPQ = NS / 2;
+    extern __shared__ float s_sa[];
+    float *s_w = s_sa;                                    // [H1][CW], zero beyond H2
+    float *A = s_sa + H1 * CW + (threadIdx.x >> 6) * 32 * Cp;
+    const int t = threadIdx.x, l = t & 63;
+    const int wv = __builtin_amdgcn_readfirstlane(t >> 6);
+    for (int e = t; e < H1 * CW; e += 256) {
+        const int ci = e / CW, co = e - ci * CW;
+        s_w[e] = co < H2 ? W2[(size_t)ci * H2 + co] : 0.f;
+    }
+    float bias[NT];
+#pragma unroll
+    for (int q = 0; q < NT; ++q) bias[q] = (q * 32 + (l & 31)) < H2 ? b2[q * 32 + (l & 31)] : 0.f;
+    __syncthreads();
+    const int ar = l & 31, ak = l >> 5;
+    const int ngroups = (M + QW - 1) / QW;
+    for (int g = blockIdx.x * 4 + wv; g < ngroups; g += gridDim.x * 4) {              // wave-uniform
+        // row r = l & 31 of the tile: query m0 + r / NS, sample r % NS
+        const int mq = g * QW + (l & 31) / NS;
+        int src = -1;                                                              // source row in `table`, -1: empty ball / no query
+        if (mq < M) {
+            const int *row = idx + (size_t)mq * NS;
+            if (row[0] >= 0) {
+                int b = 0, acc = idx_cnt[0], start = 0;
+                for (int k = 1; k < B; ++k) {
+                    if (mq < acc) break;
+                    acc += idx_cnt[k];
+                    start += feat_cnt[k - 1];
+                    b = k;
+                }
+                (void)b;
+                src = start + row[(l & 31) % NS];
+            }
+        }
+#pragma unroll
+        for (int u = 0; u < NG; ++u) {
+            const int e = u * 64 + l, r = e / C4, c = e - r * C4;
+            const int sr = __shfl(src, r, 64);
+            const int mr = g * QW + r / NS;
+            float4 v = empty_row[c];
+            if (sr >= 0) {
+                v = table[(size_t)sr * C4 + c];
+                if (query_term) {
+                    const float4 qv = query_term[(size_t)mr * C4 + c];
+                    v.x -= qv.x; v.y -= qv.y; v.z -= qv.z; v.w -= qv.w;
+                }
+                v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f);
+            }
+            float *dst = A + r * Cp + c * 4;
+            dst[0] = v.x; dst[1] = v.y; dst[2] = v.z; dst[3] = v.w;
+        }
+        sa_f32x16 acc[NT];
+#pragma unroll
+        for (int q = 0; q < NT; ++q)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[q][r] = 0.f;
+#pragma unroll 8
+        for (int c0 = 0; c0 < H1; c0 += 2) {
+            const float a = A[ar * Cp + c0 + ak];
+#pragma unroll
+            for (int q = 0; q < NT; ++q) {
+                const float b = s_w[(c0 + ak) * CW + q * 32 + ar];
+                acc[q] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, acc[q], 0, 0, 0);
+            }
+        }
+        // accumulator register r of lane l holds row (r & 3) + 8 * (r >> 2) + 4 * (l >> 5), column q * 32 + (l & 31):
+        // query j of the tile = rows [j * NS, (j + 1) * NS) = registers [j * RPQ, (j + 1) * RPQ) of both lane halves
+#pragma unroll
+        for (int q = 0; q < NT; ++q) {
+#pragma unroll
+            for (int j = 0; j < QW; ++j) {
+                float mx = -3.0e38f;
+#pragma unroll
+                for (int r = 0; r < RPQ; ++r) mx = fmaxf(mx, acc[q][j * RPQ + r]);
+                mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+                const int m = g * QW + j, col = q * 32 + (l & 31);
+                if (l < 32 && m < M && col < H2) out[(size_t)m * H2 + col] = fmaxf(mx + bias[q], 0.f);   // relu and max commute
+            }
+        }
+    }
+}
+
+LIDAR_EXPORT int lidar_sa_layer2_max_supported(int H1, int H2, int nsample) {
+    return ((H1 == 16 || H1 == 32 || H1 == 64) && H2 >= 1 && H2 <= 128 && (nsample == 8 || nsample == 16 || nsample == 32)) ? 1 : 0;
+}
+
+// table (N, H1), query_term (M, H1) or null, empty_row (H1), W2 (H1, H2) row-major, b2 (H2), idx = RAW ball-query result
+// (M, nsample); out (M, H2).  See lidar_group_rows_affine_stack for the first layer's algebra.
+LIDAR_EXPORT int lidar_sa_layer2_max_stack(int B, int M, int H1, int H2, int nsample, const float *table, const float *query_term,
+                                           const float *empty_row, const float *W2, const float *b2,
+                                           const int *features_batch_cnt, const int *idx, const int *idx_batch_cnt, float *out,
+                                           void *stream) {
+    if (B <= 0 || M < 0 || !lidar_sa_layer2_max_supported(H1, H2, nsample)) return LIDAR_ERR_ARG;
+    if (M == 0) return LIDAR_OK;
+    if (!table || !empty_row || !W2 || !b2 || !features_batch_cnt || !idx || !idx_batch_cnt || !out) return LIDAR_ERR_ARG;
+    const int nt = divup(H2, 32), c4 = H1 / 4;
+    const size_t lds = ((size_t)H1 * nt * 32 + (size_t)4 * 32 * (H1 + 1)) * sizeof(float);
+    const int qw = 32 / nsample, ngroups = divup(M, qw);
+    const int blocks = (int)std::min<long long>(divup(ngroups, 4), 256 * 3);
+    hipStream_t s = (hipStream_t)stream;
+#define SAL(NT, C4, NS) hipLaunchKernelGGL((sa_layer2_max_kernel<NT, C4, NS>), dim3(blocks), dim3(256), lds, s, B, M, H2, (const float4 *)table, (const float4 *)query_term, (const float4 *)empty_row, W2, b2, features_batch_cnt, idx, idx_batch_cnt, out)
+#define SAL_NS(NT, C4) do { if (nsample == 8) SAL(NT, C4, 8); else if (nsample == 16) SAL(NT, C4, 16); else SAL(NT, C4, 32); } while (0)
+#define SAL_C4(NT) do { if (c4 == 4) SAL_NS(NT, 4); else if (c4 == 8) SAL_NS(NT, 8); else SAL_NS(NT, 16); } while (0)
+    switch (nt) { case 1: SAL_C4(1); break; case 2: SAL_C4(2); break; case 3: SAL_C4(3); break; default: SAL_C4(4); break; }
+#undef SAL_C4
+#undef SAL_NS
+#undef SAL
+    return lidar_check_launch("lidar_sa_layer2_max_stack");
 }
 
 // idx: the RAW ball-query result (-1 in column 0 marks an empty ball).  features may be null (C = 0, use_xyz required).

@@ -73,6 +73,20 @@ def group_rows_affine_wrapper(B, M, H, nsample, table, query_term, empty_row, fe
     return 1
 
 
+def sa_layer2_max_supported(H1, H2, nsample):
+    return bool(_lib.lib().lidar_sa_layer2_max_supported(int(H1), int(H2), int(nsample)))
+
+
+def sa_layer2_max_wrapper(B, M, nsample, table, query_term, empty_row, w2, b2, features_batch_cnt, idx, idx_batch_cnt, out):
+    """not in the reference's module: layer-1 gather + second layer (MFMA) + max over the samples in one kernel
+    (include/lidar_hip.h: lidar_sa_layer2_max_stack)"""
+    _lib.require_cuda(table, query_term, empty_row, w2, b2, features_batch_cnt, idx, idx_batch_cnt, out)
+    _lib.check(_lib.lib().lidar_sa_layer2_max_stack(B, M, table.shape[1], w2.shape[1], nsample, _p(table), _p(query_term), _p(empty_row),
+                                                    _p(w2), _p(b2), _p(features_batch_cnt), _p(idx), _p(idx_batch_cnt), _p(out), _S()),
+               "lidar_sa_layer2_max_stack")
+    return 1
+
+
 def group_points_grad_wrapper(B, M, C, N, nsample, grad_out, idx, idx_batch_cnt, features_batch_cnt, grad_features):
     _lib.require_cuda(grad_out, idx, idx_batch_cnt, features_batch_cnt, grad_features)
     _lib.check(_lib.lib().lidar_group_points_grad_stack(B, M, C, N, nsample, _p(grad_out), _p(idx), _p(idx_batch_cnt),

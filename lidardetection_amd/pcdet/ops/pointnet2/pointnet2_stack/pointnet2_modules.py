@@ -115,6 +115,13 @@ class StackSAModuleMSG(nn.Module):
                     query_term = torch.mm(new_xyz, w1[:3])
                 else:
                     table, query_term = torch.addmm(b1, feats, w1[:width]), None
+                if len(layers) == 2 and native.sa_layer2_max_supported(w1.shape[1], layers[1][0].shape[1], grouper.nsample):
+                    # two-layer scale (every one in PV-RCNN): gather + second layer on the matrix cores + max in ONE kernel
+                    pooled = C.empty_f32((n_query, layers[1][0].shape[1]), xyz.device)
+                    native.sa_layer2_max_wrapper(n_batch, n_query, grouper.nsample, table, query_term, torch.relu(b1), layers[1][0],
+                                                 layers[1][1], xyz_batch_cnt, idx, new_xyz_batch_cnt, pooled)
+                    per_scale.append(pooled)
+                    continue
                 rows = C.empty_f32((n_query * grouper.nsample, w1.shape[1]), xyz.device)
                 native.group_rows_affine_wrapper(n_batch, n_query, w1.shape[1], grouper.nsample, table, query_term,
                                                  torch.relu(b1), xyz_batch_cnt, idx, new_xyz_batch_cnt, rows)
