@@ -212,3 +212,30 @@ def test_host_voxel_generator_runs_in_a_forked_worker():
     assert p.exitcode == 0
     ev, ec, en = c_oracle.voxelize(pts, synth.PP_VOXEL, synth.PP_RANGE, 32, 16000)
     assert np.array_equal(v, ev) and np.array_equal(c, ec) and np.array_equal(n, en)
+
+
+def test_trim_padding_cuts_capacity_sized_tensors_to_their_true_rows():
+    """host logic of the read-back-free sparse forward (spconv/modules.py:_trim_padding): capacity-sized outputs and rulebook
+    tables become prefix views of their true row counts, SubM tables keep nbr_t aliased to nbr, cached row orders (which cover
+    the padding rows) are dropped, exact-sized tensors are left alone."""
+    import torch
+    from lidardetection_amd.spconv import modules
+    from lidardetection_amd.spconv.tensor import SparseConvTensor
+    c1 = torch.arange(40, dtype=torch.int32).view(10, 4)            # level 1: exact (10 rows)
+    c2 = torch.arange(64, dtype=torch.int32).view(16, 4)            # level 2: capacity 16, true 11
+    f2 = torch.randn(16, 8)
+    nbr_conv, nbr_sub2 = torch.zeros(16, 27, dtype=torch.int32), torch.ones(16, 27, dtype=torch.int32)
+    idict = {"__grid_token__": {"token": 1},
+             "spconv2": {"subm": False, "nbr": nbr_conv, "nbr_t": None, "in_indices": c1, "out_indices": c2, "order": [1, 2, None]},
+             "subm2": {"subm": True, "nbr": nbr_sub2, "nbr_t": nbr_sub2, "in_indices": c2, "out_indices": c2, "order": [1, 2, None]},
+             "subm1": {"subm": True, "nbr": torch.zeros(10, 27, dtype=torch.int32), "nbr_t": None, "in_indices": c1, "out_indices": c1,
+                       "order": "kept"}}
+    idict["subm1"]["nbr_t"] = idict["subm1"]["nbr"]
+    x1, x2 = SparseConvTensor(torch.randn(10, 4), c1, [4, 4, 4], 1), SparseConvTensor(f2, c2, [2, 2, 2], 1)
+    modules._trim_padding([x1, x2], idict, {c2.data_ptr(): 11})
+    assert x1.features.shape[0] == 10 and x2.features.shape[0] == 11 and x2.indices.shape[0] == 11
+    assert x2.features.data_ptr() == f2.data_ptr() and torch.equal(x2.indices, c2[:11])
+    assert idict["spconv2"]["nbr"].shape == (11, 27) and idict["spconv2"]["out_indices"].shape[0] == 11
+    assert idict["spconv2"]["in_indices"].shape[0] == 10 and "order" not in idict["spconv2"]
+    assert idict["subm2"]["nbr"].shape == (11, 27) and idict["subm2"]["nbr_t"] is idict["subm2"]["nbr"] and "order" not in idict["subm2"]
+    assert idict["subm1"]["nbr"].shape == (10, 27) and idict["subm1"]["order"] == "kept"
