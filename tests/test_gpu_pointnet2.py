@@ -206,6 +206,13 @@ def test_stack_set_abstraction_and_fp_modules_vs_oracle(dev):
         sa_o = _perturb_bn(smod.StackSAModuleMSG(radii=[0.8], nsamples=[16], mlps=[[8, 6, 10]]).to(dev), 7)
         _close(sa_o(t(xyz), t(xc), t(new), t(nc), t(feat))[1].cpu().numpy(), sa_oracle.stack_sa_msg(sa_o, xyz, xc, new, nc, feat),
                "StackSAModuleMSG, odd first width")
+        # 8 samples per ball = 4 queries per wave tile of the fused two-layer kernel, a query count that does not fill the
+        # last tile, second-layer width 40 (two MFMA column tiles, the second partly empty)
+        sa_q = _perturb_bn(smod.StackSAModuleMSG(radii=[1.0], nsamples=[8], mlps=[[8, 32, 40]]).to(dev), 8)
+        nc_odd = nc.copy()
+        nc_odd[-1] -= 1
+        _close(sa_q(t(xyz), t(xc), t(new[:-1]), t(nc_odd), t(feat))[1].cpu().numpy(),
+               sa_oracle.stack_sa_msg(sa_q, xyz, xc, new[:-1], nc_odd, feat), "StackSAModuleMSG, 8 samples, odd query count")
         # far from the origin the commuted first layer subtracts two large products: still inside the tolerance
         far = np.array([60.0, -35.0, 1.0], np.float32)
         _close(sa(t(xyz + far), t(xc), t(new + far), t(nc), t(feat))[1].cpu().numpy(),
