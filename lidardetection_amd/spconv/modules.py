@@ -137,6 +137,8 @@ def prebuild_rulebooks(module, indices, spatial_shape, batch_size, indice_dict, 
 
 
 _RULEBOOK_STREAMS = {}
+# stages the rulebook stream is enqueued ahead of the feature stream (0-3 measured equal: the host is not the limit any more)
+RULEBOOK_STAGES_AHEAD = int(__import__("os").environ.get("LIDAR_SPCONV_AHEAD", "1"))
 
 
 def _hand_tables_to(stream, indice_dict):
@@ -221,7 +223,7 @@ def _run_stages_pipelined(stages, x):
     indices.record_stream(rb)
     bs, idict = x.batch_size, x.indice_dict
     outs = []
-    ahead = int(__import__("os").environ.get("LIDAR_SPCONV_AHEAD", "1"))       # stages the rulebook stream is enqueued ahead of the features
+    ahead = RULEBOOK_STAGES_AHEAD
     try:                                         # plain set_stream calls: the context manager costs the host ~10 us a time
         torch.cuda.set_stream(rb)
         ready, built, nxt = [], 0, (indices, x.spatial_shape)
