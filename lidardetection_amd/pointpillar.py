@@ -191,11 +191,15 @@ class PointPillarKITTI(nn.Module):
             return self.post_process_fused(heads[0])
         return self.post_process_torch(*heads)
 
+    def select_topk(self, masked, k):
+        """(B, N) masked scores -> the k best per frame, sorted descending: (scores (B, k), anchor indices (B, k))"""
+        return torch.topk(masked, k, dim=1)
+
     def post_process_fused(self, head):
         a = self.num_anchor_per_loc
         masked, labels_all = anchor_post.anchor_scores(head, a, self.num_class, self.score_thresh, cls_off=0)
         k = min(self.nms_pre, masked.shape[1])
-        top_scores, top_idx = torch.topk(masked, k, dim=1)            # sorted descending == nms_gpu's sort
+        top_scores, top_idx = self.select_topk(masked, k)             # sorted descending == nms_gpu's sort
         counts = (top_scores >= self.score_thresh).sum(dim=1).to(torch.int32)
         boxes = anchor_post.decode_topk(head, top_idx, self.anchors, a, box_off=a * self.num_class,
                                         dir_off=a * (self.num_class + 7), num_dir_bins=self.num_dir_bins,

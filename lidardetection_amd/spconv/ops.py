@@ -199,7 +199,11 @@ def conv_rulebook_begin(indices, batch_size, spatial_shape, ksize, stride, paddi
     num = torch.empty((1,), dtype=torch.int32, device=dev)
     D, H, W = spatial_shape
     token = _grid_token(indice_dict)
-    gin = GRIDS.loaded(indices, batch_size, spatial_shape, token)
+    # a convolution whose output level has the input level's shape (k 3, s 1, p 1) would share ONE pool grid between its input
+    # rows and its output candidates (the pool is keyed by level shape): emptied() would wipe the rows just scattered and the
+    # table builder would read output ids as input rows.  Such a level takes the hash builder.
+    same_level = [int(v) for v in st["out_shape"]] == [int(v) for v in spatial_shape]
+    gin = None if same_level else GRIDS.loaded(indices, batch_size, spatial_shape, token)
     gout = GRIDS.emptied(dev, batch_size, st["out_shape"]) if gin is not None else None
     if gin is not None and gout is not None and n * K <= 0x3FFFFFFF:
         wsb = L.lidar_spconv_grid_outputs_workspace_bytes(n, K)

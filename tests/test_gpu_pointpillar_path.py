@@ -288,6 +288,7 @@ def test_rotated_nms_dense_tiles_bit_exact(dev, thresh, seed, objects, copies):
     tb = torch.from_numpy(bs).to(dev)
     mask_d = iou3d_nms_cuda.nms_mask_debug(tb, thresh).cpu().numpy().view(np.uint64)
     near = np.argwhere(np.abs(iou - thresh) < 2e-6)
+    assert len(near) <= 1e-5 * n * (n - 1), f"{len(near)} of {n * (n - 1)} ordered pairs patched: the escape hatch is bounded at 1e-5"
     for i, j in near:
         if j > i:                                                  # upper triangle only (what the greedy reads)
             bit = np.uint64(1) << np.uint64(j % 64)
@@ -299,6 +300,25 @@ def test_rotated_nms_dense_tiles_bit_exact(dev, thresh, seed, objects, copies):
     keep = torch.LongTensor(n)
     num = iou3d_nms_cuda.nms_gpu(tb, keep, thresh)
     assert keep[:num].tolist() == keep_o.tolist()
+
+
+@pytest.mark.parametrize("seed,thresh", [(3020, 0.1), (3034, 0.01), (3034, 0.1), (3035, 0.01), (3035, 0.1)])
+def test_rotated_nms_dense_tiles_bit_exact_without_patching(dev, seed, thresh):
+    """Dense-tile fixtures (2 objects x 700 proposals, half of all pairs overlap) in which NO pair lies within 2e-6 of the
+    threshold (asserted from the oracle's IoU matrix): device mask words and keep list vs the oracle with nothing patched."""
+    boxes, scores = synth.boxes_nms(seed=seed, objects=2, copies=700)
+    bs = boxes[np.argsort(-scores, kind="stable")]
+    n = len(bs)
+    iou = c_oracle.pairwise(bs, bs, 1)
+    assert int((np.abs(iou - thresh) < 2e-6).sum()) == 0 and ((iou > 0).sum() - n) / (n * (n - 1)) > 0.25
+    mask_o = c_oracle.nms_mask(bs, thresh)
+    tb = torch.from_numpy(bs).to(dev)
+    mask_d = iou3d_nms_cuda.nms_mask_debug(tb, thresh).cpu().numpy().view(np.uint64)
+    for i in range(n):
+        assert np.array_equal(mask_d[i, i // 64:], mask_o[i, i // 64:]), f"mask row {i}"
+    keep = torch.LongTensor(n)
+    num = iou3d_nms_cuda.nms_gpu(tb, keep, thresh)
+    assert keep[:num].tolist() == c_oracle.nms_greedy(mask_o).tolist()
 
 
 def test_nms_normal_and_pre_maxsize(dev):

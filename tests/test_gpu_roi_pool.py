@@ -26,6 +26,8 @@ def _scene(seed, nbox, npts, extent=20.0):
     lx, ly = dx * c - dy * s, dx * s + dy * c
     near = (np.abs(np.abs(lx) - b[:, None, 3] / 2) < 1e-4) | (np.abs(np.abs(ly) - b[:, None, 4] / 2) < 1e-4) | \
            (np.abs(np.abs(p[None, :, 2] - b[:, None, 2]) - b[:, None, 5] / 2) < 1e-4)
+    dropped = int(near.any(0).sum())
+    assert dropped <= 0.01 * npts, f"the 1e-4 face margin removed {dropped} of {npts} points"      # bounded escape hatch
     return boxes, pts[~near.any(0)]
 
 
@@ -81,8 +83,9 @@ def test_roipoint_pool3d(dev):
     assert np.array_equal(pooled.cpu().numpy(), po)
     # S larger than every box's point count -> cyclic duplication path, boxes enlarged by pool_extra_width.  The device and
     # glibc may differ in the last ulp of cos / sin of the heading, which can move a point that sits ON an enlarged face to
-    # the other side; such points (within 1e-3 of a face of any enlarged box, in float64) are taken out of the scene, and the
-    # result must then be exact for EVERY box.
+    # the other side; such points (within 1e-4 of a face of any enlarged box, in float64 — the margin every in-box scene of this
+    # file uses) are taken out of the scene, their number is BOUNDED (<= 0.5 % of the points), and the result must then be
+    # exact for EVERY box.
     bxe = bx.copy()
     bxe[:, :, 3:6] += 0.2
     keep = np.ones((B, N), bool)
@@ -91,11 +94,12 @@ def test_roipoint_pool3d(dev):
         d = p64[None, :, :] - q[:, None, :3]
         c, s_ = np.cos(-q[:, 6])[:, None], np.sin(-q[:, 6])[:, None]
         lx, ly = d[..., 0] * c - d[..., 1] * s_, d[..., 0] * s_ + d[..., 1] * c
-        near = ((np.abs(np.abs(lx) - q[:, None, 3] / 2) < 1e-3) | (np.abs(np.abs(ly) - q[:, None, 4] / 2) < 1e-3)
-                | (np.abs(np.abs(d[..., 2]) - q[:, None, 5] / 2) < 1e-3))
+        near = ((np.abs(np.abs(lx) - q[:, None, 3] / 2) < 1e-4) | (np.abs(np.abs(ly) - q[:, None, 4] / 2) < 1e-4)
+                | (np.abs(np.abs(d[..., 2]) - q[:, None, 5] / 2) < 1e-4))
         keep[b] = ~near.any(0)
     n_keep = int(keep.sum(1).min())
-    assert n_keep > N - 400                                           # only a handful of points are affected
+    print(f"roipoint enlarged boxes: {N - n_keep} of {N} points within 1e-4 of a face removed")
+    assert N - n_keep <= 0.005 * N                                    # bounded: at most 0.5 % of the points
     xyz2 = np.stack([xyz[b][keep[b]][:n_keep] for b in range(B)], 0).copy()
     feat2 = np.stack([feat[b][keep[b]][:n_keep] for b in range(B)], 0).copy()
     pool2 = roipoint_pool3d_utils.RoIPointPool3d(num_sampled_points=512, pool_extra_width=[0.2, 0.2, 0.2])

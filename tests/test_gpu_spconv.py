@@ -38,6 +38,9 @@ CASES = [
     ([11, 8, 8], [3, 1, 1], [2, 1, 1], [0, 0, 0], False, 64, 128, False),
     ([6, 10, 10], [3, 3, 3], [1, 1, 1], [1, 1, 1], True, 5, 16, True),      # odd Cin (NuScenes' 5 point features)
     ([8, 9, 7], [3, 3, 3], [1, 1, 1], [0, 0, 0], True, 32, 32, False),
+    # regular convolutions whose OUTPUT level has the INPUT level's shape: both would map to one pool grid
+    ([9, 14, 16], [3, 3, 3], [1, 1, 1], [1, 1, 1], False, 16, 16, False),
+    ([7, 8, 9], [3, 1, 1], [1, 1, 1], [1, 0, 0], False, 16, 32, True),
 ]
 
 
@@ -340,7 +343,8 @@ def test_dense_grid_rulebooks_equal_hash_rulebooks(dev):
     coordinates, and a budget too small for the grid (fallback to the hash builder)."""
     from lidardetection_amd.spconv import ops
     geoms = [([9, 14, 16], [3, 3, 3], [2, 2, 2], [1, 1, 1]), ([5, 12, 10], [3, 3, 3], [2, 2, 2], [0, 1, 1]),
-             ([11, 8, 8], [3, 1, 1], [2, 1, 1], [0, 0, 0]), ([41, 60, 52], [3, 3, 3], [2, 2, 2], [1, 1, 1])]
+             ([11, 8, 8], [3, 1, 1], [2, 1, 1], [0, 0, 0]), ([41, 60, 52], [3, 3, 3], [2, 2, 2], [1, 1, 1]),
+             ([9, 14, 16], [3, 3, 3], [1, 1, 1], [1, 1, 1]), ([7, 8, 9], [3, 1, 1], [1, 1, 1], [1, 0, 0])]   # same-shape output level
     B = 3
     for shape, ks, st, pd in geoms:
         cells = B * shape[0] * shape[1] * shape[2]
