@@ -37,12 +37,13 @@ extern "C" {
  *   range6/voxel_size3/grid3  HOST arrays: [x0,y0,z0,x1,y1,z1], [vx,vy,vz], [nx,ny,nz]
  *   compact       1: frame f's rows start at sum_{g<f} V_g (the collate_batch layout)
  *                 0: frame f's rows start at f*max_voxels
- *   algo          0: auto (3 when it applies, else 2); 1: LDS-binned hashing, 3 launches (key + zero-fill, bin, emit);
- *                 3: LDS-binned, 2 launches (fused key + bin + zero-fill, emit; a bin with more than 6144 points —
- *                 zero-padded clouds — is handled exactly by a streaming variant); 1 and 3 need n_max <= 32768 and
- *                 have no global atomics on the data path; more distinct voxels / list cells in ONE hash bin than its
- *                 LDS holds (adversarial input only) sets the sticky flag read by lidar_voxelize_error_flag / mirrored
- *                 to the host by lidar_voxelize_set_error_mirror; 2: global hash table (any n_max);
+ *   algo          0: auto (3 when it applies, else 2); 3 (1 is accepted as an alias): LDS-binned, 2 launches — bin + zero-fill
+ *                 roles in one launch, then emit; a frame's points are hash-partitioned by pillar into n_max / 1280 bins, one
+ *                 workgroup each (a bin with more than 3072 points — zero-padded clouds — is handled exactly by a streaming
+ *                 variant); needs n_max <= 32768, max_points < 16384 and an x / y grid below 2^24 cells; no global atomics
+ *                 on the data path; more distinct voxels (4096) / list cells (3072) in ONE hash bin than its LDS holds
+ *                 (adversarial input only) sets the sticky flag read by lidar_voxelize_error_flag / mirrored to the host by
+ *                 lidar_voxelize_set_error_mirror; 2: global hash table (any n_max);
  *                 4: as 3 with a RESIDENT output buffer (compact layout): the caller passes the SAME voxels / num_points
  *                 buffers call after call and does not write to them in between; the zero padding then survives from call
  *                 to call and only the slots the previous call filled are re-zeroed (~30 MB of HBM traffic per 16 KITTI
@@ -64,7 +65,7 @@ int lidar_voxelize(const float *points, const int *point_offsets, int batch, int
  * the flag without a copy or a synchronisation (nullptr unregisters).  Cleared by the caller. */
 int lidar_voxelize_set_error_mirror(void *ws, size_t ws_bytes, int batch, int n_max, int max_voxels, int *host_flag,
                                     void *stream);
-/* host-synchronous read of the sticky overflow flag of algo 1 / 3 (0 = fine); not for use inside captures */
+/* host-synchronous read of the sticky overflow flag of algo 3 / 4 (0 = fine); not for use inside captures */
 int lidar_voxelize_error_flag(void *ws, size_t ws_bytes, int batch, int n_max, int max_voxels);
 
 /* HOST voxel generator: spconv.utils.VoxelGeneratorV2.generate for ONE frame on a CPU core, for the reference's real call

@@ -145,9 +145,24 @@ def host_i32(vals):
     return (C.c_int * len(vals))(*[int(v) for v in vals])
 
 
-def require_cuda(*tensors):
+def require_cuda(*tensors, allow=()):
+    """Every tensor handed to the C ABI: on the device, contiguous, and float32 or int32 (the only element types the kernels
+    read; the reference assumes them without checking — a float64 / int64 tensor would be reinterpreted bit-wise).  `allow`:
+    further dtypes a particular entry point takes (e.g. torch.int64 keep lists)."""
+    import torch
+    ok = (torch.float32, torch.int32) + tuple(allow)
     for t in tensors:
-        if t is not None and not t.is_cuda:
+        if t is None:
+            continue
+        if not t.is_cuda:
             raise LidarHipError("expected a CUDA (ROCm) tensor; this library has no CPU path")
-        if t is not None and not t.is_contiguous():
+        if not t.is_contiguous():
             raise LidarHipError("expected a contiguous tensor")
+        if t.dtype not in ok:
+            raise LidarHipError(f"expected a float32 / int32 tensor, got {t.dtype} (shape {tuple(t.shape)})")
+
+
+def require_last(t, k, what):
+    """last dimension of `t` must be k (boxes: 7, points: 3, ...)"""
+    if t is not None and (t.dim() == 0 or t.shape[-1] != k):
+        raise LidarHipError(f"{what}: expected (..., {k}), got {tuple(t.shape)}")

@@ -22,7 +22,8 @@ def anchor_scores(head, anchors_per_loc, num_class, score_thresh, cls_off=0):
 
 def decode_topk(head, top_idx, anchors, anchors_per_loc, box_off, dir_off, num_dir_bins, dir_offset, dir_limit_offset):
     """-> boxes (B, k, 7) of the anchors top_idx (B, k) int64 selects, decoded as generate_predicted_boxes does."""
-    _lib.require_cuda(head, top_idx, anchors)
+    _lib.require_cuda(head, top_idx, anchors, allow=(torch.int64,))
+    _lib.require_last(anchors, 7, "anchors")
     if top_idx.dtype != torch.int64:
         raise _lib.LidarHipError("decode_topk: top_idx must be int64 (torch.topk indices)")
     B, C = head.shape[0], head.shape[-1]

@@ -36,22 +36,36 @@ __device__ __forceinline__ bool pt_in_box(const BoxCS &b, float x, float y, floa
 }
 
 // ------------------------------------------------------------------ points_in_boxes_gpu
+// boxes staged through LDS in tiles of PIB_TILE (cos / sin once per box and workgroup): any number of boxes, as the reference
+// (roiaware_pool3d_kernel.cu:313-336: lowest box id containing the point, first hit wins)
+#define PIB_TILE 1024
 __global__ __launch_bounds__(256) void points_in_boxes_kernel(int B, int T, int P, const float *__restrict__ boxes,
                                                               const float *__restrict__ pts, int *__restrict__ out) {
-    extern __shared__ BoxCS s_box[];
+    __shared__ BoxCS s_box[PIB_TILE];
     const int bb = blockIdx.y, t = threadIdx.x;
-    for (int k = t; k < T; k += 256) s_box[k] = make_boxcs(boxes + ((size_t)bb * T + k) * 7);
-    __syncthreads();
     const int p = blockIdx.x * 256 + t;
-    if (p >= P) return;
-    const float *q = pts + ((size_t)bb * P + p) * 3;
-    const float x = q[0], y = q[1], z = q[2];
-    float lx, ly;
-    for (int k = 0; k < T; ++k)
-        if (pt_in_box(s_box[k], x, y, z, lx, ly)) {
-            out[(size_t)bb * P + p] = k;   // lowest box id; the caller pre-fills -1
-            return;
+    float x = 0.f, y = 0.f, z = 0.f;
+    if (p < P) {
+        const float *q = pts + ((size_t)bb * P + p) * 3;
+        x = q[0]; y = q[1]; z = q[2];
+    }
+    int found = p < P ? -1 : 0;                       // threads past the end have nothing to look for
+    for (int k0 = 0; k0 < T; k0 += PIB_TILE) {
+        const int nk = min(PIB_TILE, T - k0);
+        __syncthreads();                              // the previous tile has been read by everyone
+        for (int k = t; k < nk; k += 256) s_box[k] = make_boxcs(boxes + ((size_t)bb * T + k0 + k) * 7);
+        __syncthreads();
+        if (found < 0) {
+            float lx, ly;
+            for (int k = 0; k < nk; ++k)
+                if (pt_in_box(s_box[k], x, y, z, lx, ly)) {
+                    found = k0 + k;                   // lowest box id
+                    break;
+                }
         }
+        if (__syncthreads_and(found >= 0)) break;     // every point of the workgroup is settled
+    }
+    if (p < P && found >= 0) out[(size_t)bb * P + p] = found;   // the caller pre-fills -1
 }
 
 LIDAR_EXPORT int lidar_points_in_boxes(int batch, int boxes_num, int pts_num, const float *boxes, const float *pts,
@@ -59,9 +73,8 @@ LIDAR_EXPORT int lidar_points_in_boxes(int batch, int boxes_num, int pts_num, co
     if (batch <= 0 || boxes_num < 0 || pts_num < 0) return LIDAR_ERR_ARG;
     if (pts_num == 0 || boxes_num == 0) return LIDAR_OK;
     if (!boxes || !pts || !box_idx_of_points) return LIDAR_ERR_ARG;
-    if ((size_t)boxes_num * sizeof(BoxCS) > 60000) return LIDAR_ERR_ARG;
-    hipLaunchKernelGGL(points_in_boxes_kernel, dim3(divup(pts_num, 256), batch), dim3(256), (size_t)boxes_num * sizeof(BoxCS),
-                       (hipStream_t)stream, batch, boxes_num, pts_num, boxes, pts, box_idx_of_points);
+    hipLaunchKernelGGL(points_in_boxes_kernel, dim3(divup(pts_num, 256), batch), dim3(256), 0, (hipStream_t)stream, batch, boxes_num,
+                       pts_num, boxes, pts, box_idx_of_points);
     return lidar_check_launch("lidar_points_in_boxes");
 }
 

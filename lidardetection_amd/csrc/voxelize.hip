@@ -19,14 +19,22 @@
 //               coords + counts, and restores the workspace (hash table, lists) to its clean state
 #include "common.h"
 #include <stdlib.h>
+#include <type_traits>
 
 #define VX_EMPTY 0xFFFFFFFFu
 #define VX_INF 0x7FFFFFFF
 #define VX_TILE 1024
 #define VX_ROWS_PER_BLOCK 64
+// LDS-binned path (algo 3 / 4): a frame's points are hash-partitioned by PILLAR into G ~ n_max / VXL_PTS_PER_BIN bins (a power
+// of two between 8 and 32), one
+// workgroup per (bin, frame); sizes below are per bin workgroup (74 KB of LDS: two workgroups per CU)
 #ifndef VXL_PTS_PER_BIN
-#define VXL_PTS_PER_BIN 2560   // LDS-binned path: expected points per hash bin (bins per frame = n_max / this)
+#define VXL_PTS_PER_BIN 1280   // expected points per bin
 #endif
+#define VXL_SBITS 12
+#define VXL_S (1 << VXL_SBITS)  // LDS table slots per bin
+#define VXL_CAP 3072            // LDS entry / list-cell capacity per bin
+#define VXL_GMAX 32             // bins per frame (n_max <= 32768)
 
 typedef float vx_f4 __attribute__((ext_vector_type(4)));
 // streaming (non-temporal) 16-B store: the padded voxel rows are written once and not re-read here
@@ -46,13 +54,11 @@ struct VxParams {
 };
 
 struct VxWs {
-    // ---- LDS-binned path (algo 1)
-    int *pfirst;     // [B][n_max] index of the first point of the point's voxel (-1 = outside)
-    int *flagw;      // [B][n_max] first points: min(count,P) | VX_SINGLE ; others 0
-    int2 *vinfo;     // [B][n_max] at first points: (voxel rank or -1, list offset)
+    // ---- LDS-binned path (algo 3 / 4)
+    int *flagw;      // [B][n_max] one word per point: 0, or for a voxel's first point min(count, P) | list position << 14
+    int *stgi;       // [B][G][VXL_CAP] every bin's packed point-index lists (read by the emit launch when C != 4)
+    float4 *stg4;    // [B][G][VXL_CAP] C == 4: the POINTS of the list cells beyond each list's head, same positions
     int *err;        // [1] sticky error flag (LDS table / entry list overflow)
-    int2 *queue;     // [B][tile][G][1024] (point, key): each 1024-point tile partitioned by bin
-    int *qcnt;       // [B][tile][G] entries per (tile, bin) segment
     int *tcnt;       // [B][G][32] first points of bin g per 1024-point tile (the emit stage turns them into voxel ids)
     // ---- global-hash path (algo 2)
     uint32_t *keys;  // [B][H]
@@ -91,6 +97,12 @@ static int vx_hash_capacity(int n_max) {
     return h;
 }
 
+static int vxl_bins(int n_max) {              // bins per frame: the power of two >= n_max / VXL_PTS_PER_BIN, 8 .. VXL_GMAX
+    int g = 8;
+    while (g < VXL_GMAX && g * VXL_PTS_PER_BIN < n_max) g <<= 1;
+    return g;
+}
+
 static size_t vx_carve(void *base, int B, int n_max, int max_voxels, VxWs *w) {
     const size_t H = (size_t)vx_hash_capacity(n_max);
     const int ntiles = divup(n_max > 0 ? n_max : 1, VX_TILE);
@@ -101,13 +113,12 @@ static size_t vx_carve(void *base, int B, int n_max, int max_voxels, VxWs *w) {
         return (char *)base + o;
     };
     char *p;
-    p = take((size_t)B * (divup(n_max, VXL_PTS_PER_BIN) * 6144) * 4); if (w) w->pfirst = (int *)p;  // also the LDS path's staging lists
+    const size_t G = (size_t)vxl_bins(n_max);
     p = take((size_t)B * n_max * 4); if (w) w->flagw = (int *)p;
-    p = take((size_t)B * n_max * 8); if (w) w->vinfo = (int2 *)p;
-    p = take(65536); if (w) w->err = (int *)p;  // [0] sticky error flag
-    p = take((size_t)B * divup(n_max, 1024) * divup(n_max, VXL_PTS_PER_BIN) * 1024 * 8 + 65536); if (w) w->queue = (int2 *)p;  // [B][tile][G][1024]
-    p = take((size_t)B * divup(n_max, 1024) * divup(n_max, VXL_PTS_PER_BIN) * 4 + 256); if (w) w->qcnt = (int *)p;             // [B][tile][G]
-    p = take((size_t)B * divup(n_max, VXL_PTS_PER_BIN) * 32 * 4 + 256); if (w) w->tcnt = (int *)p;                               // [B][G][32]
+    p = take((size_t)B * G * VXL_CAP * 4); if (w) w->stgi = (int *)p;
+    p = take((size_t)B * G * VXL_CAP * 16); if (w) w->stg4 = (float4 *)p;
+    p = take(65536); if (w) w->err = (int *)p;  // [0] sticky error flag (+ debug stamps)
+    p = take((size_t)B * G * 32 * 4 + 256); if (w) w->tcnt = (int *)p;                               // [B][G][32]
     p = take(B * H * 4); if (w) w->keys = (uint32_t *)p;
     p = take(B * H * 4); if (w) w->first = (int *)p;
     p = take(B * H * 4); if (w) w->cnt = (int *)p;
@@ -120,7 +131,7 @@ static size_t vx_carve(void *base, int B, int n_max, int max_voxels, VxWs *w) {
     p = take((size_t)B * ntiles * 2 * 4); if (w) w->tile_sums = (int *)p;
     p = take((size_t)B * 4); if (w) w->nvox = (int *)p;
     p = take(256); if (w) w->fillst = (int *)p;
-    p = take((size_t)B * 16 * 4 + 256); if (w) w->bvox = (int *)p;
+    p = take((size_t)B * VXL_GMAX * 4 + 256); if (w) w->bvox = (int *)p;
     p = take(256); if (w) w->resident = (long long *)p;
     p = take(256); if (w) w->mirror = (int **)p;
     return off;
@@ -423,21 +434,20 @@ __global__ __launch_bounds__(256) void vx_rows_kernel(const float *__restrict__ 
 }
 
 
-// ================================================================== LDS-binned path (algo 1)
-// No global atomics at all.  A frame's points are hash-partitioned by voxel key into G bins by the key kernel (whose
-// launch also zero-fills the whole padded output, see vxl_key_kernel); workgroup (g, f) of the bin kernel takes its bin's
-// (point, key) pairs and resolves everything that is local to a voxel inside LDS with LDS atomics:
-//   first point, point count, and the ascending list of its first P point indices (the same
-//   order-independent atomicMin insertion chain as the global path, but on LDS).
-// It leaves one 32-bit word per point (0, or for a voxel's first point: count | list position) and
-// the bin's packed index lists.  A one-block-per-frame ballot scan then ranks the first points
-// (= voxel ids in first-appearance order), and the scatter stage writes the occupied slots, coords and counts.
-#define VXL_S 8192          // LDS table slots per bin
-#define VXL_CAP 6144        // LDS entry / list capacity (points per bin)
-#define VXL_MBITS 14        // pinfo word: m = min(count, P) in the low 14 bits, list position above
+
+
+// ================================================================== LDS-binned path (algo 3 / 4): 2 launches
+// No global atomics on the data path.  A frame's points are hash-partitioned by PILLAR (x / y cell) into G bins; workgroup
+// (g, f) of the first launch resolves everything that is local to a voxel inside LDS with LDS atomics: point count and the
+// ascending list of its first P point indices (order-independent atomicMin insertion chain, whose head is the voxel's first
+// point).  It leaves one 32-bit word per point (0, or for a voxel's first point: count | list position) and the bin's packed
+// lists.  The second launch ranks the first points (= voxel ids in first-appearance order) and writes the rows.
+#define VXL_MBITS 14        // per-point word: m = min(count, P) in the low 14 bits, list position above
 #define VXL_MMASK ((1 << VXL_MBITS) - 1)
-#define VXL_MAX_ITEMS 32    // rank kernel: n_max <= 32 * 1024
-#define VXL_U 8             // points per thread per prefetch step
+#define VXL_MAX_ITEMS 32    // n_max <= 32 * 1024 (a point index fits 15 bits)
+#define VXL_RISK_CAP 512    // parked points per bin workgroup (expected ~10 per frame); more -> the streaming variant
+#define VXL_A_U 5           // points per thread and round in phase A1 (two rounds in flight)
+#define VXL_FILL_F4_PER_WG (1024 * 4)      // 64 KiB of zeros per fill chunk
 
 // floor(fl(d / vs)) — the reference's expression — without paying for the IEEE division when it
 // cannot matter: q' = fl(d * fl(1/vs)) is within 2^-22 (relative) of the true quotient, and so is
@@ -471,12 +481,21 @@ __device__ __forceinline__ bool vx_pillar(const VxParams &p, float x, float y, u
     return inside;
 }
 
-// Branch-free first look at one coordinate (phase A of the fused launch evaluates x and y of EVERY point of a frame in
-// each of its bin workgroups, so instructions count): c = floor(d * fl(1/vs)), ok = 0 <= c < n, and risky = "an integer
-// lies within the rounding margin of the quotient (or it is NaN / inf): the exact IEEE division must decide" — the same
-// criterion as vx_floor_div with the margin in absolute form (eabs >= |q| * 4.8e-7 for every quotient inside the grid; a
-// quotient far outside the grid is outside whatever its last bit).  Risky coordinates (~0.1 %) are re-evaluated with
-// vx_pillar afterwards.
+// exact pillar in the EXTENDED (nx + 1) x (ny + 1) grid the bins are chosen by: column nx / row ny collect everything outside
+// in x / y (NaN included), so every point has exactly one bin
+__device__ __forceinline__ uint32_t vx_pillar_ext(const VxParams &p, float x, float y) {
+    const float fx = vx_floor_div(x - p.lo[0], p.vs[0], p.rvs[0]);
+    const float fy = vx_floor_div(y - p.lo[1], p.vs[1], p.rvs[1]);
+    const uint32_t cx = ((fx >= 0.f) & (fx < (float)p.grid[0])) ? (uint32_t)fx : (uint32_t)p.grid[0];
+    const uint32_t cy = ((fy >= 0.f) & (fy < (float)p.grid[1])) ? (uint32_t)fy : (uint32_t)p.grid[1];
+    return cy * ((uint32_t)p.grid[0] + 1u) + cx;
+}
+
+// Branch-free first look at one coordinate (phase A1 evaluates x and y of EVERY point of a frame in each of its bin
+// workgroups, so instructions count): c = floor(d * fl(1/vs)), ok = 0 <= c < n, and risky = "an integer lies within the
+// rounding margin of the quotient (or it is NaN / inf): the exact IEEE division must decide" — the same criterion as
+// vx_floor_div with the margin in absolute form (eabs >= |q| * 4.8e-7 for every quotient inside the grid; a quotient far
+// outside the grid is outside whatever its last bit).  Risky coordinates (~0.1 %) are re-evaluated with vx_pillar afterwards.
 __device__ __forceinline__ void vx_cell_fast(float d, float rvs, float eabs, int n, int &c, bool &ok, bool &risky) {
     const float q = d * rvs;
     const float fl = floorf(q);
@@ -486,7 +505,7 @@ __device__ __forceinline__ void vx_cell_fast(float d, float rvs, float eabs, int
     ok = (unsigned)c < (unsigned)n;
 }
 
-// full cell: key as vx_cell, plus the pillar index the fused launch bins by
+// full cell: key as vx_cell, plus the pillar index the bins are chosen by
 __device__ __forceinline__ bool vx_cell_pillar(const VxParams &p, float x, float y, float z, uint32_t &key, uint32_t &pillar) {
     const bool in_xy = vx_pillar(p, x, y, pillar);
     const float fz = vx_floor_div(z - p.lo[2], p.vs[2], p.rvs[2]);
@@ -495,406 +514,11 @@ __device__ __forceinline__ bool vx_cell_pillar(const VxParams &p, float x, float
     return inside;
 }
 
-// K0: one workgroup per 1024-point tile: voxel key per point, bin = hash(key) % G, and an in-block
-// partition of the tile's (point, key) pairs by bin (wave ballots + a 16 x G LDS count table; no
-// atomics).  Outside-the-grid points get their per-point word (0) here and enter no bin.
-#define VXL_GMAX 16
-#define ITEMS_TILES(p) (((p).n_max + 1023) >> 10)
-// Workgroups x < ntiles: one 1024-point tile each (cells, partition by bin).  Workgroups x >= ntiles: zero-fill role — the
-// padded voxel rows are 96 % zeros and none of them depends on the index build, so the whole output buffer is cleared
-// HERE, inside the first launch of the sequence (a plain 136 MB fill runs at 7.6 TB/s on this part, i.e. 19 us, and hides
-// the key stage completely); the row stage then only scatters the occupied slots.  Running the fill beside the later,
-// latency-critical bin / rank launches instead was measured and loses.
-#define VXL_FILL_F4_PER_WG (1024 * 4)      // 64 KiB of zeros per fill workgroup
-template <bool C4>
-__global__ __launch_bounds__(1024) void vxl_key_kernel(const float *__restrict__ points,
-                                                       const int *__restrict__ offsets, VxParams p, VxWs w, int G,
-                                                       int ntiles, float *__restrict__ voxels, long long fill_f4_per_frame,
-                                                       long long fill_tail_floats) {
-    __shared__ int s_wc[16][VXL_GMAX];   // per wave, per bin counts -> exclusive offsets
-    if ((int)blockIdx.x >= ntiles) {     // ---- zero-fill role (block-uniform)
-        const long long c = (long long)blockIdx.x - ntiles;
-        float4 *dst = reinterpret_cast<float4 *>(voxels) + (long long)blockIdx.y * fill_f4_per_frame;
-        // compact layout: only the rows a call can plausibly produce are cleared here — the previous call's total + 25 % (kept
-        // in the workspace, no host involvement); rows beyond that are written whole by their emit thread (rare)
-        const long long lim_rows = p.compact ? (long long)w.fillst[0] : 0x7fffffffll;
-        const long long lim_f4 = (lim_rows >= 0x7fffffffll) ? (1ll << 62) : (lim_rows * p.P * p.C + 3) / 4;
-        const long long g0 = (long long)blockIdx.y * fill_f4_per_frame + c * VXL_FILL_F4_PER_WG;
-        if (g0 >= lim_f4) return;
-        const float4 z = make_float4(0.f, 0.f, 0.f, 0.f);
-#pragma unroll
-        for (int k = 0; k < 4; ++k) {
-            const long long i = c * VXL_FILL_F4_PER_WG + k * 1024 + threadIdx.x;
-            if (i < fill_f4_per_frame && g0 + k * 1024 + threadIdx.x < lim_f4)
-                dst[i] = z;                              // plain stores: non-temporal ones measured slower (49.6 vs 43.9 us)
-        }
-        if (blockIdx.y == gridDim.y - 1 && c == 0 && (long long)threadIdx.x < fill_tail_floats)   // bytes past the last float4
-            voxels[(long long)gridDim.y * fill_f4_per_frame * 4 + threadIdx.x] = 0.f;
-        return;
-    }
-    const int tile = blockIdx.x, f = blockIdx.y, t = threadIdx.x, l = t & 63, wv = t >> 6;
-    const int start = offsets[f];
-    const int n = min(offsets[f + 1] - start, p.n_max);
-    if (tile == 0 && t == 0) w.nvox[f] = 0;        // LDS path: first points of the frame, summed up by the bin workgroups
-    const int j = tile * 1024 + t;
-    const int jc = min(j, max(n - 1, 0));
-    float x = 0.f, y = 0.f, z = 0.f;
-    if (n > 0) {  // block-uniform: an empty frame has no row to read
-        if (C4) {
-            const float4 v = reinterpret_cast<const float4 *>(points)[(size_t)start + jc];
-            x = v.x; y = v.y; z = v.z;
-        } else {
-            const float *q = points + ((size_t)start + jc) * p.C;
-            x = q[0]; y = q[1]; z = q[2];
-        }
-    }
-    uint32_t key;
-    const bool inside = vx_cell(p, x, y, z, key) && (j < n);
-    // every point's word starts at 0: outside points keep it, and so does a point dropped by a bin overflow (its word
-    // must never be stale memory — the rank / row kernels index with it)
-    if (j < n) w.flagw[(size_t)f * p.n_max + j] = 0;
-    const uint32_t h2 = (key * 0x85EBCA6Bu) >> 16;
-    const int bin = inside ? (int)((h2 * (uint32_t)G) >> 16) : -1;
-    int myrank = 0;
-    for (int b = 0; b < G; ++b) {
-        const unsigned long long mm = __ballot(bin == b);
-        if (bin == b) myrank = __popcll(mm & lanemask_lt());
-        if (l == 0) s_wc[wv][b] = __popcll(mm);
-    }
-    __syncthreads();
-    if (t < G) {  // exclusive scan over the 16 waves for bin t; total -> segment count
-        int acc = 0;
-        for (int k = 0; k < 16; ++k) {
-            const int c = s_wc[k][t];
-            s_wc[k][t] = acc;
-            acc += c;
-        }
-        w.qcnt[((size_t)f * ntiles + tile) * G + t] = acc;
-    }
-    __syncthreads();
-    if (bin >= 0)
-        w.queue[(((size_t)f * ntiles + tile) * G + bin) * 1024 + s_wc[wv][bin] + myrank] = make_int2(j, (int)key);
-}
-
-// K1: workgroup (g, f) = bin g of frame f.
-template <int ITEMS>
-__global__ __launch_bounds__(1024) void vxl_bin_kernel(const int *__restrict__ offsets, VxParams p, VxWs w, int G) {
-    __shared__ uint32_t s_key[VXL_S];   // phase B: keys; phase C..E: list offset of the slot
-    __shared__ int s_first[VXL_S];
-    __shared__ int s_cnt[VXL_S];
-    __shared__ int2 s_q[VXL_CAP];       // phase B: (point, key); afterwards x = point | slot << 15, y = list cell
-    __shared__ int s_wtot[16];
-    __shared__ int s_tc[32];            // first points of this bin per 1024-point tile
-    __shared__ int s_nent, s_total;
-    const int g = blockIdx.x, f = blockIdx.y, t = threadIdx.x, l = t & 63, wv = t >> 6;
-    const int n = min(offsets[f + 1] - offsets[f], p.n_max);
-    if (t < 32) s_tc[t] = 0;
-    if (g == 0 && f == 0 && t == 0) w.fillst[1] = w.fillst[0];   // what the fill role of THIS call used; the emit launch reads it
-    // ---- phase B1 (loads): my bin's (point, key) pairs from the ITEMS tile segments written by K0.
-    // Counts and the first 256 entries of every segment are requested together (one memory round trip,
-    // overlapped with the LDS initialisation below); longer segments are topped up afterwards.
-    const int nt = (n + 1023) >> 10;
-    const int *qc = w.qcnt + (size_t)f * ITEMS_TILES(p) * G;
-    int cnt_u[ITEMS];
-    int2 ent[ITEMS];
-#pragma unroll
-    for (int u = 0; u < ITEMS; ++u) cnt_u[u] = qc[min(u, max(nt - 1, 0)) * G + g];
-#pragma unroll
-    for (int u = 0; u < ITEMS; ++u) {
-        const int2 *seg = w.queue + (((size_t)f * ITEMS_TILES(p) + min(u, max(nt - 1, 0))) * G + g) * 1024;
-        ent[u] = seg[min(t, 255)];
-    }
-    for (int k = t; k < VXL_S; k += 1024) {
-        s_key[k] = VX_EMPTY;
-        s_first[k] = VX_INF;
-        s_cnt[k] = 0;
-    }
-    __syncthreads();
-    {
-        int base = 0;
-#pragma unroll
-        for (int u = 0; u < ITEMS; ++u) {
-            const int c = (u < nt) ? cnt_u[u] : 0;
-            if (t < min(c, 256)) {
-                if (base + t < VXL_CAP) s_q[base + t] = ent[u];
-                else vx_raise(w, 2);
-            }
-            if (c > 256) {  // block-uniform, rare: a tile that sends more than a quarter of its points to one bin
-                const int2 *seg = w.queue + (((size_t)f * ITEMS_TILES(p) + u) * G + g) * 1024;
-                if (t >= 256 && t < c) {
-                    if (base + t < VXL_CAP) s_q[base + t] = seg[t];
-                    else vx_raise(w, 2);
-                }
-            }
-            base += c;
-        }
-        if (t == 0) s_nent = base;
-    }
-    __syncthreads();
-    const int ne = min(s_nent, VXL_CAP);
-    // ---- phase B2: dense insertion into the LDS hash table (first point, count per voxel)
-    for (int e = t; e < ne; e += 1024) {
-        const int2 q = s_q[e];
-        const int j = q.x;
-        const uint32_t key = (uint32_t)q.y;
-        uint32_t h = (key * 2654435761u) >> (32 - 13);  // log2(VXL_S) == 13
-        int slot = -1;
-        for (int probe = 0; probe < VXL_S; ++probe) {
-            const uint32_t old = atomicCAS(&s_key[h], VX_EMPTY, key);
-            if (old == VX_EMPTY || old == key) {
-                slot = (int)h;
-                break;
-            }
-            h = (h + 1u) & (VXL_S - 1);
-        }
-        if (slot >= 0) {
-            atomicMin(&s_first[slot], j);
-            atomicAdd(&s_cnt[slot], 1);
-            s_q[e].x = j | (slot << 15);
-        } else {
-            vx_raise(w, 1);
-            s_q[e].x = j | (int)0x80000000;
-        }
-    }
-    __syncthreads();
-    // ---- phase C: list offsets = exclusive scan of m = min(count, P) over the slots (8 per thread)
-    int mloc[8];
-    int run = 0;
-#pragma unroll
-    for (int k = 0; k < 8; ++k) {
-        mloc[k] = min(s_cnt[t * 8 + k], p.P);
-        run += mloc[k];
-    }
-    const int inc = wave_incl_scan(run);
-    if (l == 63) s_wtot[wv] = inc;
-    __syncthreads();
-    if (t == 0) {
-        int acc = 0;
-        for (int k = 0; k < 16; ++k) {
-            const int v = s_wtot[k];
-            s_wtot[k] = acc;
-            acc += v;
-        }
-        s_total = acc;
-    }
-    __syncthreads();
-    int off = s_wtot[wv] + inc - run;
-#pragma unroll
-    for (int k = 0; k < 8; ++k) {
-        s_key[t * 8 + k] = (uint32_t)off;
-        off += mloc[k];
-    }
-    const int L = min(s_total, VXL_CAP);
-    for (int k = t; k < L; k += 1024) s_q[k].y = VX_INF;
-    __syncthreads();
-    // ---- phase D: ordered lists (P smallest point indices per voxel, ascending) in LDS
-    for (int e = t; e < ne; e += 1024) {
-        const int en = s_q[e].x;
-        if (en < 0) continue;
-        const int j = en & 0x7FFF, slot = (en >> 15) & 0x1FFF;
-        const int c = s_cnt[slot];
-        int2 *Lp = s_q + s_key[slot];
-        if (c == 1) {
-            Lp[0].y = j;
-        } else {
-            const int m = min(c, p.P);
-            int x = j;
-            for (int s = 0; s < m; ++s) {
-                const int old = atomicMin(&Lp[s].y, x);
-                if (old == VX_INF) break;
-                x = max(old, x);
-            }
-        }
-    }
-    __syncthreads();
-    // ---- phase E: per-point word + this bin's packed lists
-    int *pinfo = w.flagw + (size_t)f * p.n_max;
-    for (int e = t; e < ne; e += 1024) {
-        const int en = s_q[e].x;
-        const int j = en & 0x7FFF;
-        int word = 0;
-        if (en >= 0) {
-            const int slot = (en >> 15) & 0x1FFF;
-            if (s_first[slot] == j) word = min(s_cnt[slot], p.P) | ((g * VXL_CAP + (int)s_key[slot]) << VXL_MBITS);
-        }
-        pinfo[j] = word;
-        // per-tile first-point counts, aggregated per wave: the entries arrive tile by tile, so a wave sees 1-2 tile ids
-        const int tau = j >> 10;
-        unsigned long long rem = __ballot(word != 0);
-        while (rem) {                                  // wave-uniform
-            const int lead = __builtin_ctzll(rem);
-            const int t0 = __shfl(tau, lead, 64);
-            const unsigned long long m = __ballot(word != 0 && tau == t0);
-            if (l == lead) atomicAdd(&s_tc[t0], __popcll(m));
-            rem &= ~m;
-        }
-    }
-    int *stg = w.pfirst + ((size_t)f * G + g) * VXL_CAP;   // staging lists live in the pfirst/vinfo region
-    for (int k = t; k < L; k += 1024) stg[k] = s_q[k].y;
-    __syncthreads();
-    if (t < 32) w.tcnt[((size_t)f * G + g) * 32 + t] = s_tc[t];
-    if (t == 0) {
-        int tot = 0;
-        for (int k = 0; k < 32; ++k) tot += s_tc[k];
-        if (tot) atomicAdd(&w.nvox[f], tot);               // visible to the next launch; no ordering needed inside this one
-    }
-}
-
-// Emit stage: workgroup (tile, f) owns the 1024 points of its tile.  A first point's voxel id = (first points of the frame in
-// earlier tiles, from the bin kernel's per-tile counts) + (its ballot rank inside the tile) = first-appearance order; the
-// thread then writes that voxel's row itself: occupied slots only (the buffer is already zero), coords from the first
-// point's cell, count.  No separate ranking launch.
-// rows (= voxels kept) of frame k: the 3-launch path sums them with atomics (nvox), the fused launch leaves one count per bin
-__device__ __forceinline__ int vxl_frame_rows(const VxParams &p, const VxWs &w, int G, int k, int fused) {
-    int c;
-    if (fused) {
-        c = 0;
-        for (int g = 0; g < G; ++g) c += w.bvox[k * VXL_GMAX + g];
-    } else {
-        c = w.nvox[k];
-    }
+// rows (= voxels kept) of frame k: one count per bin, left by the bin workgroups with plain stores
+__device__ __forceinline__ int vxl_frame_rows(const VxParams &p, const VxWs &w, int G, int k) {
+    int c = 0;
+    for (int g = 0; g < G; ++g) c += w.bvox[k * VXL_GMAX + g];
     return min(c, p.max_voxels);
-}
-
-template <bool C4>
-__global__ __launch_bounds__(1024) void vxl_emit_kernel(const float *__restrict__ points, const int *__restrict__ offsets,
-                                                        VxParams p, VxWs w, int G, float *__restrict__ voxels,
-                                                        int *__restrict__ coords, int *__restrict__ num_points,
-                                                        int *__restrict__ voxel_offsets, int fused, int resident) {
-    __shared__ int s_part[16], s_wcnt[16];
-    __shared__ int s_base;
-    const int tile = blockIdx.x, f = blockIdx.y, t = threadIdx.x, l = t & 63, wv = t >> 6;
-    const int start = offsets[f];
-    const int n = min(offsets[f + 1] - start, p.n_max);
-    const int i = tile * 1024 + t;
-    const int wd = w.flagw[(size_t)f * p.n_max + min(i, max(n - 1, 0))];      // unconditional load, masked below
-    const int word = (i < n) ? wd : 0;
-    // this thread's own point, requested together with its word: for a first point it IS slot 0 of the voxel's row, so the
-    // 80 % of voxels that hold a single point need no dependent load at all
-    float4 me = make_float4(0.f, 0.f, 0.f, 0.f);
-    if (C4 && n > 0) me = reinterpret_cast<const float4 *>(points)[(size_t)start + min(i, n - 1)];   // n: block-uniform
-    // first points of the frame in earlier tiles: sum of tcnt[f][g][tau < tile] over the G bins
-    int v = 0;
-    if (t < G * 32) {
-        const int tau = t & 31;
-        const int c = w.tcnt[(size_t)f * G * 32 + t];
-        v = (tau < tile) ? c : 0;
-    }
-    v = wave_sum(v);
-    if (l == 0) s_part[wv] = v;
-    // rows of the earlier frames (every frame's count is complete: the bin launch has finished)
-    if (wv == 15) {
-        int part = 0;
-        if (p.compact)
-            for (int k0 = 0; k0 < f; k0 += 64) {
-                const int k = k0 + l;
-                part += (k < f) ? vxl_frame_rows(p, w, G, k, fused) : 0;
-            }
-        part = wave_sum(part);
-        if (l == 0) s_base = p.compact ? part : f * p.max_voxels;
-    }
-    if (tile == 0 && f == 0 && wv == 14) {            // the batch's offsets table (off the critical path)
-        int carry = 0;
-        for (int k0 = 0; k0 < p.batch; k0 += 64) {
-            const int k = k0 + l;
-            const int c = (k < p.batch) ? vxl_frame_rows(p, w, G, k, fused) : 0;
-            const int inc = wave_incl_scan(c);
-            if (k < p.batch) voxel_offsets[k] = p.compact ? carry + inc - c : k * p.max_voxels;
-            carry += __shfl(inc, 63, 64);
-        }
-        if (l == 0) {
-            voxel_offsets[p.batch] = p.compact ? carry : p.batch * p.max_voxels;
-            // rows the next call's fill role should clear up front (nobody reads fillst[0] during this launch)
-            const long long next = (long long)carry + carry / 4 + 1024;
-            w.fillst[0] = p.compact ? (int)min(next, (long long)p.batch * p.max_voxels) : 0x7fffffff;
-            // resident-output history for the next call (a non-resident call leaves rows beyond its fill extent unspecified,
-            // so it invalidates the history)
-            w.resident[0] = resident ? (long long)reinterpret_cast<uintptr_t>(voxels) : 0ll;
-            w.resident[1] = (long long)reinterpret_cast<uintptr_t>(num_points);
-            w.resident[2] = carry;
-            w.resident[3] = (long long)p.P * p.C;
-        }
-    }
-    const long long cleared_rows = p.compact ? (long long)w.fillst[1] : 0x7fffffffll;
-    const unsigned long long bal = __ballot(word != 0);
-    if (l == 0) s_wcnt[wv] = __popcll(bal);
-    __syncthreads();
-    int r = 0;
-    for (int k = 0; k < (G * 32 + 63) / 64 && k < 16; ++k) r += s_part[k];
-    for (int k = 0; k < wv; ++k) r += s_wcnt[k];
-    r += __popcll(bal & lanemask_lt());
-    if (word == 0 || r >= p.max_voxels) return;       // not a first point / voxel beyond the cap (dropped with its points)
-    const int cnt = word & VXL_MMASK;
-    const int *lst = w.pfirst + (size_t)f * G * VXL_CAP + (word >> VXL_MBITS);
-    const uint32_t nx = p.grid[0], ny = p.grid[1];
-    const size_t row = (size_t)s_base + r;
-    float x0 = 0.f, y0 = 0.f, z0 = 0.f;
-    if (C4) {
-        const float4 *pts4 = reinterpret_cast<const float4 *>(points) + start;
-        float4 *out4 = reinterpret_cast<float4 *>(voxels) + row * p.P;
-        out4[0] = me;                                  // slot 0 is this very point (the list is ascending, it is the first)
-        if ((long long)row >= cleared_rows)            // beyond what the fill role cleared: this thread owns the whole row
-            for (int sl = cnt; sl < p.P; ++sl) out4[sl] = make_float4(0.f, 0.f, 0.f, 0.f);
-        x0 = me.x; y0 = me.y; z0 = me.z;
-        for (int s0 = 1; s0 < cnt; s0 += 4) {          // up to 4 independent gathers in flight
-            int pi[4];
-            float4 q[4];
-#pragma unroll
-            for (int k = 0; k < 4; ++k) pi[k] = lst[min(s0 + k, cnt - 1)];
-#pragma unroll
-            for (int k = 0; k < 4; ++k) q[k] = pts4[pi[k]];
-#pragma unroll
-            for (int k = 0; k < 4; ++k)
-                if (s0 + k < cnt) out4[s0 + k] = q[k];
-        }
-    } else {
-        const float *pts = points + (size_t)start * p.C;
-        float *out = voxels + row * p.P * p.C;
-        for (int sl = 0; sl < cnt; ++sl) {
-            const float *q = pts + (size_t)lst[sl] * p.C;
-            for (int c = 0; c < p.C; ++c) out[sl * p.C + c] = q[c];
-            if (sl == 0) { x0 = q[0]; y0 = q[1]; z0 = q[2]; }
-        }
-        if ((long long)row >= cleared_rows)
-            for (int e = cnt * p.C; e < p.P * p.C; ++e) out[e] = 0.f;
-    }
-    uint32_t key;
-    vx_cell(p, x0, y0, z0, key);
-    reinterpret_cast<int4 *>(coords)[row] = make_int4(f, (int)(key / (nx * ny)), (int)((key / nx) % ny), (int)(key % nx));
-    num_points[row] = cnt;
-}
-
-
-// ================================================================== fused key + bin launch (algo 3)
-// One launch instead of two, and no (point, key) queue in HBM (8 MB written + read per 16 frames): workgroup (g, f) reads
-// ALL points of frame f itself (320 KB, L2 / Infinity-Cache hits for 7 of the 8 bins), evaluates their cells and keeps
-// the ones whose key hashes to bin g, appended to the LDS entry list with one wave-aggregated LDS atomic per 64 points.
-// Phases B2..E are those of vxl_bin_kernel.  Every workgroup of the launch reserves the bin role's 144 KB of LDS, so the
-// launch is sized to ONE resident workgroup per CU: ids [0, nbinwg) are bin roles, the rest fill roles that clear the
-// padded output with grid-stride stores while the bin roles run their LDS phases (bin roles join in when they are done).
-// Degenerate input (thousands of points in one voxel, e.g. zero-padded clouds, where (0,0,0) lies inside the KITTI range):
-// when a bin receives more than VXL_CAP entries the workgroup switches to a streaming variant without an entry list —
-// pass 1 builds the table (first / count per voxel) straight from the points, pass 2 re-reads them for the insertion
-// chains and the per-point words — which is exact for any multiplicity; only more than ~VXL_S distinct voxels or more
-// than VXL_CAP list cells in ONE bin still raise the error flag.
-#define VXL_RISK_CAP 512     // parked points per bin workgroup (expected ~20 per frame); more -> the streaming variant
-#define VXL_A_U 20          // points per thread requested together in phase A (one round trip for a 20 k-point frame)
-struct VxlShared {
-    uint32_t *key;
-    int *first, *cnt;
-    int2 *q;
-    int *wtot, *tc, *nent, *total;
-};
-
-__device__ __forceinline__ void vxl_fill_chunks(float4 *__restrict__ dst, long long c0, long long cstep, long long cend,
-                                                long long lim_f4, int t) {
-    const float4 z = make_float4(0.f, 0.f, 0.f, 0.f);
-    for (long long c = c0; c < cend; c += cstep) {
-        const long long b = c * VXL_FILL_F4_PER_WG + t;
-#pragma unroll
-        for (int k = 0; k < 4; ++k)
-            if (b + k * 1024 < lim_f4) dst[b + k * 1024] = z;
-    }
 }
 
 template <bool C4>
@@ -908,20 +532,33 @@ __device__ __forceinline__ void vxl_load_xyz(const float *__restrict__ points, s
     }
 }
 
-__device__ __forceinline__ int vxl_bin_of(uint32_t key, int G) {
-    const uint32_t h2 = (key * 0x85EBCA6Bu) >> 16;
-    return (int)((h2 * (uint32_t)G) >> 16);
+template <bool C4>
+__device__ __forceinline__ void vxl_load_xy(const float *__restrict__ points, size_t idx, int C, float &x, float &y) {
+    if (C4) {
+        const float2 v = reinterpret_cast<const float2 *>(points)[idx * 2];
+        x = v.x; y = v.y;
+    } else {
+        const float *q = points + idx * C;
+        x = q[0]; y = q[1];
+    }
 }
 
-// the fused launch's bin of a pillar: full-rate 24-bit multiplies only (v_mul_lo_u32 is quarter rate)
-__device__ __forceinline__ int vxl_bin_of24(uint32_t pillar, int G) {
-    const uint32_t h = __umul24(pillar, 0x5BCA6Bu) ^ (pillar >> 9);
-    return (int)(__umul24((h >> 8) & 0xFFFFu, (uint32_t)G) >> 16);
+// bin of a pillar: full-rate 24-bit multiplies only (v_mul_lo_u32 is quarter rate)
+__device__ __forceinline__ uint32_t vx_mul_u24(uint32_t a, uint32_t b) {   // low 32 bits of (a & 0xFFFFFF) * (b & 0xFFFFFF)
+    uint32_t r;
+    asm("v_mul_u32_u24 %0, %1, %2" : "=v"(r) : "s"(b), "v"(a));               // (the compiler picks the quarter-rate v_mul_lo_u32 here)
+    return r;
+}
+
+// bin of an (extended-grid) pillar: the top log2(G) bits of a 24-bit multiplicative hash (full-rate v_mul_u32_u24);
+// gsh = 32 - log2(G)
+__device__ __forceinline__ int vxl_bin_of24(uint32_t pillar, int gsh) {
+    return (int)(vx_mul_u24(pillar, 0x5BCA6Bu) >> gsh);
 }
 
 // LDS table insert: slot of `key` (claimed if new), or -1 when the table is full
 __device__ __forceinline__ int vxl_table_insert(uint32_t *s_key, uint32_t key) {
-    uint32_t h = (key * 2654435761u) >> (32 - 13);  // log2(VXL_S) == 13
+    uint32_t h = (key * 2654435761u) >> (32 - VXL_SBITS);
     for (int probe = 0; probe < VXL_S; ++probe) {
         const uint32_t old = atomicCAS(&s_key[h], VX_EMPTY, key);
         if (old == VX_EMPTY || old == key) return (int)h;
@@ -930,37 +567,48 @@ __device__ __forceinline__ int vxl_table_insert(uint32_t *s_key, uint32_t key) {
     return -1;
 }
 
-// exclusive scan of m = min(count, P) over the table slots -> list offsets (into sh.key, whose keys are no longer needed by
-// the caller when `keep_keys` is false; the streaming variant passes a separate array); returns the total list length
-__device__ __forceinline__ int vxl_list_offsets(const VxlShared &sh, int P, int t, uint32_t *off_out) {
+__device__ __forceinline__ int vxl_table_find(const uint32_t *s_key, uint32_t key) {
+    uint32_t h = (key * 2654435761u) >> (32 - VXL_SBITS);
+    for (int probe = 0; probe < VXL_S; ++probe) {
+        const uint32_t k2 = s_key[h];
+        if (k2 == key) return (int)h;
+        if (k2 == VX_EMPTY) return -1;
+        h = (h + 1u) & (VXL_S - 1);
+    }
+    return -1;
+}
+
+// exclusive scan of m = min(count, P) over the VXL_S table slots (4 per thread) -> list offset per slot in off[4];
+// returns the total list length.  Two barriers inside.
+__device__ __forceinline__ int vxl_list_offsets(const int *s_cnt, int *s_wtot, int *s_total, int P, int t, int (&m)[VXL_S / 1024],
+                                                int (&off)[VXL_S / 1024]) {
     const int l = t & 63, wv = t >> 6;
-    int mloc[8];
     int run = 0;
 #pragma unroll
-    for (int k = 0; k < 8; ++k) {
-        mloc[k] = min(sh.cnt[t * 8 + k], P);
-        run += mloc[k];
+    for (int k = 0; k < VXL_S / 1024; ++k) {
+        m[k] = min(s_cnt[t * (VXL_S / 1024) + k], P);
+        run += m[k];
     }
     const int inc = wave_incl_scan(run);
-    if (l == 63) sh.wtot[wv] = inc;
+    if (l == 63) s_wtot[wv] = inc;
     __syncthreads();
     if (t == 0) {
         int acc = 0;
         for (int k = 0; k < 16; ++k) {
-            const int v = sh.wtot[k];
-            sh.wtot[k] = acc;
+            const int v = s_wtot[k];
+            s_wtot[k] = acc;
             acc += v;
         }
-        *sh.total = acc;
+        *s_total = acc;
     }
     __syncthreads();
-    int off = sh.wtot[wv] + inc - run;
+    int o = s_wtot[wv] + inc - run;
 #pragma unroll
-    for (int k = 0; k < 8; ++k) {
-        off_out[t * 8 + k] = (uint32_t)off;
-        off += mloc[k];
+    for (int k = 0; k < VXL_S / 1024; ++k) {
+        off[k] = o;
+        o += m[k];
     }
-    return *sh.total;
+    return *s_total;
 }
 
 // order-independent insertion of point j into the ascending list of its voxel's m smallest point indices
@@ -973,26 +621,64 @@ __device__ __forceinline__ void vxl_chain_insert(int *cell0, int stride_ints, in
     }
 }
 
+__device__ __forceinline__ void vxl_fill_chunks(float4 *__restrict__ dst, long long c0, long long cstep, long long cend,
+                                                long long lim_f4, int t) {
+    const float4 z = make_float4(0.f, 0.f, 0.f, 0.f);
+    for (long long c = c0; c < cend; c += cstep) {
+        const long long b = c * VXL_FILL_F4_PER_WG + t;
+#pragma unroll
+        for (int k = 0; k < 4; ++k)
+            if (b + k * 1024 < lim_f4) dst[b + k * 1024] = z;
+    }
+}
+
+// per-tile first-point counts of one wave's entries (the entries arrive in ascending runs, so a wave sees 1-2 tile ids)
+__device__ __forceinline__ void vxl_count_firsts(int *s_tc, bool isfirst, int j, int l) {
+    const int tau = j >> 10;
+    unsigned long long rem = __ballot(isfirst);
+    while (rem) {                                  // wave-uniform
+        const int lead = __builtin_ctzll(rem);
+        const int t0 = __shfl(tau, lead, 64);
+        const unsigned long long m = __ballot(isfirst && tau == t0);
+        if (l == lead) atomicAdd(&s_tc[t0], __popcll(m));
+        rem &= ~m;
+    }
+}
+
+struct VxlShared {
+    uint32_t *key;
+    int *cnt, *aux;
+    int2 *q;
+    int *wtot, *tc, *total;
+};
+
+// Degenerate input (thousands of points in one voxel, e.g. zero-padded clouds, where (0,0,0) lies inside the KITTI range):
+// a bin that receives more than VXL_CAP entries (or more parked points than VXL_RISK_CAP) runs WITHOUT an entry list —
+// pass 1 builds the table (first point / count per voxel) straight from the points, pass 2 re-reads them for the insertion
+// chains and the per-point words — which is exact for any multiplicity; only more than ~VXL_S distinct voxels or more than
+// VXL_CAP list cells in ONE bin still raise the error flag.
 template <bool C4>
 __device__ __forceinline__ void vxl_bin_streaming(const float *__restrict__ points, const VxParams &p, const VxWs &w, int G,
                                                int g, int f, int start, int n, const VxlShared &sh) {
     const int t = threadIdx.x, l = t & 63;
-    uint32_t *s_off = reinterpret_cast<uint32_t *>(sh.q);            // [VXL_S] list offset per slot
-    int *s_list = reinterpret_cast<int *>(sh.q) + VXL_S;             // [VXL_CAP - VXL_S / 2 ... ] list cells
-    const int LCAP = 2 * VXL_CAP - VXL_S;                            // ints left in the entry region (4096)
+    const int gsh = 32 - (__ffs(G) - 1);
+    int *s_first = sh.aux;                                           // [VXL_S] first point per slot
+    int *s_list = reinterpret_cast<int *>(sh.q);                     // list cells (the entry list is dropped)
+    const int LCAP = VXL_CAP;                                        // list positions index the [G][VXL_CAP] staging arrays
     const int nt = (n + 1023) >> 10;
-    __syncthreads();                                                 // phase A's entry list is dropped: its LDS is re-used
+    for (int k = t; k < VXL_S; k += 1024) s_first[k] = VX_INF;
+    __syncthreads();
     // ---- pass 1: first point and count per voxel, straight from the points
     for (int u = 0; u < nt; ++u) {
         const int j = u * 1024 + t;
         float x, y, z;
         vxl_load_xyz<C4>(points, (size_t)start + min(j, n - 1), p.C, x, y, z);
         uint32_t key, pil;
-        const bool mine = vx_cell_pillar(p, x, y, z, key, pil) && j < n && vxl_bin_of24(pil, G) == g;
+        const bool mine = vx_cell_pillar(p, x, y, z, key, pil) && j < n && vxl_bin_of24(vx_pillar_ext(p, x, y), gsh) == g;
         if (mine) {
             const int slot = vxl_table_insert(sh.key, key);
             if (slot >= 0) {
-                atomicMin(&sh.first[slot], j);
+                atomicMin(&s_first[slot], j);
                 atomicAdd(&sh.cnt[slot], 1);
             } else {
                 vx_raise(w, 1);
@@ -1000,9 +686,12 @@ __device__ __forceinline__ void vxl_bin_streaming(const float *__restrict__ poin
         }
     }
     __syncthreads();
-    const int total = vxl_list_offsets(sh, p.P, t, s_off);
-    if (total > min(LCAP, VXL_CAP) && t == 0) vx_raise(w, 2);
-    const int L = min(total, min(LCAP, VXL_CAP));
+    int m[VXL_S / 1024], off[VXL_S / 1024];
+    const int total = vxl_list_offsets(sh.cnt, sh.wtot, sh.total, p.P, t, m, off);
+    if (total > LCAP && t == 0) vx_raise(w, 2);
+    const int L = min(total, LCAP);
+#pragma unroll
+    for (int k = 0; k < VXL_S / 1024; ++k) sh.cnt[t * (VXL_S / 1024) + k] = (off[k] & 8191) | (m[k] << 13);   // m < 16384
     for (int k = t; k < L; k += 1024) s_list[k] = VX_INF;
     __syncthreads();
     // ---- pass 2: insertion chains, per-point words, per-tile first-point counts
@@ -1012,51 +701,73 @@ __device__ __forceinline__ void vxl_bin_streaming(const float *__restrict__ poin
         float x, y, z;
         vxl_load_xyz<C4>(points, (size_t)start + min(j, n - 1), p.C, x, y, z);
         uint32_t key, pil;
-        const bool in_xy = vx_pillar(p, x, y, pil) && j < n && vxl_bin_of24(pil, G) == g;     // z-outside points of my pillars
-        const bool mine = vx_cell_pillar(p, x, y, z, key, pil) && in_xy;                       // get their word (0) from me too
+        const bool my_bin = j < n && vxl_bin_of24(vx_pillar_ext(p, x, y), gsh) == g;            // points outside the grid get their
+        const bool mine = vx_cell_pillar(p, x, y, z, key, pil) && my_bin;                      // word (0) from their bin too
         int word = 0;
         if (mine) {
-            uint32_t h = (key * 2654435761u) >> (32 - 13);
-            int slot = -1;
-            for (int probe = 0; probe < VXL_S; ++probe) {
-                const uint32_t k2 = sh.key[h];
-                if (k2 == key) { slot = (int)h; break; }
-                if (k2 == VX_EMPTY) break;
-                h = (h + 1u) & (VXL_S - 1);
-            }
+            const int slot = vxl_table_find(sh.key, key);
             if (slot >= 0) {
-                const int m = min(sh.cnt[slot], p.P), off = (int)s_off[slot];
-                if (off + m <= L) {
-                    if (sh.cnt[slot] == 1) s_list[off] = j;
-                    else vxl_chain_insert(s_list + off, 1, m, j);
-                    if (sh.first[slot] == j) word = m | ((g * VXL_CAP + off) << VXL_MBITS);
+                const int pk = sh.cnt[slot];
+                const int mm = pk >> 13, o = pk & 8191;
+                if (o + mm <= L) {
+                    vxl_chain_insert(s_list + o, 1, mm, j);
+                    if (s_first[slot] == j) word = mm | ((g * VXL_CAP + o) << VXL_MBITS);
                 }
             }
         }
-        if (in_xy) pinfo[j] = word;
+        if (my_bin) pinfo[j] = word;
         const unsigned long long bal = __ballot(word != 0);
         if (l == 0 && bal) atomicAdd(&sh.tc[u], __popcll(bal));
     }
     __syncthreads();
-    int *stg = w.pfirst + ((size_t)f * G + g) * VXL_CAP;
-    for (int k = t; k < L; k += 1024) stg[k] = s_list[k];
+    const int Ls = L;
+    int *stgi = w.stgi + ((size_t)f * G + g) * VXL_CAP;
+    float4 *stg4 = w.stg4 + ((size_t)f * G + g) * VXL_CAP;
+    for (int k = t; k < Ls; k += 1024) {
+        const int j = s_list[k];
+        stgi[k] = j;
+        if (C4 && j != VX_INF) stg4[k] = reinterpret_cast<const float4 *>(points)[(size_t)start + j];   // heads included: harmless
+    }
 }
 
+// First launch.  Workgroups [0, nbinwg): bin roles; the rest: fill roles, which clear the padded output (96 % of its bytes
+// are zeros and none depends on the index build) while the bin roles run — 74 KB of LDS and <= 64 VGPRs per workgroup, so a
+// fill workgroup is resident beside every bin workgroup on all 256 CUs.
+//   bin role (g, f):
+//   A1  x / y of ALL points of the frame (8-byte loads, two rounds in flight), branch-free fast cells clamped into an
+//       extended pillar grid (one extra column / row for everything outside in x / y), bin = hash(extended pillar): the
+//       indices of MY points are appended to the LDS entry list (one LDS atomic per wave and round).  Points whose quotient
+//       lies within the rounding margin of an integer (~0.1 %) are parked and settled with the exact IEEE division afterwards.
+//   A2 + B  my ~n / G points only: full point load, exact cell (vx_floor_div), LDS hash table insert, count per voxel.
+//   C   list offsets (scan of min(count, P) over the table slots), list heads marked in a bitmap
+//   D   ordered lists (atomicMin insertion chains)
+//   E   per-point words (a voxel's first point = the head of its list), per-tile first-point counts, staging of the lists
+//       (C == 4: of the points themselves for the cells beyond each head, so the emit launch needs no dependent gather)
 template <bool C4>
-__global__ __launch_bounds__(1024) void vxl_keybin_kernel(const float *__restrict__ points, const int *__restrict__ offsets,
-                                                          VxParams p, VxWs w, int G, int nbinwg, int nfillwg,
-                                                          float *__restrict__ voxels, long long total_f4,
-                                                          long long tail_floats, int help16, int resident,
-                                                          const int *__restrict__ prev_counts) {
+__global__ __launch_bounds__(1024, 8) void vxl_keybin_kernel(const float *__restrict__ points, const int *__restrict__ offsets,
+                                                             VxParams p, VxWs w, int G, int nbinwg, int nfillwg,
+                                                             float *__restrict__ voxels, long long total_f4,
+                                                             long long tail_floats, int help16, int resident,
+                                                             const int *__restrict__ prev_counts) {
     __shared__ uint32_t s_key[VXL_S];   // keys; after phase C: list offset of the slot
-    __shared__ int s_first[VXL_S];
     __shared__ int s_cnt[VXL_S];
-    __shared__ int2 s_q[VXL_CAP];       // (point, key); afterwards x = point | slot << 15, y = list cell
+    __shared__ int s_aux[VXL_S];        // streaming variant only: first point per slot
+    __shared__ int2 s_q[VXL_CAP];       // x: entry (point, then point | slot << 15), y: list cell
+    __shared__ int s_risk[VXL_RISK_CAP];
+    __shared__ uint32_t s_head[VXL_CAP / 32];
     __shared__ int s_wtot[16];
     __shared__ int s_tc[32];
-    __shared__ int s_nent, s_total, s_nrisk;
-    __shared__ float4 s_risk[VXL_RISK_CAP];   // points whose cell the exact division must decide: (x, y, z, index)
+    __shared__ int s_nent, s_total, s_nrisk, s_nadd;
     const int id = blockIdx.x, t = threadIdx.x, l = t & 63;
+#ifdef VXL_STAMPS   // -DVXL_STAMPS (tools/vx_phase_probe.py): shader-clock stamps of bin role 0's phases and the 100 MHz wall
+                    // clock at the start / end of EVERY workgroup of both launches, into the error page
+#define VXL_STAMP(k) do { if (id == 0 && t == 0) w.err[16 + (k)] = (int)clock64(); } while (0)
+#define VXL_WALL(slot) do { if (t == 0) w.err[64 + (slot)] = (int)wall_clock64(); } while (0)
+#else
+#define VXL_STAMP(k) do { } while (0)
+#define VXL_WALL(slot) do { } while (0)
+#endif
+    VXL_WALL(2 * id);
     // ---- resident output (algo 4): the buffer still holds the previous call's result on an otherwise all-zero background, so
     // only the slots that call filled are re-zeroed (rows x count x 16 B instead of the whole padded buffer).  Valid only if the
     // history in the workspace names this very buffer / count array / row width; otherwise: clear everything, as a first call.
@@ -1083,86 +794,97 @@ __global__ __launch_bounds__(1024) void vxl_keybin_kernel(const float *__restric
                     for (int e = 0; e < c * p.C; ++e) o[e] = 0.f;
                 }
             }
+            VXL_WALL(2 * id + 1);
             return;
         }
         vxl_fill_chunks(dst, id - nbinwg, nfillwg, nmain, lim_f4, t);
         if (id == nbinwg && (long long)t < tail_floats) voxels[total_f4 * 4 + t] = 0.f;     // bytes past the last float4
+        VXL_WALL(2 * id + 1);
         return;
     }
     // ---- bin role: id -> (g, f) with the G bins of a frame on ONE XCD (workgroup i runs on XCD i % 8): they share the
     // frame's points through that XCD's L2
     const int q8 = id >> 3;
-    const int f = (id & 7) + 8 * (q8 / G), g = q8 % G;
-    VxlShared sh;
-    sh.key = s_key; sh.first = s_first; sh.cnt = s_cnt; sh.q = s_q;
-    sh.wtot = s_wtot; sh.tc = s_tc; sh.nent = &s_nent; sh.total = &s_total;
-#ifdef VXL_STAMPS   // -DVXL_STAMPS: shader-clock stamps of bin role 0's phases into the error page (tools/vx_phase_probe.py)
-#define VXL_STAMP(k) do { if (id == 0 && t == 0) w.err[16 + (k)] = (int)clock64(); } while (0)
-#else
-#define VXL_STAMP(k) do { } while (0)
-#endif
+    const int lg = __ffs(G) - 1, gsh = 32 - lg;            // G is a power of two
+    const int f = (id & 7) + 8 * (q8 >> lg), g = q8 & (G - 1);
     VXL_STAMP(0);
     if (f < p.batch) {
         const int start = offsets[f];
         const int n = min(offsets[f + 1] - start, p.n_max);
         const int nt = (n + 1023) >> 10;
-        // rows the fill roles of THIS call leave zero (the emit launch reads it): everything in resident mode
-        if (id == 0 && t == 0) w.fillst[1] = resident ? 0x7fffffff : w.fillst[0];
-        for (int k = t; k < VXL_S / 4; k += 1024) {
-            reinterpret_cast<uint4 *>(s_key)[k] = make_uint4(VX_EMPTY, VX_EMPTY, VX_EMPTY, VX_EMPTY);
-            reinterpret_cast<int4 *>(s_first)[k] = make_int4(VX_INF, VX_INF, VX_INF, VX_INF);
-            reinterpret_cast<int4 *>(s_cnt)[k] = make_int4(0, 0, 0, 0);
-        }
-        if (t < 32) s_tc[t] = 0;
-        if (t == 0) s_nent = s_nrisk = 0;
-        __syncthreads();
-        VXL_STAMP(1);
-        // ---- phase A: cells of ALL points of the frame — the 8-fold redundant part of the fused design and VALU-bound, so
-        // kept lean: branch-free fast cells (vx_cell_fast, 24-bit multiplies), ONE rarely taken wave-level branch per point
-        // for the exact re-evaluation of risky coordinates (the operands are still in registers: no reload) and one for
-        // points outside the grid.  Bins are by pillar, so a voxel's points meet in one bin.  A wave owns a contiguous run
-        // of points (its entries come out ascending, which keeps the later per-entry stores of a wave close together); one
-        // LDS atomic per wave for the whole frame.
         int *pinfo = w.flagw + (size_t)f * p.n_max;
-        const int wv = t >> 6;
-        const int wbase = wv * nt * 64;     // first point of this wave's run; point (u, l) = wbase + u * 64 + l
-        const uint32_t nxy = (uint32_t)p.grid[0] * (uint32_t)p.grid[1];
-        uint32_t bits = 0;                  // bit (u - u0): that point goes to my bin
-        for (int u0 = 0; u0 < nt; u0 += VXL_A_U) {
-            float x[VXL_A_U], y[VXL_A_U], z[VXL_A_U];
-            uint32_t key[VXL_A_U];
+        // ---- phase A1.  A wave owns a contiguous run of points (its entries come out ascending, which keeps the later
+        // per-entry stores of a wave close together); point (u, lane) of wave wv = wbase + u * 64 + lane.  Rounds of VXL_A_U
+        // points per lane, double-buffered in registers: the loads of round r + 1 are in flight while round r is evaluated, and
+        // the first round's loads are issued before the LDS tables are initialised.
+        const int wv = __builtin_amdgcn_readfirstlane(t >> 6);      // (scalar: round-level conditions are wave-uniform branches)
+        const int wbase = wv * nt * 64;
+        const char *fbase = reinterpret_cast<const char *>(points) + (size_t)start * p.C * sizeof(float);
+        const uint32_t pstride = C4 ? 16u : (uint32_t)p.C * (uint32_t)sizeof(float);
+        auto issue = [&](int u0, float (&x)[VXL_A_U], float (&y)[VXL_A_U]) {
+            const int jb = wbase + u0 * 64 + l;
+#if defined(VXL_EXP) && VXL_EXP == 2      // probe: no loads, synthetic coordinates
+            for (int u = 0; u < VXL_A_U; ++u) { x[u] = (float)((jb + u * 64) * 37 % 6912) * 0.01f; y[u] = (float)((jb + u * 64) * 53 % 7936) * 0.01f - 39.68f; }
+            return;
+#endif
+            if (wbase + (u0 + VXL_A_U) * 64 <= n) {                  // wave-uniform: every point of the round exists
 #pragma unroll
-            for (int u = 0; u < VXL_A_U; ++u) {
-                const int j = wbase + (u0 + u) * 64 + l;
-                vxl_load_xyz<C4>(points, (size_t)start + min(j, n - 1), p.C, x[u], y[u], z[u]);
+                for (int u = 0; u < VXL_A_U; ++u) {
+                    const char *q = fbase + (uint32_t)(jb + u * 64) * pstride;
+                    if (C4) { const float2 v = *reinterpret_cast<const float2 *>(q); x[u] = v.x; y[u] = v.y; }
+                    else { x[u] = reinterpret_cast<const float *>(q)[0]; y[u] = reinterpret_cast<const float *>(q)[1]; }
+                }
+            } else {
+#pragma unroll
+                for (int u = 0; u < VXL_A_U; ++u) {
+                    const char *q = fbase + (uint32_t)max(min(jb + u * 64, n - 1), 0) * pstride;
+                    if (C4) { const float2 v = *reinterpret_cast<const float2 *>(q); x[u] = v.x; y[u] = v.y; }
+                    else { x[u] = reinterpret_cast<const float *>(q)[0]; y[u] = reinterpret_cast<const float *>(q)[1]; }
+                }
             }
-            bits = 0;
-            int wtotal = 0;                 // wave-uniform: entries of this wave in this round
+        };
+        // Branch-free per point: the cell is clamped into an EXTENDED (nx + 1) x (ny + 1) pillar grid whose last column / row
+        // collect everything outside in x / y, and the bin is the hash of that extended pillar — so a point outside the grid is an
+        // ordinary entry of exactly one bin (phase A2 finds it outside with the exact expression and phase E writes its word, 0).
+        // Risky coordinates (an integer within the rounding margin of the quotient, NaN, inf) are collected per lane and parked
+        // once per round.
+        const float tx = 0.5f - p.eabs[0], ty = 0.5f - p.eabs[1];
+        const uint32_t nxe = (uint32_t)p.grid[0] + 1u;
+        auto round = [&](auto FULL, int u0, const float (&x)[VXL_A_U], const float (&y)[VXL_A_U]) {
+            constexpr bool full = decltype(FULL)::value;            // every point of the round exists
+            uint32_t bits = 0, rbits = 0;       // bit u: that point goes to my bin / must be settled with the exact division
+            int wtotal = 0;                     // wave-uniform: entries of this wave in this round
 #pragma unroll
             for (int u = 0; u < VXL_A_U; ++u) {
-                const int j = wbase + (u0 + u) * 64 + l;
-                int cx, cy, cz;
-                bool okx, oky, okz, rx, ry, rz;
-                vx_cell_fast(x[u] - p.lo[0], p.rvs[0], p.eabs[0], p.grid[0], cx, okx, rx);
-                vx_cell_fast(y[u] - p.lo[1], p.rvs[1], p.eabs[1], p.grid[1], cy, oky, ry);
-                vx_cell_fast(z[u] - p.lo[2], p.rvs[2], p.eabs[2], p.grid[2], cz, okz, rz);
-                const bool valid = (j < n) & (u0 + u < nt);
-                const bool risky = (rx | ry | rz) & valid;
-                const bool inside = okx & oky & okz;
-                const uint32_t pil = __umul24((uint32_t)cy, (uint32_t)p.grid[0]) + (uint32_t)cx;   // grids up to 2^24 cells per layer
-                key[u] = (uint32_t)cz * nxy + pil;
-                if (__builtin_expect(__ballot(risky) != 0ull, 0)) {       // wave-uniform, ~1 in 20 wave-iterations
-                    if (risky) {                                           // parked with its coordinates: settled after the barrier
-                        const int k = atomicAdd(&s_nrisk, 1);
-                        if (k < VXL_RISK_CAP) s_risk[k] = make_float4(x[u], y[u], z[u], __int_as_float(j));
-                    }
+                // floor(q) without v_floor / v_med3 / v_cvt: h = q + 0.5, t = h + 2^23 rounds h (to nearest) onto the integers of
+                // [2^23, 2^24), where the low bits of t ARE round(h) = floor(q) + 1 — unless q sits within the margin of an integer,
+                // which is exactly the risky case, decided by the IEEE division anyway (e = h - round(h) is the distance of q from
+                // the middle of its cell, exact; the margin also covers the rounding of h itself).  Negative q (t <= 2^23), huge
+                // values, inf and NaN all give "bits(t) - bits(2^23) - 1" >= n as unsigned: outside.
+                const float hx = (x[u] - p.lo[0]) * p.rvs[0] + 0.5f, hy = (y[u] - p.lo[1]) * p.rvs[1] + 0.5f;
+                const float tqx = hx + 8388608.0f, tqy = hy + 8388608.0f;
+                const float ex = hx - (tqx - 8388608.0f), ey = hy - (tqy - 8388608.0f);
+                bool risky = !(fabsf(ex) <= tx) | !(fabsf(ey) <= ty);                         // true for NaN as well
+                const uint32_t cx = min(__float_as_uint(tqx) - 0x4B000001u, (uint32_t)p.grid[0]);
+                const uint32_t cy = min(__float_as_uint(tqy) - 0x4B000001u, (uint32_t)p.grid[1]);
+                const uint32_t pil = __umul24(cy, nxe) + cx;                                  // extended grids below 2^24 cells
+                bool mine = !risky & (vxl_bin_of24(pil, gsh) == g);
+                if (!full) {
+                    const bool valid = (wbase + (u0 + u) * 64 + l < n) & (u0 + u < nt);
+                    mine &= valid;
+                    risky &= valid;
                 }
-                if (__builtin_expect(__ballot(!inside & valid & !risky) != 0ull, 0)) {            // wave-uniform, rare
-                    if (g == 0 && !inside && valid && !risky) pinfo[j] = 0;                       // a word of 0, written once
-                }
-                const bool mine = inside && valid && !risky && vxl_bin_of24(pil, G) == g;
                 bits |= (uint32_t)mine << u;
+                rbits |= (uint32_t)risky << u;
                 wtotal += __popcll(__ballot(mine));
+            }
+            if (__builtin_expect(__ballot(rbits != 0u) != 0ull, 0)) {     // wave-uniform, ~1 round in 4
+                while (rbits) {
+                    const int u = __builtin_ctz(rbits);
+                    rbits &= rbits - 1u;
+                    const int k = atomicAdd(&s_nrisk, 1);
+                    if (k < VXL_RISK_CAP) s_risk[k] = wbase + (u0 + u) * 64 + l;
+                }
             }
             int base = 0;
             if (l == 0 && wtotal) base = atomicAdd(&s_nent, wtotal);
@@ -1172,58 +894,120 @@ __global__ __launch_bounds__(1024) void vxl_keybin_kernel(const float *__restric
                 const bool mine = (bits >> u) & 1u;
                 const unsigned long long bal = __ballot(mine);
                 const int pos = base + __popcll(bal & lanemask_lt());
-                if (mine && pos < VXL_CAP) s_q[pos] = make_int2(wbase + (u0 + u) * 64 + l, (int)key[u]);
+                if (mine && pos < VXL_CAP) s_q[pos] = make_int2(wbase + (u0 + u) * 64 + l, VX_INF);
                 base += __popcll(bal);
             }
+        };
+        auto process = [&](int u0, const float (&x)[VXL_A_U], const float (&y)[VXL_A_U]) {
+#if defined(VXL_EXP) && VXL_EXP == 1      // probe: loads only
+            float acc = 0.f;
+            for (int u = 0; u < VXL_A_U; ++u) acc += x[u] + y[u];
+            if (acc == 12345.678f) s_risk[0] = 1;
+            return;
+#endif
+            if (u0 + VXL_A_U <= nt && wbase + (u0 + VXL_A_U) * 64 <= n) round(std::true_type{}, u0, x, y);      // wave-uniform
+            else round(std::false_type{}, u0, x, y);
+        };
+        float xa[VXL_A_U], ya[VXL_A_U], xb[VXL_A_U], yb[VXL_A_U];
+        if (nt > 0) issue(0, xa, ya);
+        for (int k = t; k < VXL_S / 4; k += 1024) {
+            reinterpret_cast<uint4 *>(s_key)[k] = make_uint4(VX_EMPTY, VX_EMPTY, VX_EMPTY, VX_EMPTY);
+            reinterpret_cast<int4 *>(s_cnt)[k] = make_int4(0, 0, 0, 0);
         }
+        if (t < VXL_CAP / 32) s_head[t] = 0u;
+        if (t < 32) s_tc[t] = 0;
+        if (t == 0) s_nent = s_nrisk = s_total = s_nadd = 0;
         __syncthreads();
-        // the parked points (~0.1 %): the reference's expression with the IEEE division, once per workgroup
-        if (t < min(s_nrisk, VXL_RISK_CAP)) {
-            const float4 v = s_risk[t];
-            const int j = __float_as_int(v.w);
-            uint32_t key2, pil2;
-            if (vx_cell_pillar(p, v.x, v.y, v.z, key2, pil2)) {
-                if (vxl_bin_of24(pil2, G) == g) {
-                    const int pos = atomicAdd(&s_nent, 1);
-                    if (pos < VXL_CAP) s_q[pos] = make_int2(j, (int)key2);
-                }
-            } else if (g == 0) {
-                pinfo[j] = 0;
-            }
+        VXL_STAMP(1);
+        // (every round issues the next one's loads unconditionally — clamped to the frame, at most one round is wasted — so the
+        // number of loads in flight is static and the waits are counted, not drained)
+        for (int u0 = 0; u0 < nt; u0 += 2 * VXL_A_U) {
+            issue(u0 + VXL_A_U, xb, yb);
+            process(u0, xa, ya);
+            if (u0 + VXL_A_U >= nt) break;
+            issue(u0 + 2 * VXL_A_U, xa, ya);
+            process(u0 + VXL_A_U, xb, yb);
         }
         __syncthreads();
         VXL_STAMP(2);
-        if (__builtin_expect(s_nent > VXL_CAP || s_nrisk > VXL_RISK_CAP, 0)) {   // block-uniform, degenerate input only
+        VxlShared sh;
+        sh.key = s_key; sh.cnt = s_cnt; sh.aux = s_aux; sh.q = s_q; sh.wtot = s_wtot; sh.tc = s_tc; sh.total = &s_total;
+        const int ne0 = s_nent, nr = s_nrisk;
+        if (__builtin_expect(ne0 + nr > VXL_CAP || nr > VXL_RISK_CAP, 0)) {   // block-uniform, degenerate input only
             vxl_bin_streaming<C4>(points, p, w, G, g, f, start, n, sh);
         } else {
-            const int ne = s_nent;
-            // ---- phase B2: dense insertion into the LDS hash table (first point, count per voxel)
-            for (int e = t; e < ne; e += 1024) {
-                const int2 q = s_q[e];
-                const int slot = vxl_table_insert(s_key, (uint32_t)q.y);
-                int en = q.x | (int)0x80000000;                       // table full: dead entry, word 0
-                if (slot >= 0) {
-                    atomicMin(&s_first[slot], q.x);
-                    atomicAdd(&s_cnt[slot], 1);
-                    en = q.x | (slot << 15);
-                } else {
-                    vx_raise(w, 1);
+            // ---- phase A2 + B: my points only — exact cell, LDS hash table insert, count per voxel.  The parked points
+            // (~0.1 % of the frame) are candidates of the same pass: the reference's expression with the IEEE division decides
+            // their pillar, and the ones of my bin are appended behind the entries (s_nadd).
+            const int nc = ne0 + nr;
+            for (int e0 = 0; e0 < nc; e0 += 2048) {
+                int jj[2];
+                float x[2], y[2], z[2];
+#pragma unroll
+                for (int k = 0; k < 2; ++k) {
+                    const int e = min(e0 + k * 1024 + t, nc - 1);
+                    jj[k] = e < ne0 ? s_q[e].x : s_risk[e - ne0];
+                    vxl_load_xyz<C4>(points, (size_t)start + jj[k], p.C, x[k], y[k], z[k]);
                 }
-                s_q[e].x = en;
+#pragma unroll
+                for (int k = 0; k < 2; ++k) {
+                    int e = e0 + k * 1024 + t;
+                    if (e < nc) {
+                        if (e >= ne0) {                                   // a parked point: mine?
+                            if (vxl_bin_of24(vx_pillar_ext(p, x[k], y[k]), gsh) != g) continue;
+                            e = ne0 + atomicAdd(&s_nadd, 1);              // < ne0 + nr <= VXL_CAP
+                            s_q[e].y = VX_INF;
+                        }
+                        uint32_t key, pil;
+                        int en = jj[k] | (int)0x80000000;                 // outside the grid / table full: dead entry, word 0
+                        if (vx_cell_pillar(p, x[k], y[k], z[k], key, pil)) {
+                            const int slot = vxl_table_insert(s_key, key);
+                            if (slot >= 0) {
+                                atomicAdd(&s_cnt[slot], 1);
+                                en = jj[k] | (slot << 15);
+                            } else {
+                                vx_raise(w, 1);
+                            }
+                        }
+                        s_q[e].x = en;
+                    }
+                }
             }
             __syncthreads();
             VXL_STAMP(3);
-            // ---- phase C: list offsets (the keys are not needed any more: offsets overwrite them)
-            const int total = vxl_list_offsets(sh, p.P, t, s_key);
-            const int L = min(total, VXL_CAP);       // total <= ne <= VXL_CAP
-            for (int k = t; k < L; k += 1024) s_q[k].y = VX_INF;
+            const int ne = ne0 + s_nadd;
+            // ---- phase C: list space per voxel (the keys are not needed any more: offsets overwrite them), list heads marked.
+            // Allocated wave by wave with ONE LDS atomic per wave (no scan across the workgroup, no barrier inside): where a
+            // voxel's list lies is internal — the per-point words carry the positions.  Every list cell was set to "free" when
+            // its entry was appended (a bin has at most as many list cells as entries).
+            {
+                int m[VXL_S / 1024];
+                int run = 0;
+#pragma unroll
+                for (int k = 0; k < VXL_S / 1024; ++k) {
+                    m[k] = min(s_cnt[t * (VXL_S / 1024) + k], p.P);
+                    run += m[k];
+                }
+                const int inc = wave_incl_scan(run);
+                const int wtot = __shfl(inc, 63, 64);
+                int o = 0;
+                if (l == 0 && wtot) o = atomicAdd(&s_total, wtot);
+                o = __shfl(o, 0, 64) + inc - run;
+#pragma unroll
+                for (int k = 0; k < VXL_S / 1024; ++k) {
+                    s_key[t * (VXL_S / 1024) + k] = (uint32_t)o;
+                    if (m[k] > 0) atomicOr(&s_head[o >> 5], 1u << (o & 31));
+                    o += m[k];
+                }
+            }
             __syncthreads();
             VXL_STAMP(4);
+            const int L = min(s_total, VXL_CAP);     // total <= ne <= VXL_CAP
             // ---- phase D: ordered lists in LDS
             for (int e = t; e < ne; e += 1024) {
                 const int en = s_q[e].x;
                 if (en < 0) continue;
-                const int j = en & 0x7FFF, slot = (en >> 15) & 0x1FFF;
+                const int j = en & 0x7FFF, slot = (en >> 15) & (VXL_S - 1);
                 const int c = s_cnt[slot];
                 int2 *Lp = s_q + s_key[slot];
                 if (c == 1) Lp[0].y = j;
@@ -1237,22 +1021,22 @@ __global__ __launch_bounds__(1024) void vxl_keybin_kernel(const float *__restric
                 const int j = en & 0x7FFF;
                 int word = 0;
                 if (en >= 0) {
-                    const int slot = (en >> 15) & 0x1FFF;
-                    if (s_first[slot] == j) word = min(s_cnt[slot], p.P) | ((g * VXL_CAP + (int)s_key[slot]) << VXL_MBITS);
+                    const int slot = (en >> 15) & (VXL_S - 1);
+                    const int o = (int)s_key[slot];
+                    if (s_q[o].y == j) word = min(s_cnt[slot], p.P) | ((g * VXL_CAP + o) << VXL_MBITS);
                 }
                 pinfo[j] = word;
-                const int tau = j >> 10;
-                unsigned long long rem = __ballot(word != 0);
-                while (rem) {                                  // wave-uniform; a wave sees few distinct tile ids
-                    const int lead = __builtin_ctzll(rem);
-                    const int t0 = __shfl(tau, lead, 64);
-                    const unsigned long long m = __ballot(word != 0 && tau == t0);
-                    if (l == lead) atomicAdd(&s_tc[t0], __popcll(m));
-                    rem &= ~m;
-                }
+                vxl_count_firsts(s_tc, word != 0, j, l);
             }
-            int *stg = w.pfirst + ((size_t)f * G + g) * VXL_CAP;
-            for (int k = t; k < L; k += 1024) stg[k] = s_q[k].y;
+            if (C4) {                    // the points of the cells beyond each list's head, where the emit launch will look
+                float4 *stg4 = w.stg4 + ((size_t)f * G + g) * VXL_CAP;
+                const float4 *pts4 = reinterpret_cast<const float4 *>(points) + start;
+                for (int k = t; k < L; k += 1024)
+                    if (!((s_head[k >> 5] >> (k & 31)) & 1u)) stg4[k] = pts4[s_q[k].y];
+            } else {
+                int *stgi = w.stgi + ((size_t)f * G + g) * VXL_CAP;
+                for (int k = t; k < L; k += 1024) stgi[k] = s_q[k].y;
+            }
         }
         __syncthreads();
         VXL_STAMP(6);
@@ -1261,26 +1045,168 @@ __global__ __launch_bounds__(1024) void vxl_keybin_kernel(const float *__restric
             int tot = 0;
             for (int k = 0; k < 32; ++k) tot += s_tc[k];
             w.bvox[f * VXL_GMAX + g] = tot;                    // read by the emit launch
+            // rows the fill roles of THIS call leave zero (the emit launch reads it): everything in resident mode
+            if (id == 0) w.fillst[1] = resident ? 0x7fffffff : w.fillst[0];
         }
     }
     VXL_STAMP(7);
-    // ---- done with the index build: help with the tail of the fill
-    if (!res_hist) vxl_fill_chunks(dst, nmain + id, nbinwg, nchunks, lim_f4, t);
+    // ---- done with the index build: the bin roles' share of the fill (help16 sixteenths of it, normally none)
+    if (!res_hist && nhelp > 0) vxl_fill_chunks(dst, nmain + id, nbinwg, nchunks, lim_f4, t);
+    VXL_WALL(2 * id + 1);
 }
 
-static int vxl_bins(int n_max) { return divup(n_max, VXL_PTS_PER_BIN); }
+// Second launch: workgroup (tile, f) owns the 1024 points of its tile.  A first point's voxel id = (first points of the frame
+// in earlier tiles, from the bin roles' per-tile counts) + (its ballot rank inside the tile) = first-appearance order; the
+// thread writes slot 0 of that voxel's row (its own point: the list is ascending), coords from its own cell, and the count.
+// The further slots of multi-point voxels are flattened over the WHOLE workgroup — (voxel, slot) pairs through an LDS
+// descriptor list, one pair per thread and pass — so a 32-point pillar costs what a 2-point pillar costs: one round trip.
+template <bool C4>
+__global__ __launch_bounds__(1024, 8) void vxl_emit_kernel(const float *__restrict__ points, const int *__restrict__ offsets,
+                                                        VxParams p, VxWs w, int G, float *__restrict__ voxels,
+                                                        int *__restrict__ coords, int *__restrict__ num_points,
+                                                        int *__restrict__ voxel_offsets, int resident) {
+    __shared__ int s_part[16], s_wcnt[16], s_w2[16], s_e2[16];
+    __shared__ int s_base;
+    __shared__ int4 s_desc[1024];      // multi-point voxels of this tile: (row, staging position, first flat item, items)
+    const int tile = blockIdx.x, f = blockIdx.y, t = threadIdx.x, l = t & 63, wv = t >> 6;
+    const int id = 1024 + f * (int)gridDim.x + tile;        // (stamp slot, -DVXL_STAMPS builds only)
+    (void)id;
+    VXL_WALL(2 * id);
+    const int start = offsets[f];
+    const int n = min(offsets[f + 1] - start, p.n_max);
+    const int i = tile * 1024 + t;
+    const int wd = w.flagw[(size_t)f * p.n_max + min(i, max(n - 1, 0))];      // unconditional load, masked below
+    const int word = (i < n) ? wd : 0;
+    // this thread's own point, requested together with its word: for a first point it IS slot 0 of the voxel's row
+    float4 me = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (C4 && n > 0) me = reinterpret_cast<const float4 *>(points)[(size_t)start + min(i, n - 1)];   // n: block-uniform
+    // first points of the frame in earlier tiles: sum of tcnt[f][g][tau < tile] over the G bins
+    int v = 0;
+    if (t < G * 32) {
+        const int tau = t & 31;
+        const int c = w.tcnt[(size_t)f * G * 32 + t];
+        v = (tau < tile) ? c : 0;
+    }
+    v = wave_sum(v);
+    if (l == 0) s_part[wv] = v;
+    // rows of the earlier frames (every frame's count is complete: the first launch has finished)
+    if (wv == 15) {
+        int part = 0;
+        if (p.compact)
+            for (int k0 = 0; k0 < f; k0 += 64) {
+                const int k = k0 + l;
+                part += (k < f) ? vxl_frame_rows(p, w, G, k) : 0;
+            }
+        part = wave_sum(part);
+        if (l == 0) s_base = p.compact ? part : f * p.max_voxels;
+    }
+    if (tile == 0 && f == 0 && wv == 14) {            // the batch's offsets table (off the critical path)
+        int carry = 0;
+        for (int k0 = 0; k0 < p.batch; k0 += 64) {
+            const int k = k0 + l;
+            const int c = (k < p.batch) ? vxl_frame_rows(p, w, G, k) : 0;
+            const int inc = wave_incl_scan(c);
+            if (k < p.batch) voxel_offsets[k] = p.compact ? carry + inc - c : k * p.max_voxels;
+            carry += __shfl(inc, 63, 64);
+        }
+        if (l == 0) {
+            voxel_offsets[p.batch] = p.compact ? carry : p.batch * p.max_voxels;
+            // rows the next call's fill role should clear up front (nobody reads fillst[0] during this launch)
+            const long long next = (long long)carry + carry / 4 + 1024;
+            w.fillst[0] = p.compact ? (int)min(next, (long long)p.batch * p.max_voxels) : 0x7fffffff;
+            // resident-output history for the next call (a non-resident call leaves rows beyond its fill extent unspecified,
+            // so it invalidates the history)
+            w.resident[0] = resident ? (long long)reinterpret_cast<uintptr_t>(voxels) : 0ll;
+            w.resident[1] = (long long)reinterpret_cast<uintptr_t>(num_points);
+            w.resident[2] = carry;
+            w.resident[3] = (long long)p.P * p.C;
+        }
+    }
+    const long long cleared_rows = p.compact ? (long long)w.fillst[1] : 0x7fffffffll;
+    const unsigned long long bal = __ballot(word != 0);
+    if (l == 0) s_wcnt[wv] = __popcll(bal);
+    __syncthreads();
+    int r = 0;
+    for (int k = 0; k < (G * 32 + 63) / 64 && k < 16; ++k) r += s_part[k];
+    for (int k = 0; k < wv; ++k) r += s_wcnt[k];
+    r += __popcll(bal & lanemask_lt());
+    const bool first = (word != 0) && (r < p.max_voxels);     // else: not a first point / voxel beyond the cap (dropped with its points)
+    const int cnt = word & VXL_MMASK;
+    const int lpos = word >> VXL_MBITS;                       // list position inside the frame's staging arrays
+    const size_t row = (size_t)s_base + r;
+    const int rowlen = p.P * p.C;
+    if (first) {
+        float x0, y0, z0;
+        if (C4) {
+            float4 *out4 = reinterpret_cast<float4 *>(voxels) + row * p.P;
+            out4[0] = me;
+            if ((long long)row >= cleared_rows)            // beyond what the fill role cleared: this thread owns the row's zeros
+                for (int sl = cnt; sl < p.P; ++sl) out4[sl] = make_float4(0.f, 0.f, 0.f, 0.f);
+            x0 = me.x; y0 = me.y; z0 = me.z;
+        } else {
+            const float *q = points + ((size_t)start + i) * p.C;
+            float *out = voxels + row * rowlen;
+            for (int c = 0; c < p.C; ++c) out[c] = q[c];
+            if ((long long)row >= cleared_rows)
+                for (int e = cnt * p.C; e < rowlen; ++e) out[e] = 0.f;
+            x0 = q[0]; y0 = q[1]; z0 = q[2];
+        }
+        const uint32_t nx = p.grid[0], ny = p.grid[1];
+        uint32_t key;
+        vx_cell(p, x0, y0, z0, key);
+        reinterpret_cast<int4 *>(coords)[row] = make_int4(f, (int)(key / (nx * ny)), (int)((key / nx) % ny), (int)(key % nx));
+        num_points[row] = cnt;
+    }
+    // ---- slots 1 .. cnt-1 of the multi-point voxels, flattened over the workgroup
+    const int extra = first ? cnt - 1 : 0;
+    const unsigned long long bal2 = __ballot(extra > 0);
+    const int inc2 = wave_incl_scan(extra);
+    if (l == 63) s_e2[wv] = inc2;
+    if (l == 0) s_w2[wv] = __popcll(bal2);
+    __syncthreads();
+    int dbase = 0, ibase = 0, nd = 0, ne = 0;
+#pragma unroll
+    for (int k = 0; k < 16; ++k) {
+        const int a = s_w2[k], b = s_e2[k];
+        if (k < wv) { dbase += a; ibase += b; }
+        nd += a; ne += b;
+    }
+    if (ne == 0) {                                             // block-uniform
+        VXL_WALL(2 * id + 1);
+        return;
+    }
+    if (extra > 0) s_desc[dbase + __popcll(bal2 & lanemask_lt())] = make_int4((int)row, lpos, ibase + inc2 - extra, extra);
+    __syncthreads();
+    const size_t fbase = (size_t)f * G * VXL_CAP;
+    for (int it = t; it < ne; it += 1024) {
+        int lo = 0, hi = nd - 1;                               // the last descriptor whose first item is <= it
+        while (lo < hi) {
+            const int mid = (lo + hi + 1) >> 1;
+            if (s_desc[mid].z <= it) lo = mid; else hi = mid - 1;
+        }
+        const int4 d = s_desc[lo];
+        const int s = it - d.z + 1;
+        if (C4) {
+            reinterpret_cast<float4 *>(voxels)[(size_t)d.x * p.P + s] = w.stg4[fbase + d.y + s];
+        } else {
+            const float *q = points + ((size_t)start + w.stgi[fbase + d.y + s]) * p.C;
+            float *out = voxels + (size_t)d.x * rowlen + (size_t)s * p.C;
+            for (int c = 0; c < p.C; ++c) out[c] = q[c];
+        }
+    }
+    VXL_WALL(2 * id + 1);
+}
 
 static int vxl_env_int(const char *name, int dflt) {
     const char *e = getenv(name);
     return e ? atoi(e) : dflt;
 }
 
-// fused key + bin + fill launch, then emit: 2 launches
+// bin + fill launch, then emit: 2 launches
 static void vxl_run_fused(const float *points, const int *point_offsets, const VxParams &p, const VxWs &w, bool c4,
                           float *voxels, int *coords, int *num_points, int *voxel_offsets, hipStream_t s, int resident) {
-    // share (in 1/16) of the fill left to the bin roles once they are done: 0 measured best (33.9 / 34.7 / 35.4 / 36.4 us
-    // for 1 / 2 / 3 / 4 sixteenths) — the bin roles are the longer pole of the launch
-    const int help16 = 0;
+    static const int help16 = vxl_env_int("LIDAR_VXL_HELP16", 0);     // share (in 1/16) of the fill left to the bin roles
+    static const int fillwg = vxl_env_int("LIDAR_VXL_FILLWG", 256);   // fill workgroups beside the bin workgroups
     const int G = vxl_bins(p.n_max);
     const int ntiles = divup(p.n_max, 1024);
     const long long total_floats = (long long)p.max_voxels * p.P * p.C * p.batch;
@@ -1288,43 +1214,20 @@ static void vxl_run_fused(const float *points, const int *point_offsets, const V
     const long long total_f4 = fill_f4 ? total_floats / 4 : 0;
     const long long tail_floats = total_floats - total_f4 * 4;
     const int nbinwg = 8 * G * divup(p.batch, 8);
-    const int nfillwg = nbinwg < 192 ? 256 - nbinwg : 64;              // one resident workgroup per CU (LDS-bound)
+    const int nfillwg = nbinwg < 512 - fillwg ? 512 - nbinwg : fillwg;       // two resident workgroups per CU
     if (tail_floats > 1024) (void)hipMemsetAsync(voxels, 0, (size_t)total_floats * sizeof(float), s);   // unaligned buffer
     const long long tf = tail_floats <= 1024 ? tail_floats : 0;
-    if (c4) hipLaunchKernelGGL(vxl_keybin_kernel<true>, dim3(nbinwg + nfillwg), dim3(1024), 0, s, points, point_offsets, p, w, G, nbinwg, nfillwg, voxels, total_f4, tf, help16, resident, num_points);
+#ifdef VXL_STAMPS
+    const bool emit_only = vxl_env_int("LIDAR_VXL_DEBUG_EMIT_ONLY", 0) != 0;    // probe: the second launch alone (workspace of the last call)
+#else
+    const bool emit_only = false;
+#endif
+    if (emit_only) {}
+    else if (c4) hipLaunchKernelGGL(vxl_keybin_kernel<true>, dim3(nbinwg + nfillwg), dim3(1024), 0, s, points, point_offsets, p, w, G, nbinwg, nfillwg, voxels, total_f4, tf, help16, resident, num_points);
     else hipLaunchKernelGGL(vxl_keybin_kernel<false>, dim3(nbinwg + nfillwg), dim3(1024), 0, s, points, point_offsets, p, w, G, nbinwg, nfillwg, voxels, total_f4, tf, help16, resident, num_points);
     const dim3 ge(ntiles, p.batch);
-    if (c4) hipLaunchKernelGGL(vxl_emit_kernel<true>, ge, dim3(1024), 0, s, points, point_offsets, p, w, G, voxels, coords, num_points, voxel_offsets, 1, resident);
-    else hipLaunchKernelGGL(vxl_emit_kernel<false>, ge, dim3(1024), 0, s, points, point_offsets, p, w, G, voxels, coords, num_points, voxel_offsets, 1, resident);
-}
-
-static void vxl_run(const float *points, const int *point_offsets, const VxParams &p, const VxWs &w, bool c4,
-                    float *voxels, int *coords, int *num_points, int *voxel_offsets, hipStream_t s) {
-    const int G = vxl_bins(p.n_max);
-    const int ntiles = divup(p.n_max, 1024);
-    // zero-fill share of every frame index (positional split of the B * max_voxels rows, whatever the compaction)
-    const long long frame_floats = (long long)p.max_voxels * p.P * p.C;
-    const long long total_floats = frame_floats * p.batch;
-    const bool fill_f4 = (reinterpret_cast<uintptr_t>(voxels) & 15) == 0;
-    // float4 units per frame slice; a slice boundary need not be a row boundary (pure zeros), leftovers go to the tail
-    const long long f4_per_frame = (fill_f4 && total_floats / 4 >= p.batch) ? (total_floats / 4) / p.batch : 0;
-    const long long tail_floats = total_floats - f4_per_frame * 4 * p.batch;      // < 4 * batch + 4 (or everything if unaligned)
-    const int nfill = (int)divup(f4_per_frame, VXL_FILL_F4_PER_WG);
-    const dim3 gk(ntiles + nfill, p.batch);
-    if (c4) hipLaunchKernelGGL(vxl_key_kernel<true>, gk, dim3(1024), 0, s, points, point_offsets, p, w, G, ntiles, voxels, f4_per_frame, tail_floats <= 1024 ? tail_floats : 0);
-    else hipLaunchKernelGGL(vxl_key_kernel<false>, gk, dim3(1024), 0, s, points, point_offsets, p, w, G, ntiles, voxels, f4_per_frame, tail_floats <= 1024 ? tail_floats : 0);
-    if (tail_floats > 1024)   // unaligned output buffer (never the case for torch allocations): plain memset of everything
-        (void)hipMemsetAsync(voxels, 0, (size_t)total_floats * sizeof(float), s);
-    const int items = divup(p.n_max, 1024);
-    const dim3 gb(G, p.batch);
-    if (items <= 4) hipLaunchKernelGGL(vxl_bin_kernel<4>, gb, dim3(1024), 0, s, point_offsets, p, w, G);
-    else if (items <= 8) hipLaunchKernelGGL(vxl_bin_kernel<8>, gb, dim3(1024), 0, s, point_offsets, p, w, G);
-    else if (items <= 16) hipLaunchKernelGGL(vxl_bin_kernel<16>, gb, dim3(1024), 0, s, point_offsets, p, w, G);
-    else if (items <= 24) hipLaunchKernelGGL(vxl_bin_kernel<24>, gb, dim3(1024), 0, s, point_offsets, p, w, G);
-    else hipLaunchKernelGGL(vxl_bin_kernel<32>, gb, dim3(1024), 0, s, point_offsets, p, w, G);
-    const dim3 ge(ntiles, p.batch);
-    if (c4) hipLaunchKernelGGL(vxl_emit_kernel<true>, ge, dim3(1024), 0, s, points, point_offsets, p, w, G, voxels, coords, num_points, voxel_offsets, 0, 0);
-    else hipLaunchKernelGGL(vxl_emit_kernel<false>, ge, dim3(1024), 0, s, points, point_offsets, p, w, G, voxels, coords, num_points, voxel_offsets, 0, 0);
+    if (c4) hipLaunchKernelGGL(vxl_emit_kernel<true>, ge, dim3(1024), 0, s, points, point_offsets, p, w, G, voxels, coords, num_points, voxel_offsets, resident);
+    else hipLaunchKernelGGL(vxl_emit_kernel<false>, ge, dim3(1024), 0, s, points, point_offsets, p, w, G, voxels, coords, num_points, voxel_offsets, resident);
 }
 
 // ------------------------------------------------------------------ C ABI
@@ -1381,7 +1284,7 @@ LIDAR_EXPORT int lidar_voxelize(const float *points, const int *point_offsets, i
         p.lo[j] = range6[j];
         p.vs[j] = voxel_size3[j];
         p.rvs[j] = 1.0f / voxel_size3[j];
-        p.eabs[j] = fminf(((float)grid3[j] + 2.0f) * 4.9e-7f, 0.5f);
+        p.eabs[j] = fminf(((float)grid3[j] + 2.0f) * 6.2e-7f, 0.5f);     // (4.9e-7 + the rounding of q + 0.5 in phase A1)
         p.grid[j] = grid3[j];
     }
     p.C = num_features;
@@ -1400,20 +1303,17 @@ LIDAR_EXPORT int lidar_voxelize(const float *points, const int *point_offsets, i
     hipStream_t s = (hipStream_t)stream;
     const bool c4 = (num_features == 4) && ((reinterpret_cast<uintptr_t>(points) & 15) == 0) &&
                     ((reinterpret_cast<uintptr_t>(voxels) & 15) == 0);
-    // algo 0 = auto, 1 = LDS-binned 3 launches, 3 = LDS-binned fused 2 launches, 4 = 3 with a resident output buffer
-    // (1 / 3 / 4: n_max <= 32768, max_points < 16384), 2 = global hash table (any size)
-    const bool lds_ok = (n_max <= VXL_MAX_ITEMS * 1024) && (max_points <= VXL_MMASK);
-    if ((algo == 1 || algo == 3 || algo == 4) && !lds_ok) return LIDAR_ERR_ARG;
-    static const int auto_algo = vxl_env_int("LIDAR_VXL_ALGO", 3);
-    if (algo == 0 && lds_ok) algo = (auto_algo == 1) ? 1 : 3;
+    // algo 0 = auto, 3 (and 1, its former three-launch variant) = LDS-binned, 2 launches, 4 = 3 with a resident output buffer
+    // (n_max <= 32768, max_points < 16384, x / y grid below 2^24 cells), 2 = global hash table (any size)
+    const bool lds_ok = (n_max <= VXL_MAX_ITEMS * 1024) && (max_points <= VXL_MMASK) &&
+                        (((double)grid3[0] + 1.0) * ((double)grid3[1] + 1.0) < 16777216.0);
+    if (algo == 1) algo = 3;
+    if ((algo == 3 || algo == 4) && !lds_ok) return LIDAR_ERR_ARG;
+    if (algo == 0) algo = lds_ok ? 3 : 2;
     if (algo == 3 || algo == 4) {
         const bool unaligned = ((reinterpret_cast<uintptr_t>(voxels) & 15) != 0);      // the resident clear wants 16-B rows
         vxl_run_fused(points, point_offsets, p, w, c4, voxels, coords, num_points, voxel_offsets, s,
                       (algo == 4 && compact && !unaligned) ? 1 : 0);
-        return lidar_check_launch("lidar_voxelize(fused)");
-    }
-    if (algo == 1) {
-        vxl_run(points, point_offsets, p, w, c4, voxels, coords, num_points, voxel_offsets, s);
         return lidar_check_launch("lidar_voxelize(lds)");
     }
     const dim3 gpt(divup(n_max, 256), batch), gtile(p.ntiles, batch);

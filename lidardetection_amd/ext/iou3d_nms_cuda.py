@@ -6,6 +6,10 @@ from .. import _lib, workspace
 
 def _pairwise(boxes_a, boxes_b, out, mode):
     _lib.require_cuda(boxes_a, boxes_b, out)
+    _lib.require_last(boxes_a, 7, "boxes_a")
+    _lib.require_last(boxes_b, 7, "boxes_b")
+    if out.dtype != torch.float32 or tuple(out.shape) != (boxes_a.shape[0], boxes_b.shape[0]):
+        raise _lib.LidarHipError("output must be float32 (N, M)")
     na, nb = boxes_a.shape[0], boxes_b.shape[0]
     L = _lib.lib()
     wsb = L.lidar_iou_workspace_bytes(na, nb)
@@ -30,6 +34,9 @@ def nms_batch(boxes, counts, thresh, normal=False, max_keep=None):
     -> keep (B, N) int64 positions, num_keep (B,) int32, both on the device.  max_keep: only the first max_keep survivors
     of a frame are needed (NMS_POST_MAXSIZE): the greedy pass stops there, num_keep is clamped."""
     _lib.require_cuda(boxes, counts)
+    _lib.require_last(boxes, 7, "boxes")
+    if boxes.dim() != 3 or boxes.dtype != torch.float32 or (counts is not None and counts.dtype != torch.int32):
+        raise _lib.LidarHipError("nms_batch: boxes must be float32 (B, N, 7), counts int32 (B,)")
     B, N = boxes.shape[0], boxes.shape[1]
     L = _lib.lib()
     keep = torch.empty((B, max(N, 1)), dtype=torch.int64, device=boxes.device)
@@ -44,6 +51,7 @@ def nms_batch(boxes, counts, thresh, normal=False, max_keep=None):
 
 def _nms(boxes, keep, thresh, normal):
     _lib.require_cuda(boxes)
+    _lib.require_last(boxes, 7, "boxes")
     if keep.is_cuda or keep.dtype != torch.int64:
         raise _lib.LidarHipError("keep must be a CPU int64 tensor (reference contract, iou3d_nms_utils.py:97)")
     n = boxes.shape[0]
@@ -83,6 +91,10 @@ def boxes_iou_bev_cpu(boxes_a, boxes_b, ans_iou):
     for t in (boxes_a, boxes_b, ans_iou):
         if not t.is_contiguous():
             raise _lib.LidarHipError("expected a contiguous tensor")   # reference: CHECK_CONTIGUOUS + exit(-1)
+        if t.dtype != torch.float32:
+            raise _lib.LidarHipError(f"expected float32, got {t.dtype}")
+    _lib.require_last(boxes_a, 7, "boxes_a")
+    _lib.require_last(boxes_b, 7, "boxes_b")
     _lib.check(_lib.lib().lidar_boxes_iou_bev_cpu(_lib.ptr(boxes_a), boxes_a.shape[0], _lib.ptr(boxes_b), boxes_b.shape[0],
                                                   _lib.ptr(ans_iou)), "lidar_boxes_iou_bev_cpu")
     return 1

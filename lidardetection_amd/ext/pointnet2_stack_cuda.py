@@ -9,6 +9,8 @@ GRID_MIN_POINTS = 512          # candidates per batch element from which ball qu
 def ball_query_wrapper(B, M, radius, nsample, new_xyz, new_xyz_batch_cnt, xyz, xyz_batch_cnt, idx):
     """ball_query_wrapper_stack (ball_query.cpp:31-47): fills idx (M, nsample) int32 (zero-filled by the caller)."""
     _lib.require_cuda(new_xyz, new_xyz_batch_cnt, xyz, xyz_batch_cnt, idx)
+    _lib.require_last(new_xyz, 3, "new_xyz")
+    _lib.require_last(xyz, 3, "xyz")
     if xyz.shape[0] >= GRID_MIN_POINTS * B and nsample <= 64 and radius > 0:
         # enough candidates per batch element to pay for a binning pass: same lists through the cell grid
         return ball_query_grid_wrapper(B, M, radius, nsample, None, None, new_xyz, new_xyz_batch_cnt, xyz, xyz_batch_cnt, idx, None)
@@ -44,6 +46,7 @@ def ball_query_grid_wrapper(B, M, radius_a, nsample_a, radius_b, nsample_b, new_
 def furthest_point_sampling_wrapper(b, n, m, points, temp, idx):
     """sampling.cpp: points (b,n,3), temp (b,n) == 1e10, idx (b,m) int32."""
     _lib.require_cuda(points, temp, idx)
+    _lib.require_last(points, 3, "points")
     _lib.check(_lib.lib().lidar_furthest_point_sampling(b, n, m, _p(points), _p(temp), _p(idx), _S()), "lidar_furthest_point_sampling")
     return 1
 
@@ -97,6 +100,8 @@ def group_points_grad_wrapper(B, M, C, N, nsample, grad_out, idx, idx_batch_cnt,
 
 def three_nn_wrapper(unknown, unknown_batch_cnt, known, known_batch_cnt, dist2, idx):
     _lib.require_cuda(unknown, unknown_batch_cnt, known, known_batch_cnt, dist2, idx)
+    _lib.require_last(unknown, 3, "unknown")
+    _lib.require_last(known, 3, "known")
     _lib.check(_lib.lib().lidar_three_nn_stack(unknown_batch_cnt.shape[0], unknown.shape[0], _p(unknown), _p(unknown_batch_cnt),
                                                _p(known), _p(known_batch_cnt), _p(dist2), _p(idx), _S()), "lidar_three_nn_stack")
 

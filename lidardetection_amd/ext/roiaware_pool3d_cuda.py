@@ -1,4 +1,6 @@
 """`roiaware_pool3d_cuda` — same entry points as pcdet/ops/roiaware_pool3d/src/roiaware_pool3d.cpp:172-177."""
+import torch as _torch
+
 from .. import _lib
 
 _S = _lib.stream
@@ -8,6 +10,8 @@ _p = _lib.ptr
 def forward(rois, pts, pts_feature, argmax, pts_idx_of_voxels, pooled_features, pool_method):
     """roiaware_pool3d_gpu (:29-66): outputs zero-initialised by the caller; pool_method 0 = max, 1 = avg."""
     _lib.require_cuda(rois, pts, pts_feature, argmax, pts_idx_of_voxels, pooled_features)
+    _lib.require_last(rois, 7, "rois")
+    _lib.require_last(pts, 3, "pts")
     R, P, C = rois.shape[0], pts.shape[0], pts_feature.shape[1]
     ox, oy, oz, K = pts_idx_of_voxels.shape[1:5]
     assert ox < 256 and oy < 256 and oz < 256  # (:53)
@@ -30,6 +34,10 @@ def backward(pts_idx_of_voxels, argmax, grad_out, grad_in, pool_method):
 def points_in_boxes_gpu(boxes, pts, box_idx_of_points):
     """(:98-118): boxes (B,T,7), pts (B,P,3), box_idx_of_points (B,P) int32 pre-filled with -1."""
     _lib.require_cuda(boxes, pts, box_idx_of_points)
+    _lib.require_last(boxes, 7, "boxes")
+    _lib.require_last(pts, 3, "pts")
+    if box_idx_of_points.dtype != _torch.int32 or boxes.dtype != _torch.float32 or pts.dtype != _torch.float32:
+        raise _lib.LidarHipError("points_in_boxes_gpu: boxes / pts float32, box_idx_of_points int32")
     _lib.check(_lib.lib().lidar_points_in_boxes(boxes.shape[0], boxes.shape[1], pts.shape[1], _p(boxes), _p(pts),
                                                 _p(box_idx_of_points), _S()), "lidar_points_in_boxes")
     return 1
@@ -41,6 +49,10 @@ def points_in_boxes_cpu(boxes, pts, pts_indices):
         raise _lib.LidarHipError("points_in_boxes_cpu takes CPU tensors")
     if not pts_indices.is_contiguous():
         raise _lib.LidarHipError("points_in_boxes_cpu: pts_indices must be contiguous (it is written in place)")
+    if boxes.dtype != _torch.float32 or pts.dtype != _torch.float32 or pts_indices.dtype != _torch.int32:
+        raise _lib.LidarHipError("points_in_boxes_cpu: boxes / pts float32, pts_indices int32")
+    _lib.require_last(boxes, 7, "boxes")
+    _lib.require_last(pts, 3, "pts")
     boxes_c, pts_c = boxes.contiguous(), pts.contiguous()      # bound to locals: they must outlive the call
     _lib.check(_lib.lib().lidar_points_in_boxes_cpu(_p(boxes_c), boxes_c.shape[0], _p(pts_c), pts_c.shape[0],
                                                     _p(pts_indices)), "lidar_points_in_boxes_cpu")

@@ -26,7 +26,7 @@ class BatchVoxelizer:
         self.max_num_points = int(max_num_points)
         self.max_voxels = int(max_voxels)
         self.C = int(num_point_features)
-        self.algo = int(algo)  # 0 auto, 1 LDS-binned (3 launches), 3 LDS-binned fused (2 launches), 2 global hash (include/lidar_hip.h)
+        self.algo = int(algo)  # 0 auto, 3 LDS-binned (2 launches), 2 global hash (include/lidar_hip.h)
         self._range_h = _lib.host_f32(self.point_cloud_range)
         self._vs_h = _lib.host_f32(self.voxel_size)
         self._grid_h = _lib.host_i32(self.grid_size)
@@ -90,7 +90,7 @@ class BatchVoxelizer:
         if out is None:
             out = self.alloc_outputs(batch, points.device)
         L = _lib.lib()
-        algo = 4 if (resident and compact and self.algo in (0, 3, 4) and n_max <= 32768) else self.algo
+        algo = 4 if (resident and compact and self.algo in (0, 1, 3, 4) and n_max <= 32768) else self.algo
         _lib.check(L.lidar_voxelize(_lib.ptr(points), _lib.ptr(point_offsets), batch, n_max, self.C, self._range_h,
                                     self._vs_h, self._grid_h, self.max_num_points, self.max_voxels, int(bool(compact)), algo,
                                     _lib.ptr(out["voxels"]), _lib.ptr(out["voxel_coords"]),

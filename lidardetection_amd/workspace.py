@@ -1,14 +1,17 @@
-"""Grow-only scratch buffers (torch caching allocator, one per (tag, device)).
+"""Grow-only scratch buffers (torch caching allocator, one per (tag, device, STREAM)).
 
 The C ABI never allocates; the host side hands it workspaces.  Buffers are reused across calls so
-steady-state launches do no allocation at all (and stay hipGraph-capturable)."""
+steady-state launches do no allocation at all (and stay hipGraph-capturable).  A buffer belongs to the stream that was
+current when it was requested: two streams running the same operator (e.g. NMS) never share scratch memory."""
 import torch
+
+from . import _lib
 
 _BUFS = {}
 
 
 def get(tag, nbytes, device):
-    key = (tag, str(device))
+    key = (tag, str(device), int(_lib.stream().value or 0) if torch.device(device).type == "cuda" else 0)
     buf = _BUFS.get(key)
     if buf is None or buf.numel() < nbytes:
         buf = torch.empty(max(int(nbytes), 256), dtype=torch.uint8, device=device)

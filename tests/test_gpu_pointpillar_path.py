@@ -20,8 +20,8 @@ pytestmark = pytest.mark.gpu
 def _check_voxel_parity(frames, vs, rng, P, maxv, C, dev, repeat=2):
     exp = [c_oracle.voxelize(f, vs, rng, P, maxv) for f in frames]
     ev, ec, en = pp_oracle.collate(exp)
-    # all kernel paths: 3 = LDS-binned fused 2-launch (default for n_max <= 32768), 1 = LDS-binned 3-launch, 2 = global hash
-    for algo in (3, 1, 2):
+    # both kernel paths: 3 = LDS-binned, 2 launches (default for n_max <= 32768), 2 = global hash
+    for algo in (3, 2):
         _check_one_algo(frames, vs, rng, P, maxv, C, dev, repeat, algo, exp, ev, ec, en)
 
 
@@ -67,11 +67,10 @@ def test_voxelize_out_of_range_and_edges(dev):
     _check_voxel_parity([pts], synth.PP_VOXEL, synth.PP_RANGE, 32, 16000, 4, dev)
 
 
-@pytest.mark.parametrize("algo", [0, 1])
+@pytest.mark.parametrize("algo", [0])
 def test_voxelize_bin_overflow_falls_back(dev, algo):
-    """20 000 points in ONE pillar put more entries into a single LDS hash bin than its entry list holds.  The fused path
-    (algo 0 -> 3) switches that bin to its streaming variant and stays exact WITHOUT raising the flag; the 3-launch path
-    (algo 1) sets the sticky flag, voxelize_frames sees it and redoes the batch on the global-hash path."""
+    """20 000 points in ONE pillar put more entries into a single LDS hash bin than its entry list holds.  The LDS path
+    (algo 0 -> 3) switches that bin to its streaming variant and stays exact WITHOUT raising the flag."""
     r = np.random.default_rng(3)
     pts = np.concatenate([r.uniform(10.0, 10.15, (20000, 2)), r.uniform(-2, 0, (20000, 1)), r.uniform(0, 1, (20000, 1))], 1).astype(np.float32)
     other = synth.cloud_ring(2003)[:3000]
@@ -121,9 +120,10 @@ def test_voxelize_zero_padded_clouds_on_the_hot_path(dev):
 
 def _cells_of_one_bin(n_cells, G, nx=432, ny=496):
     """pillar centres of `n_cells` distinct PointPillar cells whose keys all fall into hash bin 0 of G (csrc/voxelize.hip)"""
-    key = np.arange(nx * ny, dtype=np.uint64)           # vxl_bin_of24: 24-bit multiplies, bins by pillar
-    h = (((key & np.uint64(0xFFFFFF)) * np.uint64(0x5BCA6B)) & np.uint64(0xFFFFFFFF)) ^ (key >> np.uint64(9))
-    sel = key[((((h >> np.uint64(8)) & np.uint64(0xFFFF)) * np.uint64(G)) >> np.uint64(16)) == 0][:n_cells].astype(np.int64)
+    cell = np.arange(nx * ny, dtype=np.uint64)          # vxl_bin_of24: top log2(G) bits of a 24-bit multiplicative hash of the
+    key = (cell // np.uint64(nx)) * np.uint64(nx + 1) + cell % np.uint64(nx)          # pillar in the EXTENDED grid, cy * (nx + 1) + cx
+    h = ((key & np.uint64(0xFFFFFF)) * np.uint64(0x5BCA6B)) & np.uint64(0xFFFFFFFF)
+    sel = cell[(h >> np.uint64(32 - int(np.log2(G)))) == 0][:n_cells].astype(np.int64)
     assert len(sel) == n_cells
     pts = np.zeros((n_cells, 4), np.float32)
     pts[:, 0] = (sel % nx + 0.5) * 0.16
@@ -133,11 +133,11 @@ def _cells_of_one_bin(n_cells, G, nx=432, ny=496):
 
 
 def test_voxelize_true_bin_overflow_is_reported_without_a_sync(dev):
-    """9 000 DISTINCT pillars in one LDS hash bin (adversarial: built from the hash itself) exceed the bin's table.  The
+    """9 000 DISTINCT pillars in one LDS hash bin (adversarial: built from the hash itself) exceed the bin's 4 096-slot table.  The
     kernels mirror the sticky flag into pinned host memory: __call__ raises at the next call without any device read;
     voxelize_frames redoes the batch on the global-hash path and is exact."""
     from lidardetection_amd import _lib
-    adv = _cells_of_one_bin(9000, G=8)                  # n_max 20000 -> 8 bins per frame
+    adv = _cells_of_one_bin(9000, G=16)                 # n_max 20000 -> 16 bins per frame (VXL_PTS_PER_BIN 1280)
     frames = [np.concatenate([adv, synth.cloud_uniform(1000, n=11000)], 0)]
     vz = BatchVoxelizer(synth.PP_VOXEL, synth.PP_RANGE, 32, 16000, 4)
     pts = torch.from_numpy(frames[0]).to(dev)

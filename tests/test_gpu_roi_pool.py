@@ -41,6 +41,52 @@ def test_points_in_boxes_gpu(dev):
     assert np.array_equal(out.cpu().numpy(), exp) and (exp >= 0).sum() > 500
 
 
+def test_points_in_boxes_gpu_many_boxes(dev):
+    """2 500 boxes per frame (more than one LDS tile of 1 024; r02 refused more than 1 875): the reference has no limit
+    (roiaware_pool3d_kernel.cu:313-336) — lowest containing box id, exact."""
+    r = np.random.default_rng(9)
+    nbox, npts, extent = 2500, 3000, 150.0
+    boxes = np.concatenate([r.uniform(0, extent, (nbox, 2)), r.uniform(-1, 1, (nbox, 1)), r.uniform(2.0, 6.0, (nbox, 2)),
+                            r.uniform(1.5, 3.0, (nbox, 1)), r.uniform(-np.pi, np.pi, (nbox, 1))], 1).astype(np.float32)
+    pts = np.concatenate([r.uniform(0, extent, (npts, 2)), r.uniform(-2.5, 2.5, (npts, 1))], 1).astype(np.float32)
+    # ambiguous points only: membership (float64) differs between boxes shrunk and grown by 1e-4 -> removed, and bounded
+    b, q = boxes.astype(np.float64), pts.astype(np.float64)
+    d = q[None, :, :] - b[:, None, :3]
+    c, s_ = np.cos(-b[:, 6])[:, None], np.sin(-b[:, 6])[:, None]
+    lx, ly = np.abs(d[..., 0] * c - d[..., 1] * s_), np.abs(d[..., 0] * s_ + d[..., 1] * c)
+    inside = lambda m: (lx < b[:, None, 3] / 2 + m) & (ly < b[:, None, 4] / 2 + m) & (np.abs(d[..., 2]) < b[:, None, 5] / 2 + m)
+    amb = (inside(1e-4) != inside(-1e-4)).any(0)
+    assert amb.sum() <= 0.01 * npts
+    pts = pts[~amb]
+    bb, pp = boxes[None].copy(), pts[None, :2800].copy()
+    out = roiaware_pool3d_utils.points_in_boxes_gpu(torch.from_numpy(pp).to(dev), torch.from_numpy(bb).to(dev))
+    exp = c_oracle.points_in_boxes_gpu(bb, pp)
+    assert np.array_equal(out.cpu().numpy(), exp) and (exp >= 0).sum() > 300 and exp.max() > 1100
+
+
+def test_boundary_rejects_wrong_dtype_and_shape(dev):
+    """fp32 / int32 and the last dimension are checked at the ext boundary (the reference assumes them: a float64 or (N, 8)
+    tensor would be reinterpreted bit-wise) — VERDICT r02 weak item 9."""
+    from lidardetection_amd import _lib
+    from lidardetection_amd.ext import iou3d_nms_cuda, roiaware_pool3d_cuda
+    b7 = torch.rand(10, 7, device=dev)
+    out = torch.zeros(10, 10, device=dev)
+    for bad_a, bad_out in ((b7.double(), out), (torch.rand(10, 8, device=dev), out), (b7, out.double()), (b7, torch.zeros(10, 9, device=dev))):
+        with pytest.raises(_lib.LidarHipError):
+            iou3d_nms_cuda.boxes_iou_bev_gpu(bad_a, b7, bad_out)
+    with pytest.raises(_lib.LidarHipError):
+        iou3d_nms_cuda.nms_gpu(torch.rand(10, 8, device=dev), torch.LongTensor(10), 0.1)
+    with pytest.raises(_lib.LidarHipError):
+        iou3d_nms_cuda.nms_gpu(b7.half(), torch.LongTensor(10), 0.1)
+    pts = torch.rand(1, 50, 3, device=dev)
+    idx = torch.full((1, 50), -1, dtype=torch.int32, device=dev)
+    with pytest.raises(_lib.LidarHipError):
+        roiaware_pool3d_cuda.points_in_boxes_gpu(b7.view(1, 10, 7), pts, idx.long())
+    with pytest.raises(_lib.LidarHipError):
+        roiaware_pool3d_cuda.points_in_boxes_gpu(b7.view(1, 10, 7), pts.double(), idx)
+    assert roiaware_pool3d_cuda.points_in_boxes_gpu(b7.view(1, 10, 7), pts, idx) == 1     # and the right ones pass
+
+
 @pytest.mark.parametrize("method", ["max", "avg"])
 @pytest.mark.parametrize("out_size,maxpts", [(12, 128), ((3, 5, 4), 4)])
 def test_roiaware_pool3d_forward_backward(dev, method, out_size, maxpts):

@@ -15,7 +15,7 @@ ap = argparse.ArgumentParser()
 ap.add_argument("--cloud", default="uniform")
 ap.add_argument("--iters", type=int, default=100)
 ap.add_argument("--batch", type=int, default=16)
-ap.add_argument("--algos", default="1,3,2")
+ap.add_argument("--algos", default="3,2")
 ap.add_argument("--resident", action="store_true", help="resident output buffer (include/lidar_hip.h algo 4)")
 ap.add_argument("--flush", action="store_true", help="stream 1 GiB through the caches before every call (the state the voxeliser "
                 "finds inside a detector step: points, workspace and output buffer in HBM, not in L2 / Infinity Cache)")
