@@ -60,6 +60,7 @@ struct VxWs {
     float4 *stg4;    // [B][G][VXL_CAP] C == 4: the POINTS of the list cells beyond each list's head, same positions
     int *err;        // [1] sticky error flag (LDS table / entry list overflow)
     int *tcnt;       // [B][G][32] first points of bin g per 1024-point tile (the emit stage turns them into voxel ids)
+    uint32_t *pkey;  // [B][align1024(n_max)] the frame's shared keys (vx_key2): VX_NOKEY between calls (reset by the emit launch)
     // ---- global-hash path (algo 2)
     uint32_t *keys;  // [B][H]
     int *first;      // [B][H]
@@ -119,6 +120,7 @@ static size_t vx_carve(void *base, int B, int n_max, int max_voxels, VxWs *w) {
     p = take((size_t)B * G * VXL_CAP * 16); if (w) w->stg4 = (float4 *)p;
     p = take(65536); if (w) w->err = (int *)p;  // [0] sticky error flag (+ debug stamps)
     p = take((size_t)B * G * 32 * 4 + 256); if (w) w->tcnt = (int *)p;                               // [B][G][32]
+    p = take((size_t)B * ((n_max + 1023) & ~1023) * 4 + 256); if (w) w->pkey = (uint32_t *)p;
     p = take(B * H * 4); if (w) w->keys = (uint32_t *)p;
     p = take(B * H * 4); if (w) w->first = (int *)p;
     p = take(B * H * 4); if (w) w->cnt = (int *)p;
@@ -151,6 +153,7 @@ __global__ void vx_ws_init_kernel(VxWs w, long long nh, long long nl, long long 
         w.list[k] = VX_INF;
         w.pslot[k] = -1;
     }
+    for (long long k = i; k < nq; k += stride) w.pkey[k] = 0xFFFFFFFFu;       // VX_NOKEY
     if (i == 0) {
         *w.err = 0;
         *w.mirror = nullptr;
@@ -445,9 +448,11 @@ __global__ __launch_bounds__(256) void vx_rows_kernel(const float *__restrict__ 
 #define VXL_MBITS 14        // per-point word: m = min(count, P) in the low 14 bits, list position above
 #define VXL_MMASK ((1 << VXL_MBITS) - 1)
 #define VXL_MAX_ITEMS 32    // n_max <= 32 * 1024 (a point index fits 15 bits)
-#define VXL_RISK_CAP 512    // parked points per bin workgroup (expected ~10 per frame); more -> the streaming variant
-#define VXL_A_U 5           // points per thread and round in phase A1 (two rounds in flight)
+#define VXL_A_U 10          // keys per thread requested together in phase A1 (20 spill at the 64-VGPR budget; hand-written `nt`
+                            // loads, 16 in flight on one address register, measured slower than these sc1 loads: 16.2 vs 12.1 k cycles)
 #define VXL_FILL_F4_PER_WG (1024 * 4)      // 64 KiB of zeros per fill chunk
+#define VXL_WAIT_TICKS 20000               // 200 us of the 100 MHz wall clock: how long a wave re-reads a key that has not arrived
+#define VX_NOKEY 0xFFFFFFFFu               // a shared key that has not been published (never a valid key: vx_key2)
 
 // floor(fl(d / vs)) — the reference's expression — without paying for the IEEE division when it
 // cannot matter: q' = fl(d * fl(1/vs)) is within 2^-22 (relative) of the true quotient, and so is
@@ -472,46 +477,16 @@ __device__ __forceinline__ bool vx_cell(const VxParams &p, float x, float y, flo
     return inside;
 }
 
-// x / y cell only (z is not looked at): pillar index cy * nx + cx, false when outside in x or y
-__device__ __forceinline__ bool vx_pillar(const VxParams &p, float x, float y, uint32_t &pillar) {
+// The 32-bit key the LDS path works with: cz << 24 | pillar (pillar = cy * nx + cx < 2^24, cz < 255) for a point inside the
+// grid — its low 24 bits choose the bin, so a voxel's points meet in one bin — and 0xFF000000 | (j & 0xFFFFFF) for point j
+// outside the grid (NaN included): such points spread over the bins by their index and are dead entries there (word 0).
+__device__ __forceinline__ uint32_t vx_key2(const VxParams &p, float x, float y, float z, int j) {
     const float fx = vx_floor_div(x - p.lo[0], p.vs[0], p.rvs[0]);
     const float fy = vx_floor_div(y - p.lo[1], p.vs[1], p.rvs[1]);
-    const bool inside = (fx >= 0.f) & (fx < (float)p.grid[0]) & (fy >= 0.f) & (fy < (float)p.grid[1]);
-    pillar = inside ? (uint32_t)fy * (uint32_t)p.grid[0] + (uint32_t)fx : 0u;
-    return inside;
-}
-
-// exact pillar in the EXTENDED (nx + 1) x (ny + 1) grid the bins are chosen by: column nx / row ny collect everything outside
-// in x / y (NaN included), so every point has exactly one bin
-__device__ __forceinline__ uint32_t vx_pillar_ext(const VxParams &p, float x, float y) {
-    const float fx = vx_floor_div(x - p.lo[0], p.vs[0], p.rvs[0]);
-    const float fy = vx_floor_div(y - p.lo[1], p.vs[1], p.rvs[1]);
-    const uint32_t cx = ((fx >= 0.f) & (fx < (float)p.grid[0])) ? (uint32_t)fx : (uint32_t)p.grid[0];
-    const uint32_t cy = ((fy >= 0.f) & (fy < (float)p.grid[1])) ? (uint32_t)fy : (uint32_t)p.grid[1];
-    return cy * ((uint32_t)p.grid[0] + 1u) + cx;
-}
-
-// Branch-free first look at one coordinate (phase A1 evaluates x and y of EVERY point of a frame in each of its bin
-// workgroups, so instructions count): c = floor(d * fl(1/vs)), ok = 0 <= c < n, and risky = "an integer lies within the
-// rounding margin of the quotient (or it is NaN / inf): the exact IEEE division must decide" — the same criterion as
-// vx_floor_div with the margin in absolute form (eabs >= |q| * 4.8e-7 for every quotient inside the grid; a quotient far
-// outside the grid is outside whatever its last bit).  Risky coordinates (~0.1 %) are re-evaluated with vx_pillar afterwards.
-__device__ __forceinline__ void vx_cell_fast(float d, float rvs, float eabs, int n, int &c, bool &ok, bool &risky) {
-    const float q = d * rvs;
-    const float fl = floorf(q);
-    const float fr = q - fl;                                     // in [0, 1], exact
-    risky = !(fabsf(fr - 0.5f) <= 0.5f - eabs);                   // true for NaN as well
-    c = (int)__builtin_amdgcn_fmed3f(fl, -1.0f, (float)n);        // clamped: the conversion is always defined
-    ok = (unsigned)c < (unsigned)n;
-}
-
-// full cell: key as vx_cell, plus the pillar index the bins are chosen by
-__device__ __forceinline__ bool vx_cell_pillar(const VxParams &p, float x, float y, float z, uint32_t &key, uint32_t &pillar) {
-    const bool in_xy = vx_pillar(p, x, y, pillar);
     const float fz = vx_floor_div(z - p.lo[2], p.vs[2], p.rvs[2]);
-    const bool inside = in_xy & (fz >= 0.f) & (fz < (float)p.grid[2]);
-    key = inside ? (uint32_t)fz * (uint32_t)p.grid[1] * (uint32_t)p.grid[0] + pillar : 0u;
-    return inside;
+    const bool inside = (fx >= 0.f) & (fx < (float)p.grid[0]) & (fy >= 0.f) & (fy < (float)p.grid[1]) &
+                        (fz >= 0.f) & (fz < (float)p.grid[2]);
+    return inside ? ((uint32_t)fz << 24) | ((uint32_t)fy * (uint32_t)p.grid[0] + (uint32_t)fx) : 0xFF000000u | ((uint32_t)j & 0xFFFFFFu);
 }
 
 // rows (= voxels kept) of frame k: one count per bin, left by the bin workgroups with plain stores
@@ -532,28 +507,16 @@ __device__ __forceinline__ void vxl_load_xyz(const float *__restrict__ points, s
     }
 }
 
-template <bool C4>
-__device__ __forceinline__ void vxl_load_xy(const float *__restrict__ points, size_t idx, int C, float &x, float &y) {
-    if (C4) {
-        const float2 v = reinterpret_cast<const float2 *>(points)[idx * 2];
-        x = v.x; y = v.y;
-    } else {
-        const float *q = points + idx * C;
-        x = q[0]; y = q[1];
-    }
-}
-
-// bin of a pillar: full-rate 24-bit multiplies only (v_mul_lo_u32 is quarter rate)
 __device__ __forceinline__ uint32_t vx_mul_u24(uint32_t a, uint32_t b) {   // low 32 bits of (a & 0xFFFFFF) * (b & 0xFFFFFF)
     uint32_t r;
     asm("v_mul_u32_u24 %0, %1, %2" : "=v"(r) : "s"(b), "v"(a));               // (the compiler picks the quarter-rate v_mul_lo_u32 here)
     return r;
 }
 
-// bin of an (extended-grid) pillar: the top log2(G) bits of a 24-bit multiplicative hash (full-rate v_mul_u32_u24);
-// gsh = 32 - log2(G)
-__device__ __forceinline__ int vxl_bin_of24(uint32_t pillar, int gsh) {
-    return (int)(vx_mul_u24(pillar, 0x5BCA6Bu) >> gsh);
+// bin of a key: the top log2(G) bits of a 24-bit multiplicative hash of its low 24 bits (full-rate v_mul_u32_u24, which
+// ignores the top byte by itself); gsh = 32 - log2(G)
+__device__ __forceinline__ int vxl_bin_of24(uint32_t key, int gsh) {
+    return (int)(vx_mul_u24(key, 0x5BCA6Bu) >> gsh);
 }
 
 // LDS table insert: slot of `key` (claimed if new), or -1 when the table is full
@@ -653,10 +616,10 @@ struct VxlShared {
 };
 
 // Degenerate input (thousands of points in one voxel, e.g. zero-padded clouds, where (0,0,0) lies inside the KITTI range):
-// a bin that receives more than VXL_CAP entries (or more parked points than VXL_RISK_CAP) runs WITHOUT an entry list —
-// pass 1 builds the table (first point / count per voxel) straight from the points, pass 2 re-reads them for the insertion
-// chains and the per-point words — which is exact for any multiplicity; only more than ~VXL_S distinct voxels or more than
-// VXL_CAP list cells in ONE bin still raise the error flag.
+// a bin that receives more than VXL_CAP entries runs WITHOUT an entry list — pass 1 builds the table (first point / count
+// per voxel) straight from the points, pass 2 re-reads them for the insertion chains and the per-point words — which is
+// exact for any multiplicity; only more than ~VXL_S distinct voxels or more than VXL_CAP list cells in ONE bin still raise
+// the error flag.  Works from the points alone (no shared keys).
 template <bool C4>
 __device__ __forceinline__ void vxl_bin_streaming(const float *__restrict__ points, const VxParams &p, const VxWs &w, int G,
                                                int g, int f, int start, int n, const VxlShared &sh) {
@@ -673,9 +636,8 @@ __device__ __forceinline__ void vxl_bin_streaming(const float *__restrict__ poin
         const int j = u * 1024 + t;
         float x, y, z;
         vxl_load_xyz<C4>(points, (size_t)start + min(j, n - 1), p.C, x, y, z);
-        uint32_t key, pil;
-        const bool mine = vx_cell_pillar(p, x, y, z, key, pil) && j < n && vxl_bin_of24(vx_pillar_ext(p, x, y), gsh) == g;
-        if (mine) {
+        const uint32_t key = vx_key2(p, x, y, z, j);
+        if (j < n && (key >> 24) != 0xFFu && vxl_bin_of24(key, gsh) == g) {
             const int slot = vxl_table_insert(sh.key, key);
             if (slot >= 0) {
                 atomicMin(&s_first[slot], j);
@@ -700,11 +662,10 @@ __device__ __forceinline__ void vxl_bin_streaming(const float *__restrict__ poin
         const int j = u * 1024 + t;
         float x, y, z;
         vxl_load_xyz<C4>(points, (size_t)start + min(j, n - 1), p.C, x, y, z);
-        uint32_t key, pil;
-        const bool my_bin = j < n && vxl_bin_of24(vx_pillar_ext(p, x, y), gsh) == g;            // points outside the grid get their
-        const bool mine = vx_cell_pillar(p, x, y, z, key, pil) && my_bin;                      // word (0) from their bin too
+        const uint32_t key = vx_key2(p, x, y, z, j);
+        const bool my_bin = j < n && vxl_bin_of24(key, gsh) == g;     // points outside the grid get their word (0) from their bin too
         int word = 0;
-        if (mine) {
+        if (my_bin && (key >> 24) != 0xFFu) {
             const int slot = vxl_table_find(sh.key, key);
             if (slot >= 0) {
                 const int pk = sh.cnt[slot];
@@ -720,10 +681,9 @@ __device__ __forceinline__ void vxl_bin_streaming(const float *__restrict__ poin
         if (l == 0 && bal) atomicAdd(&sh.tc[u], __popcll(bal));
     }
     __syncthreads();
-    const int Ls = L;
     int *stgi = w.stgi + ((size_t)f * G + g) * VXL_CAP;
     float4 *stg4 = w.stg4 + ((size_t)f * G + g) * VXL_CAP;
-    for (int k = t; k < Ls; k += 1024) {
+    for (int k = t; k < L; k += 1024) {
         const int j = s_list[k];
         stgi[k] = j;
         if (C4 && j != VX_INF) stg4[k] = reinterpret_cast<const float4 *>(points)[(size_t)start + j];   // heads included: harmless
@@ -731,18 +691,27 @@ __device__ __forceinline__ void vxl_bin_streaming(const float *__restrict__ poin
 }
 
 // First launch.  Workgroups [0, nbinwg): bin roles; the rest: fill roles, which clear the padded output (96 % of its bytes
-// are zeros and none depends on the index build) while the bin roles run — 74 KB of LDS and <= 64 VGPRs per workgroup, so a
+// are zeros and none depends on the index build) while the bin roles run — 72 KB of LDS and <= 64 VGPRs per workgroup, so a
 // fill workgroup is resident beside every bin workgroup on all 256 CUs.
 //   bin role (g, f):
-//   A1  x / y of ALL points of the frame (8-byte loads, two rounds in flight), branch-free fast cells clamped into an
-//       extended pillar grid (one extra column / row for everything outside in x / y), bin = hash(extended pillar): the
-//       indices of MY points are appended to the LDS entry list (one LDS atomic per wave and round).  Points whose quotient
-//       lies within the rounding margin of an integer (~0.1 %) are parked and settled with the exact IEEE division afterwards.
-//   A2 + B  my ~n / G points only: full point load, exact cell (vx_floor_div), LDS hash table insert, count per voxel.
-//   C   list offsets (scan of min(count, P) over the table slots), list heads marked in a bitmap
-//   D   ordered lists (atomicMin insertion chains)
-//   E   per-point words (a voxel's first point = the head of its list), per-tile first-point counts, staging of the lists
-//       (C == 4: of the points themselves for the cells beyond each head, so the emit launch needs no dependent gather)
+//   A0  SHARED KEYS.  Every bin workgroup of a frame needs the cell of EVERY point of the frame (to pick its own); each
+//       reading and evaluating all the points was measured L2-bound (16 workgroups x 320 KB per frame through one XCD's L2:
+//       9 us).  Instead workgroup g evaluates the exact cell of 1 / G of the frame's points and publishes 32-bit keys
+//       (vx_key2) in global memory with plain stores; the others read them with L1-bypassing (sc1) loads.  There is NO flag
+//       and no ordering requirement: a key word is VX_NOKEY from the end of the previous call (the emit launch resets it,
+//       kernel boundaries make that visible everywhere) until its producer's aligned 4-byte store lands, so a reader that
+//       sees VX_NOKEY just reads again — the data is its own flag.  The G bin workgroups of a frame are dealt to ONE XCD
+//       (ids f, f + 8, ...; observed placement, not a contract), where the store is visible in the shared L2 within ~1 us.
+//       Nothing depends on that placement for correctness: a reader on another XCD, or one whose producers are not resident
+//       beside it (another process on the GPU), keeps reading VX_NOKEY until its deadline (VXL_WAIT_TICKS) and then
+//       builds its bin from the points themselves (the streaming variant) — same result, no deadlock, every wave exits.
+//   A1  the frame's keys (4 B per point instead of a 16-B point): bin = hash(low 24 bits); the (index, key) pairs of MY
+//       points are appended to the LDS entry list (one LDS atomic per wave and round).
+//   B   LDS hash table insert, count per voxel (keys of points outside the grid are dead entries).
+//   C   list space per voxel (wave-aggregated allocation), list heads marked in a bitmap
+//   D   ordered lists (atomicMin insertion chains, whose head is the voxel's first point)
+//   E   per-point words, per-tile first-point counts, staging of the lists (C == 4: of the points themselves for the cells
+//       beyond each head, so the emit launch needs no dependent gather)
 template <bool C4>
 __global__ __launch_bounds__(1024, 8) void vxl_keybin_kernel(const float *__restrict__ points, const int *__restrict__ offsets,
                                                              VxParams p, VxWs w, int G, int nbinwg, int nfillwg,
@@ -752,12 +721,11 @@ __global__ __launch_bounds__(1024, 8) void vxl_keybin_kernel(const float *__rest
     __shared__ uint32_t s_key[VXL_S];   // keys; after phase C: list offset of the slot
     __shared__ int s_cnt[VXL_S];
     __shared__ int s_aux[VXL_S];        // streaming variant only: first point per slot
-    __shared__ int2 s_q[VXL_CAP];       // x: entry (point, then point | slot << 15), y: list cell
-    __shared__ int s_risk[VXL_RISK_CAP];
+    __shared__ int2 s_q[VXL_CAP];       // x: entry (point, then point | slot << 15), y: key, then list cell
     __shared__ uint32_t s_head[VXL_CAP / 32];
     __shared__ int s_wtot[16];
     __shared__ int s_tc[32];
-    __shared__ int s_nent, s_total, s_nrisk, s_nadd;
+    __shared__ int s_nent, s_total, s_slow;
     const int id = blockIdx.x, t = threadIdx.x, l = t & 63;
 #ifdef VXL_STAMPS   // -DVXL_STAMPS (tools/vx_phase_probe.py): shader-clock stamps of bin role 0's phases and the 100 MHz wall
                     // clock at the start / end of EVERY workgroup of both launches, into the error page
@@ -802,8 +770,7 @@ __global__ __launch_bounds__(1024, 8) void vxl_keybin_kernel(const float *__rest
         VXL_WALL(2 * id + 1);
         return;
     }
-    // ---- bin role: id -> (g, f) with the G bins of a frame on ONE XCD (workgroup i runs on XCD i % 8): they share the
-    // frame's points through that XCD's L2
+    // ---- bin role: id -> (g, f) with the G bins of a frame on ONE XCD (workgroup i runs on XCD i % 8)
     const int q8 = id >> 3;
     const int lg = __ffs(G) - 1, gsh = 32 - lg;            // G is a power of two
     const int f = (id & 7) + 8 * (q8 >> lg), g = q8 & (G - 1);
@@ -813,78 +780,69 @@ __global__ __launch_bounds__(1024, 8) void vxl_keybin_kernel(const float *__rest
         const int n = min(offsets[f + 1] - start, p.n_max);
         const int nt = (n + 1023) >> 10;
         int *pinfo = w.flagw + (size_t)f * p.n_max;
+        const int kstride = (p.n_max + 1023) & ~1023;
+        uint32_t *pkey = w.pkey + (size_t)f * kstride;
+        const int wv = __builtin_amdgcn_readfirstlane(t >> 6);
+        // ---- phase A0: my share of the frame's keys — 64-point groups [g * per, (g + 1) * per), exact cells
+        const int ngroups = (n + 63) >> 6, per = (ngroups + G - 1) >> lg;
+        const int q0 = g * per + wv, qend = min((g + 1) * per, ngroups);       // (per <= 32: at most two groups per wave)
+        float ax[2], ay[2], az[2];
+#pragma unroll
+        for (int k = 0; k < 2; ++k)                                              // requested first: the LDS tables are set up in
+            vxl_load_xyz<C4>(points, (size_t)start + min(max((q0 + 16 * k) * 64 + l, 0), max(n - 1, 0)), p.C, ax[k], ay[k], az[k]);   // their shadow
+        for (int k = t; k < VXL_S / 4; k += 1024) {
+            reinterpret_cast<uint4 *>(s_key)[k] = make_uint4(VX_EMPTY, VX_EMPTY, VX_EMPTY, VX_EMPTY);
+            reinterpret_cast<int4 *>(s_cnt)[k] = make_int4(0, 0, 0, 0);
+        }
+        if (t < VXL_CAP / 32) s_head[t] = 0u;
+        if (t < 32) s_tc[t] = 0;
+        if (t == 0) s_nent = s_total = s_slow = 0;
+#pragma unroll
+        for (int k = 0; k < 2; ++k) {
+            const int q = q0 + 16 * k, j = q * 64 + l;
+            if (q < qend) pkey[j] = j < n ? vx_key2(p, ax[k], ay[k], az[k], j) : 0xFF000000u | (uint32_t)j;   // (padding of the last group)
+        }
+        for (int q = q0 + 32; q < qend; q += 16) {                               // (frames beyond 32 768 points never get here)
+            const int j = q * 64 + l;
+            float x, y, z;
+            vxl_load_xyz<C4>(points, (size_t)start + min(j, n - 1), p.C, x, y, z);
+            pkey[j] = j < n ? vx_key2(p, x, y, z, j) : 0xFF000000u | (uint32_t)j;
+        }
+        __syncthreads();
+        VXL_STAMP(1);
         // ---- phase A1.  A wave owns a contiguous run of points (its entries come out ascending, which keeps the later
-        // per-entry stores of a wave close together); point (u, lane) of wave wv = wbase + u * 64 + lane.  Rounds of VXL_A_U
-        // points per lane, double-buffered in registers: the loads of round r + 1 are in flight while round r is evaluated, and
-        // the first round's loads are issued before the LDS tables are initialised.
-        const int wv = __builtin_amdgcn_readfirstlane(t >> 6);      // (scalar: round-level conditions are wave-uniform branches)
+        // per-entry stores of a wave close together); point (u, lane) of wave wv = wbase + u * 64 + lane.  The frame's keys are
+        // read with L1-bypassing loads and a key that still reads VX_NOKEY (its producer has not stored it yet) is simply read
+        // again, until the wave's deadline; past it the workgroup falls back to the streaming variant, which needs no shared keys.
+        // ---- phase A1.  A wave owns a contiguous run of points (its entries come out ascending, which keeps the later
+        // per-entry stores of a wave close together); point (u, lane) of wave wv = wbase + u * 64 + lane
         const int wbase = wv * nt * 64;
-        const char *fbase = reinterpret_cast<const char *>(points) + (size_t)start * p.C * sizeof(float);
-        const uint32_t pstride = C4 ? 16u : (uint32_t)p.C * (uint32_t)sizeof(float);
-        auto issue = [&](int u0, float (&x)[VXL_A_U], float (&y)[VXL_A_U]) {
-            const int jb = wbase + u0 * 64 + l;
-#if defined(VXL_EXP) && VXL_EXP == 2      // probe: no loads, synthetic coordinates
-            for (int u = 0; u < VXL_A_U; ++u) { x[u] = (float)((jb + u * 64) * 37 % 6912) * 0.01f; y[u] = (float)((jb + u * 64) * 53 % 7936) * 0.01f - 39.68f; }
-            return;
-#endif
-            if (wbase + (u0 + VXL_A_U) * 64 <= n) {                  // wave-uniform: every point of the round exists
+        const long long deadline = wall_clock64() + VXL_WAIT_TICKS;
+        for (int u0 = 0; u0 < nt; u0 += VXL_A_U) {
+            uint32_t key[VXL_A_U];
+            for (;;) {
+                bool missing = false;
 #pragma unroll
-                for (int u = 0; u < VXL_A_U; ++u) {
-                    const char *q = fbase + (uint32_t)(jb + u * 64) * pstride;
-                    if (C4) { const float2 v = *reinterpret_cast<const float2 *>(q); x[u] = v.x; y[u] = v.y; }
-                    else { x[u] = reinterpret_cast<const float *>(q)[0]; y[u] = reinterpret_cast<const float *>(q)[1]; }
-                }
-            } else {
+                for (int u = 0; u < VXL_A_U; ++u)                       // global_load_dword sc1: L1 bypassed, re-issued every time
+                    key[u] = __hip_atomic_load(pkey + wbase + (u0 + u) * 64 + l, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 #pragma unroll
-                for (int u = 0; u < VXL_A_U; ++u) {
-                    const char *q = fbase + (uint32_t)max(min(jb + u * 64, n - 1), 0) * pstride;
-                    if (C4) { const float2 v = *reinterpret_cast<const float2 *>(q); x[u] = v.x; y[u] = v.y; }
-                    else { x[u] = reinterpret_cast<const float *>(q)[0]; y[u] = reinterpret_cast<const float *>(q)[1]; }
+                for (int u = 0; u < VXL_A_U; ++u)                       // (rows past the frame read as VX_NOKEY: masked)
+                    missing |= (key[u] == VX_NOKEY) & (wbase + (u0 + u) * 64 + l < n) & (u0 + u < nt);
+                if (__ballot(missing) == 0ull) break;                  // wave-uniform
+                if (wall_clock64() > deadline) {                       // the frame's other workgroups are not (all) running beside
+                    s_slow = 1;                                        // this one: the workgroup redoes its bin from the points
+                    break;                                             // themselves (streaming variant) after the barrier
                 }
+                __builtin_amdgcn_s_sleep(4);
             }
-        };
-        // Branch-free per point: the cell is clamped into an EXTENDED (nx + 1) x (ny + 1) pillar grid whose last column / row
-        // collect everything outside in x / y, and the bin is the hash of that extended pillar — so a point outside the grid is an
-        // ordinary entry of exactly one bin (phase A2 finds it outside with the exact expression and phase E writes its word, 0).
-        // Risky coordinates (an integer within the rounding margin of the quotient, NaN, inf) are collected per lane and parked
-        // once per round.
-        const float tx = 0.5f - p.eabs[0], ty = 0.5f - p.eabs[1];
-        const uint32_t nxe = (uint32_t)p.grid[0] + 1u;
-        auto round = [&](auto FULL, int u0, const float (&x)[VXL_A_U], const float (&y)[VXL_A_U]) {
-            constexpr bool full = decltype(FULL)::value;            // every point of the round exists
-            uint32_t bits = 0, rbits = 0;       // bit u: that point goes to my bin / must be settled with the exact division
+            uint32_t bits = 0;                  // bit u: that point goes to my bin
             int wtotal = 0;                     // wave-uniform: entries of this wave in this round
 #pragma unroll
             for (int u = 0; u < VXL_A_U; ++u) {
-                // floor(q) without v_floor / v_med3 / v_cvt: h = q + 0.5, t = h + 2^23 rounds h (to nearest) onto the integers of
-                // [2^23, 2^24), where the low bits of t ARE round(h) = floor(q) + 1 — unless q sits within the margin of an integer,
-                // which is exactly the risky case, decided by the IEEE division anyway (e = h - round(h) is the distance of q from
-                // the middle of its cell, exact; the margin also covers the rounding of h itself).  Negative q (t <= 2^23), huge
-                // values, inf and NaN all give "bits(t) - bits(2^23) - 1" >= n as unsigned: outside.
-                const float hx = (x[u] - p.lo[0]) * p.rvs[0] + 0.5f, hy = (y[u] - p.lo[1]) * p.rvs[1] + 0.5f;
-                const float tqx = hx + 8388608.0f, tqy = hy + 8388608.0f;
-                const float ex = hx - (tqx - 8388608.0f), ey = hy - (tqy - 8388608.0f);
-                bool risky = !(fabsf(ex) <= tx) | !(fabsf(ey) <= ty);                         // true for NaN as well
-                const uint32_t cx = min(__float_as_uint(tqx) - 0x4B000001u, (uint32_t)p.grid[0]);
-                const uint32_t cy = min(__float_as_uint(tqy) - 0x4B000001u, (uint32_t)p.grid[1]);
-                const uint32_t pil = __umul24(cy, nxe) + cx;                                  // extended grids below 2^24 cells
-                bool mine = !risky & (vxl_bin_of24(pil, gsh) == g);
-                if (!full) {
-                    const bool valid = (wbase + (u0 + u) * 64 + l < n) & (u0 + u < nt);
-                    mine &= valid;
-                    risky &= valid;
-                }
+                const int j = wbase + (u0 + u) * 64 + l;
+                const bool mine = (vxl_bin_of24(key[u], gsh) == g) & (j < n) & (u0 + u < nt);
                 bits |= (uint32_t)mine << u;
-                rbits |= (uint32_t)risky << u;
                 wtotal += __popcll(__ballot(mine));
-            }
-            if (__builtin_expect(__ballot(rbits != 0u) != 0ull, 0)) {     // wave-uniform, ~1 round in 4
-                while (rbits) {
-                    const int u = __builtin_ctz(rbits);
-                    rbits &= rbits - 1u;
-                    const int k = atomicAdd(&s_nrisk, 1);
-                    if (k < VXL_RISK_CAP) s_risk[k] = wbase + (u0 + u) * 64 + l;
-                }
             }
             int base = 0;
             if (l == 0 && wtotal) base = atomicAdd(&s_nent, wtotal);
@@ -894,92 +852,39 @@ __global__ __launch_bounds__(1024, 8) void vxl_keybin_kernel(const float *__rest
                 const bool mine = (bits >> u) & 1u;
                 const unsigned long long bal = __ballot(mine);
                 const int pos = base + __popcll(bal & lanemask_lt());
-                if (mine && pos < VXL_CAP) s_q[pos] = make_int2(wbase + (u0 + u) * 64 + l, VX_INF);
+                if (mine && pos < VXL_CAP) s_q[pos] = make_int2(wbase + (u0 + u) * 64 + l, (int)key[u]);
                 base += __popcll(bal);
             }
-        };
-        auto process = [&](int u0, const float (&x)[VXL_A_U], const float (&y)[VXL_A_U]) {
-#if defined(VXL_EXP) && VXL_EXP == 1      // probe: loads only
-            float acc = 0.f;
-            for (int u = 0; u < VXL_A_U; ++u) acc += x[u] + y[u];
-            if (acc == 12345.678f) s_risk[0] = 1;
-            return;
-#endif
-            if (u0 + VXL_A_U <= nt && wbase + (u0 + VXL_A_U) * 64 <= n) round(std::true_type{}, u0, x, y);      // wave-uniform
-            else round(std::false_type{}, u0, x, y);
-        };
-        float xa[VXL_A_U], ya[VXL_A_U], xb[VXL_A_U], yb[VXL_A_U];
-        if (nt > 0) issue(0, xa, ya);
-        for (int k = t; k < VXL_S / 4; k += 1024) {
-            reinterpret_cast<uint4 *>(s_key)[k] = make_uint4(VX_EMPTY, VX_EMPTY, VX_EMPTY, VX_EMPTY);
-            reinterpret_cast<int4 *>(s_cnt)[k] = make_int4(0, 0, 0, 0);
         }
-        if (t < VXL_CAP / 32) s_head[t] = 0u;
-        if (t < 32) s_tc[t] = 0;
-        if (t == 0) s_nent = s_nrisk = s_total = s_nadd = 0;
-        __syncthreads();
-        VXL_STAMP(1);
-        // (every round issues the next one's loads unconditionally — clamped to the frame, at most one round is wasted — so the
-        // number of loads in flight is static and the waits are counted, not drained)
-        for (int u0 = 0; u0 < nt; u0 += 2 * VXL_A_U) {
-            issue(u0 + VXL_A_U, xb, yb);
-            process(u0, xa, ya);
-            if (u0 + VXL_A_U >= nt) break;
-            issue(u0 + 2 * VXL_A_U, xa, ya);
-            process(u0 + VXL_A_U, xb, yb);
-        }
-        __syncthreads();
         VXL_STAMP(2);
+        __syncthreads();
+        VXL_STAMP(3);
         VxlShared sh;
         sh.key = s_key; sh.cnt = s_cnt; sh.aux = s_aux; sh.q = s_q; sh.wtot = s_wtot; sh.tc = s_tc; sh.total = &s_total;
-        const int ne0 = s_nent, nr = s_nrisk;
-        if (__builtin_expect(ne0 + nr > VXL_CAP || nr > VXL_RISK_CAP, 0)) {   // block-uniform, degenerate input only
+        if (__builtin_expect(s_nent > VXL_CAP || s_slow != 0, 0)) {  // block-uniform: degenerate input, or keys that never arrived
             vxl_bin_streaming<C4>(points, p, w, G, g, f, start, n, sh);
         } else {
-            // ---- phase A2 + B: my points only — exact cell, LDS hash table insert, count per voxel.  The parked points
-            // (~0.1 % of the frame) are candidates of the same pass: the reference's expression with the IEEE division decides
-            // their pillar, and the ones of my bin are appended behind the entries (s_nadd).
-            const int nc = ne0 + nr;
-            for (int e0 = 0; e0 < nc; e0 += 2048) {
-                int jj[2];
-                float x[2], y[2], z[2];
-#pragma unroll
-                for (int k = 0; k < 2; ++k) {
-                    const int e = min(e0 + k * 1024 + t, nc - 1);
-                    jj[k] = e < ne0 ? s_q[e].x : s_risk[e - ne0];
-                    vxl_load_xyz<C4>(points, (size_t)start + jj[k], p.C, x[k], y[k], z[k]);
-                }
-#pragma unroll
-                for (int k = 0; k < 2; ++k) {
-                    int e = e0 + k * 1024 + t;
-                    if (e < nc) {
-                        if (e >= ne0) {                                   // a parked point: mine?
-                            if (vxl_bin_of24(vx_pillar_ext(p, x[k], y[k]), gsh) != g) continue;
-                            e = ne0 + atomicAdd(&s_nadd, 1);              // < ne0 + nr <= VXL_CAP
-                            s_q[e].y = VX_INF;
-                        }
-                        uint32_t key, pil;
-                        int en = jj[k] | (int)0x80000000;                 // outside the grid / table full: dead entry, word 0
-                        if (vx_cell_pillar(p, x[k], y[k], z[k], key, pil)) {
-                            const int slot = vxl_table_insert(s_key, key);
-                            if (slot >= 0) {
-                                atomicAdd(&s_cnt[slot], 1);
-                                en = jj[k] | (slot << 15);
-                            } else {
-                                vx_raise(w, 1);
-                            }
-                        }
-                        s_q[e].x = en;
+            const int ne = s_nent;
+            // ---- phase B: LDS hash table insert, count per voxel; every entry's list cell starts out free (a bin has at
+            // most as many list cells as entries)
+            for (int e = t; e < ne; e += 1024) {
+                const int2 q = s_q[e];
+                int en = q.x | (int)0x80000000;                       // outside the grid / table full: dead entry, word 0
+                if (((uint32_t)q.y >> 24) != 0xFFu) {
+                    const int slot = vxl_table_insert(s_key, (uint32_t)q.y);
+                    if (slot >= 0) {
+                        atomicAdd(&s_cnt[slot], 1);
+                        en = q.x | (slot << 15);
+                    } else {
+                        vx_raise(w, 1);
                     }
                 }
+                s_q[e] = make_int2(en, VX_INF);
             }
             __syncthreads();
-            VXL_STAMP(3);
-            const int ne = ne0 + s_nadd;
             // ---- phase C: list space per voxel (the keys are not needed any more: offsets overwrite them), list heads marked.
             // Allocated wave by wave with ONE LDS atomic per wave (no scan across the workgroup, no barrier inside): where a
-            // voxel's list lies is internal — the per-point words carry the positions.  Every list cell was set to "free" when
-            // its entry was appended (a bin has at most as many list cells as entries).
+            // voxel's list lies is internal — the per-point words carry the positions.
             {
                 int m[VXL_S / 1024];
                 int run = 0;
@@ -1100,6 +1005,7 @@ __global__ __launch_bounds__(1024, 8) void vxl_emit_kernel(const float *__restri
         part = wave_sum(part);
         if (l == 0) s_base = p.compact ? part : f * p.max_voxels;
     }
+    if (i < ((n + 63) & ~63)) w.pkey[(size_t)f * ((p.n_max + 1023) & ~1023) + i] = VX_NOKEY;      // the frame's shared keys: unpublished again for the next call
     if (tile == 0 && f == 0 && wv == 14) {            // the batch's offsets table (off the critical path)
         int carry = 0;
         for (int k0 = 0; k0 < p.batch; k0 += 64) {
@@ -1243,7 +1149,7 @@ LIDAR_EXPORT int lidar_voxelize_workspace_init(void *ws, size_t ws_bytes, int ba
     VxWs w;
     if (vx_carve(ws, batch, n_max, max_voxels, &w) > ws_bytes) return LIDAR_ERR_WORKSPACE;
     const long long nh = (long long)batch * vx_hash_capacity(n_max), nl = (long long)batch * n_max;
-    hipLaunchKernelGGL(vx_ws_init_kernel, dim3(1024), dim3(256), 0, (hipStream_t)stream, w, nh, nl, 0LL);
+    hipLaunchKernelGGL(vx_ws_init_kernel, dim3(1024), dim3(256), 0, (hipStream_t)stream, w, nh, nl, (long long)batch * ((n_max + 1023) & ~1023));
     return lidar_check_launch("vx_ws_init");
 }
 
@@ -1284,7 +1190,7 @@ LIDAR_EXPORT int lidar_voxelize(const float *points, const int *point_offsets, i
         p.lo[j] = range6[j];
         p.vs[j] = voxel_size3[j];
         p.rvs[j] = 1.0f / voxel_size3[j];
-        p.eabs[j] = fminf(((float)grid3[j] + 2.0f) * 6.2e-7f, 0.5f);     // (4.9e-7 + the rounding of q + 0.5 in phase A1)
+        p.eabs[j] = fminf(((float)grid3[j] + 2.0f) * 4.9e-7f, 0.5f);
         p.grid[j] = grid3[j];
     }
     p.C = num_features;
@@ -1306,7 +1212,7 @@ LIDAR_EXPORT int lidar_voxelize(const float *points, const int *point_offsets, i
     // algo 0 = auto, 3 (and 1, its former three-launch variant) = LDS-binned, 2 launches, 4 = 3 with a resident output buffer
     // (n_max <= 32768, max_points < 16384, x / y grid below 2^24 cells), 2 = global hash table (any size)
     const bool lds_ok = (n_max <= VXL_MAX_ITEMS * 1024) && (max_points <= VXL_MMASK) &&
-                        (((double)grid3[0] + 1.0) * ((double)grid3[1] + 1.0) < 16777216.0);
+                        ((double)grid3[0] * (double)grid3[1] < 16777216.0) && grid3[2] < 255;
     if (algo == 1) algo = 3;
     if ((algo == 3 || algo == 4) && !lds_ok) return LIDAR_ERR_ARG;
     if (algo == 0) algo = lds_ok ? 3 : 2;

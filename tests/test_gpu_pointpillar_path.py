@@ -121,8 +121,7 @@ def test_voxelize_zero_padded_clouds_on_the_hot_path(dev):
 def _cells_of_one_bin(n_cells, G, nx=432, ny=496):
     """pillar centres of `n_cells` distinct PointPillar cells whose keys all fall into hash bin 0 of G (csrc/voxelize.hip)"""
     cell = np.arange(nx * ny, dtype=np.uint64)          # vxl_bin_of24: top log2(G) bits of a 24-bit multiplicative hash of the
-    key = (cell // np.uint64(nx)) * np.uint64(nx + 1) + cell % np.uint64(nx)          # pillar in the EXTENDED grid, cy * (nx + 1) + cx
-    h = ((key & np.uint64(0xFFFFFF)) * np.uint64(0x5BCA6B)) & np.uint64(0xFFFFFFFF)
+    h = ((cell & np.uint64(0xFFFFFF)) * np.uint64(0x5BCA6B)) & np.uint64(0xFFFFFFFF)   # pillar cy * nx + cx (low 24 bits of the key)
     sel = cell[(h >> np.uint64(32 - int(np.log2(G)))) == 0][:n_cells].astype(np.int64)
     assert len(sel) == n_cells
     pts = np.zeros((n_cells, 4), np.float32)

@@ -145,6 +145,32 @@ def pp_kernels(model, pts, offs):
             "nms_mask_note": f"prep + mask kernels on the step's own {model.B} x {model.nms_pre} candidates, thr {model.nms_thresh}"}
 
 
+def pp_ring(model):
+    """the voxeliser bracket inside full PointPillar steps on KITTI-like RING clouds (multi-point pillars, 8.9 k pillars per frame,
+    a third of the points outside the grid) — the headline uses the uniform cloud; both output modes"""
+    dev = model.anchors.device
+    pts, offs, sizes = _batch([synth.cloud_ring(2000 + f) for f in range(model.B)], dev)
+    out = {}
+    keep = model.resident_voxels
+    with torch.no_grad():
+        for mode, resident in (("resident", True), ("contract", False)):
+            model.resident_voxels = resident
+            for _ in range(2):
+                model(pts, offs)
+            evs = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(10)]
+            for a, b in evs:
+                a.record()
+                vox = model.voxelize(pts, offs)
+                b.record()
+                model.post_process(*model.backbone_head(model.vfe_scatter(vox)))
+            torch.cuda.synchronize()
+            out[f"{mode}_us"] = float(np.mean([a.elapsed_time(b) for a, b in evs])) * 1e3
+        out["rows"] = int(vox["voxel_offsets"][-1].item())
+    model.resident_voxels = keep
+    model(pts, offs)
+    return {"voxelize_ring_cloud": dict(out, note="HIP-event bracket of lidar_voxelize inside full steps, cloud_ring(2000..2015), 16 frames")}
+
+
 def collect(dev):
     out = {}
     for fn in (second_kitti, nms_boxes, pvrcnn, multihead):

@@ -18,7 +18,7 @@ resident = "--resident" in sys.argv
 n_max = max(sizes); G = -(-n_max // 1280); CAP = 3072
 al = lambda x: (x + 255) // 256 * 256
 err_off = al(B * n_max * 4) + al(B * G * CAP * 4) + al(B * G * CAP * 16)          # vx_carve: flagw, stgi, stg4, then the error page
-names = ["start", "lds init", "A1 xy+append", "A2+B table", "C offsets", "D chains", "E words+staging", "end"]
+names = ["start", "A0 my keys + lds init", "A1 (wave 0)", "A1 barrier (slowest wave)", "B table + C offsets", "D chains", "E words+staging", "end"]
 junk = torch.empty(256 * 1024 * 1024, dtype=torch.float32, device=dev) if "--flush" in sys.argv else None
 nbin = 8 * G * ((B + 7) // 8)
 ntile = -(-n_max // 1024)
