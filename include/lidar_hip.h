@@ -262,18 +262,20 @@ int lidar_spconv_conv_tables(int n, int kD, int kH, int kW, int sD, int sH, int 
  * (tables hold -1), reaches no output, never scattered.  lidar_spconv_grid_pad_rows turns rows [min(*num_dev, cap), cap) of
  * out_indices into padding rows; `limit` of the table builders = row count of the tensor the looked-up grid holds (grid values
  * >= limit read as "no row"; <= 0: no limit), so a capacity that turns out too small yields wrong tables, never wild row ids.
+ * `batch` = frames the grids were allocated for: a row whose batch index lies outside [0, batch) is treated like a padding row
+ * (skipped), never an out-of-bounds access.
  *   lidar_spconv_transpose_table  nbr_t (n_in, K), pre-filled with -1 by the caller, from nbr (n_out, K) alone:
  *                              nbr[j][k] == i  <=>  nbr_t[i][k] == j (equals grid_table_t when input coordinates are unique) */
 int lidar_spconv_grid_init(int *grid, size_t cells, void *stream);
-int lidar_spconv_grid_rows(const int *indices, int n, const int *n_dev, int D, int H, int W, int *grid, int mode, void *stream);
-int lidar_spconv_grid_table(const int *out_indices, int n_out, int D, int H, int W, int kD, int kH, int kW, int sD, int sH, int sW,
+int lidar_spconv_grid_rows(const int *indices, int n, const int *n_dev, int batch, int D, int H, int W, int *grid, int mode, void *stream);
+int lidar_spconv_grid_table(const int *out_indices, int n_out, int batch, int D, int H, int W, int kD, int kH, int kW, int sD, int sH, int sW,
                             int pD, int pH, int pW, const int *grid_in, int limit, int *nbr, void *stream);
-int lidar_spconv_grid_table_t(const int *indices, int n, int D, int H, int W, int kD, int kH, int kW, int sD, int sH, int sW, int pD,
+int lidar_spconv_grid_table_t(const int *indices, int n, int batch, int D, int H, int W, int kD, int kH, int kW, int sD, int sH, int sW, int pD,
                               int pH, int pW, const int *grid_out, int limit, int *nbr_t, void *stream);
 int lidar_spconv_grid_pad_rows(int *out_indices, const int *num_dev, int cap, void *stream);
 int lidar_spconv_transpose_table(const int *nbr, int n_out, int K, int n_in, int *nbr_t, void *stream);
 size_t lidar_spconv_grid_outputs_workspace_bytes(int n, int K);
-int lidar_spconv_grid_outputs(const int *indices, int n, int D, int H, int W, int kD, int kH, int kW, int sD, int sH, int sW, int pD,
+int lidar_spconv_grid_outputs(const int *indices, int n, int batch, int D, int H, int W, int kD, int kH, int kW, int sD, int sH, int sW, int pD,
                               int pH, int pW, int *grid_out, int *out_indices, int *num_out, void *ws, size_t ws_bytes,
                               void *stream);
 /* indice_conv forward (and input gradient with the transposed table + transposed weights):
@@ -347,6 +349,33 @@ int lidar_anchor_scores(const float *head, long long n_loc, int row_stride, int 
 int lidar_decode_topk(const float *head, int batch, long long locs_per_frame, int row_stride, int box_off, int dir_off,
                       int anchors_per_loc, int num_dir_bins, const long long *top_idx, int k, const float *anchors,
                       float dir_offset, float dir_limit_offset, float period, float *boxes, void *stream);
+/* Exact top-k of the masked scores that feed NMS (reference: torch.topk(box_scores, k = min(NMS_PRE_MAXSIZE, n)) in
+ * class_agnostic_nms, pcdet/models/model_utils/model_nms_utils.py:9-11) for a whole batch, deterministic — descending score, ties by
+ * ascending anchor index (torch.topk leaves ties unspecified) — in 3 launches, no host synchronisation (csrc/topk.hip).
+ *   lidar_topk_workspace_bytes / _init   workspace for (batch, n) scores; init once per buffer (histograms start at zero)
+ *   lidar_anchor_scores_hist             = lidar_anchor_scores on (batch, locs_per_frame, row_stride) head rows, and counts every score
+ *                                        >= score_thresh into the workspace's per-frame histogram (launch 1 of the 3)
+ *   lidar_topk_desc                      scores (batch, n) f32, n % 4 == 0, rows 16-B aligned; k <= 4096; candidates = scores >=
+ *                                        valid_min (> 0); hist_ready: the histogram was filled by lidar_anchor_scores_hist with
+ *                                        score_thresh == valid_min (scores <= score_max); else one more pass builds it.
+ *                                        -> top_scores (batch, k), top_idx (batch, k) i64, counts (batch) i32 = candidates kept;
+ *                                        slots past counts[b] hold (-1, 0) */
+size_t lidar_topk_workspace_bytes(int batch, long long n);
+int lidar_topk_workspace_init(void *ws, size_t ws_bytes, int batch, long long n, void *stream);
+int lidar_anchor_scores_hist(const float *head, int batch, long long locs_per_frame, int row_stride, int cls_off, int anchors_per_loc,
+                             int num_class, float score_thresh, float *scores, unsigned char *labels, void *ws, size_t ws_bytes,
+                             void *stream);
+int lidar_topk_desc(const float *scores, int batch, long long n, int k, float valid_min, float score_max, int hist_ready,
+                    float *top_scores, long long *top_idx, int *counts, void *ws, size_t ws_bytes, void *stream);
+/* Everything between the NMS keep lists and the detector's output, batched, one launch (reference, per sample:
+ * selected = keep[:NMS_POST_MAXSIZE]; final boxes / scores / labels by index chains — pcdet/models/model_utils/
+ * model_nms_utils.py:19-25, pcdet/models/detectors/detector3d_template.py:236-262).  boxes (batch, k, 7), top_scores (batch, k),
+ * top_idx (batch, k) i64 anchor ids, labels (batch, n) u8 class ids, keep (batch, keep_stride) i64 candidate positions, num_keep
+ * (batch) -> out_boxes (batch, post, 7), out_scores (batch, post), out_labels (batch, post) i64 = class + 1, out_num (batch) =
+ * min(num_keep, post); slots past out_num repeat candidate 0. */
+int lidar_post_nms_gather(const float *boxes, const float *top_scores, const long long *top_idx, const unsigned char *labels,
+                          const long long *keep, const int *num_keep, int batch, int k, long long n, int keep_stride, int post,
+                          float *out_boxes, float *out_scores, long long *out_labels, int *out_num, void *stream);
 
 /* HeightCompression in one pass (pcdet/models/backbones_2d/map_to_bev/height_compression.py:21-24): the (N, C*D, H, W) BEV
  * map of a sparse tensor written directly channels-last: out[b][h][w][c*D + d]; D <= 4, channels % 4 == 0; same workspace

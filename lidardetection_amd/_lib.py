@@ -62,13 +62,13 @@ SIGNATURES = {
     "lidar_spconv_conv_outputs": (i32, [vp, i32, i32, i32, i32, i32, i32, i32, i32, i32, i32, i32, i32, i32, i32, vp, i32, vp, vp, sz, vp]),
     "lidar_spconv_conv_tables": (i32, [i32, i32, i32, i32, i32, i32, i32, i32, vp, vp, vp, sz, vp]),
     "lidar_spconv_grid_init": (i32, [vp, sz, vp]),
-    "lidar_spconv_grid_rows": (i32, [vp, i32, vp, i32, i32, i32, vp, i32, vp]),
-    "lidar_spconv_grid_table": (i32, [vp, i32, i32, i32, i32, i32, i32, i32, i32, i32, i32, i32, i32, i32, vp, i32, vp, vp]),
-    "lidar_spconv_grid_table_t": (i32, [vp, i32, i32, i32, i32, i32, i32, i32, i32, i32, i32, i32, i32, i32, vp, i32, vp, vp]),
+    "lidar_spconv_grid_rows": (i32, [vp, i32, vp, i32, i32, i32, i32, vp, i32, vp]),
+    "lidar_spconv_grid_table": (i32, [vp, i32, i32, i32, i32, i32, i32, i32, i32, i32, i32, i32, i32, i32, i32, vp, i32, vp, vp]),
+    "lidar_spconv_grid_table_t": (i32, [vp, i32, i32, i32, i32, i32, i32, i32, i32, i32, i32, i32, i32, i32, i32, vp, i32, vp, vp]),
     "lidar_spconv_grid_pad_rows": (i32, [vp, vp, i32, vp]),
     "lidar_spconv_transpose_table": (i32, [vp, i32, i32, i32, vp, vp]),
     "lidar_spconv_grid_outputs_workspace_bytes": (sz, [i32, i32]),
-    "lidar_spconv_grid_outputs": (i32, [vp, i32, i32, i32, i32, i32, i32, i32, i32, i32, i32, i32, i32, i32, vp, vp, vp, vp, sz, vp]),
+    "lidar_spconv_grid_outputs": (i32, [vp, i32, i32, i32, i32, i32, i32, i32, i32, i32, i32, i32, i32, i32, i32, vp, vp, vp, vp, sz, vp]),
     "lidar_spconv_implicit_gemm": (i32, [vp, vp, i32, i32, i32, i32, vp, vp, vp, vp]),
     "lidar_spconv_implicit_gemm_fused": (i32, [vp, vp, i32, i32, i32, i32, vp, vp, vp, i32, vp, vp]),
     "lidar_spconv_row_masks": (i32, [vp, i32, i32, vp, vp]),
@@ -88,6 +88,11 @@ SIGNATURES = {
     "lidar_bias_act_upsample_nhwc": (i32, [vp, vp, i32, i32, i32, i32, i32, i32, vp, i32, i32, vp]),
     "lidar_anchor_scores": (i32, [vp, C.c_longlong, i32, i32, i32, i32, f32, vp, vp, vp]),
     "lidar_decode_topk": (i32, [vp, i32, C.c_longlong, i32, i32, i32, i32, i32, vp, i32, vp, f32, f32, f32, vp, vp]),
+    "lidar_topk_workspace_bytes": (sz, [i32, C.c_longlong]),
+    "lidar_topk_workspace_init": (i32, [vp, sz, i32, C.c_longlong, vp]),
+    "lidar_anchor_scores_hist": (i32, [vp, i32, C.c_longlong, i32, i32, i32, i32, f32, vp, vp, vp, sz, vp]),
+    "lidar_topk_desc": (i32, [vp, i32, C.c_longlong, i32, f32, f32, i32, vp, vp, vp, vp, sz, vp]),
+    "lidar_post_nms_gather": (i32, [vp, vp, vp, vp, vp, vp, i32, i32, C.c_longlong, i32, i32, vp, vp, vp, vp, vp]),
     "lidar_rotate_iou_eval": (i32, [vp, i32, vp, i32, i32, vp, vp]),
     "lidar_boxes_iou_bev_cpu": (i32, [vp, i32, vp, i32, vp]),
     "lidar_points_in_boxes_cpu": (i32, [vp, i32, vp, i32, vp]),

@@ -101,3 +101,43 @@ LIDAR_EXPORT int lidar_decode_topk(const float *head, int batch, long long locs_
                        dir_limit_offset, period, boxes);
     return lidar_check_launch("lidar_decode_topk");
 }
+
+// Everything between the NMS keep lists and the detector's output in ONE launch (the reference does it per sample with index
+// chains: selected = keep[:NMS_POST_MAXSIZE]; final_boxes = box_preds[selected]; final_scores, final_labels likewise —
+// model_nms_utils.py:19-25, detector3d_template.py:236-262): out_boxes (B, post, 7), out_scores (B, post), out_labels (B, post)
+// int64 = class + 1, out_num (B) = min(num_keep, post).  Slots past out_num repeat candidate 0 of the frame, as the batched torch
+// gathers this replaces did (callers read only the first out_num).
+__global__ __launch_bounds__(256) void post_nms_gather_kernel(const float *__restrict__ boxes, const float *__restrict__ top_scores,
+                                                              const long long *__restrict__ top_idx, const unsigned char *__restrict__ labels,
+                                                              const long long *__restrict__ keep, const int *__restrict__ num_keep,
+                                                              int batch, int k, long long n, int keep_stride, int post,
+                                                              float *__restrict__ out_boxes, float *__restrict__ out_scores,
+                                                              long long *__restrict__ out_labels, int *__restrict__ out_num) {
+    const int j = blockIdx.x * 256 + threadIdx.x;
+    if (j >= batch * post) return;
+    const int b = j / post, s = j - b * post;
+    const int nk = min(num_keep[b], post);
+    if (s == 0) out_num[b] = nk;
+    long long c = 0;
+    if (s < nk) c = min(max(keep[(size_t)b * keep_stride + s], 0ll), (long long)k - 1);
+    const float *src = boxes + ((size_t)b * k + c) * 7;
+    float *dst = out_boxes + (size_t)j * 7;
+#pragma unroll
+    for (int q = 0; q < 7; ++q) dst[q] = src[q];
+    out_scores[j] = top_scores[(size_t)b * k + c];
+    const long long a = min(max(top_idx[(size_t)b * k + c], 0ll), n - 1);
+    out_labels[j] = (long long)labels[(size_t)b * n + a] + 1;
+}
+
+LIDAR_EXPORT int lidar_post_nms_gather(const float *boxes, const float *top_scores, const long long *top_idx, const unsigned char *labels,
+                                       const long long *keep, const int *num_keep, int batch, int k, long long n, int keep_stride,
+                                       int post, float *out_boxes, float *out_scores, long long *out_labels, int *out_num, void *stream) {
+    if (batch < 0 || k <= 0 || n <= 0 || post <= 0 || keep_stride < post) return LIDAR_ERR_ARG;
+    if (batch == 0) return LIDAR_OK;
+    if (!boxes || !top_scores || !top_idx || !labels || !keep || !num_keep || !out_boxes || !out_scores || !out_labels || !out_num)
+        return LIDAR_ERR_ARG;
+    hipLaunchKernelGGL(post_nms_gather_kernel, dim3((unsigned)((batch * post + 255) / 256)), dim3(256), 0, (hipStream_t)stream, boxes,
+                       top_scores, top_idx, labels, keep, num_keep, batch, k, n, keep_stride, post, out_boxes, out_scores, out_labels,
+                       out_num);
+    return lidar_check_launch("lidar_post_nms_gather");
+}

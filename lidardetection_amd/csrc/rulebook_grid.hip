@@ -13,6 +13,7 @@
 #define RG_EMPTY 0x7FFFFFFF
 
 struct RgGeom {
+    int B;                   // frames the grids were allocated for: a row whose batch index is >= B is treated like a padding row
     int D, H, W;             // input spatial shape
     int oD, oH, oW;          // output spatial shape
     int kD, kH, kW, K;
@@ -34,12 +35,12 @@ __global__ void rg_fill_kernel(int *__restrict__ grid, size_t cells) {
 // mode 0: grid[cell of row i] = min(., i) (rows of an input tensor: duplicate coordinates keep the lowest row, as the hash builder
 // does); mode 1: the same cells back to empty; mode 2: grid[cell] = i (unique output sites over the candidate ids left behind by
 // lidar_spconv_grid_outputs)
-__global__ void rg_scatter_rows_kernel(const int *__restrict__ indices, int n, const int *__restrict__ n_dev, int D, int H, int W,
+__global__ void rg_scatter_rows_kernel(const int *__restrict__ indices, int n, const int *__restrict__ n_dev, int B, int D, int H, int W,
                                        int *__restrict__ grid, int mode) {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= (n_dev ? min(*n_dev, n) : n)) return;
     const int4 c = reinterpret_cast<const int4 *>(indices)[i];
-    if (c.x < 0 || c.y < 0 || c.y >= D || c.z < 0 || c.z >= H || c.w < 0 || c.w >= W) return;      // never outside the grid
+    if (c.x < 0 || c.x >= B || c.y < 0 || c.y >= D || c.z < 0 || c.z >= H || c.w < 0 || c.w >= W) return;      // never outside the grid
     int *cell = grid + rg_cell(c.x, c.y, c.z, c.w, D, H, W);
     if (mode == 1) *cell = RG_EMPTY;
     else if (mode == 2) *cell = i;
@@ -58,7 +59,7 @@ __global__ void rg_table_kernel(const int *__restrict__ out_indices, int n_out, 
     const int4 c = reinterpret_cast<const int4 *>(out_indices)[j];
     const int z = c.y * g.sD - g.pD + kz, y = c.z * g.sH - g.pH + ky, x = c.w * g.sW - g.pW + kx;
     int r = -1;
-    if (c.x >= 0 && z >= 0 && z < g.D && y >= 0 && y < g.H && x >= 0 && x < g.W) {
+    if (c.x >= 0 && c.x < g.B && z >= 0 && z < g.D && y >= 0 && y < g.H && x >= 0 && x < g.W) {
         const int v = grid_in[rg_cell(c.x, z, y, x, g.D, g.H, g.W)];
         r = (v >= limit) ? -1 : v;
     }
@@ -82,7 +83,7 @@ __global__ void rg_table_t_kernel(const int *__restrict__ indices, int n, RgGeom
     const int i = (int)(e / g.K), k = (int)(e - (long long)i * g.K);
     const int4 c = reinterpret_cast<const int4 *>(indices)[i];
     int oz, oy, ox, r = -1;
-    if (c.x >= 0 && rg_out_of(g, c.y, c.z, c.w, k, oz, oy, ox)) {
+    if (c.x >= 0 && c.x < g.B && rg_out_of(g, c.y, c.z, c.w, k, oz, oy, ox)) {
         const int v = grid_out[rg_cell(c.x, oz, oy, ox, g.oD, g.oH, g.oW)];
         r = (v >= limit) ? -1 : v;
     }
@@ -115,7 +116,7 @@ __global__ void rg_candidates_kernel(const int *__restrict__ indices, int n, RgG
     const int i = (int)(e / g.K), k = (int)(e - (long long)i * g.K);
     const int4 c = reinterpret_cast<const int4 *>(indices)[i];
     int oz, oy, ox;
-    if (c.x >= 0 && rg_out_of(g, c.y, c.z, c.w, k, oz, oy, ox)) atomicMin(grid_out + rg_cell(c.x, oz, oy, ox, g.oD, g.oH, g.oW), (int)e);
+    if (c.x >= 0 && c.x < g.B && rg_out_of(g, c.y, c.z, c.w, k, oz, oy, ox)) atomicMin(grid_out + rg_cell(c.x, oz, oy, ox, g.oD, g.oH, g.oW), (int)e);
 }
 
 #define RG_TPB 1024
@@ -192,9 +193,9 @@ __global__ __launch_bounds__(RG_TPB) void rg_assign_kernel(const int *__restrict
 }
 
 // ------------------------------------------------------------------ C ABI
-static bool rg_geom(RgGeom &g, int D, int H, int W, int kD, int kH, int kW, int sD, int sH, int sW, int pD, int pH, int pW) {
-    if (D <= 0 || H <= 0 || W <= 0 || kD <= 0 || kH <= 0 || kW <= 0 || sD <= 0 || sH <= 0 || sW <= 0) return false;
-    g.D = D; g.H = H; g.W = W; g.kD = kD; g.kH = kH; g.kW = kW; g.K = kD * kH * kW;
+static bool rg_geom(RgGeom &g, int B, int D, int H, int W, int kD, int kH, int kW, int sD, int sH, int sW, int pD, int pH, int pW) {
+    if (B <= 0 || D <= 0 || H <= 0 || W <= 0 || kD <= 0 || kH <= 0 || kW <= 0 || sD <= 0 || sH <= 0 || sW <= 0) return false;
+    g.B = B; g.D = D; g.H = H; g.W = W; g.kD = kD; g.kH = kH; g.kW = kW; g.K = kD * kH * kW;
     g.sD = sD; g.sH = sH; g.sW = sW; g.pD = pD; g.pH = pH; g.pW = pW;
     g.oD = (D + 2 * pD - kD) / sD + 1; g.oH = (H + 2 * pH - kH) / sH + 1; g.oW = (W + 2 * pW - kW) / sW + 1;
     return g.oD > 0 && g.oH > 0 && g.oW > 0;
@@ -208,24 +209,24 @@ LIDAR_EXPORT int lidar_spconv_grid_init(int *grid, size_t cells, void *stream) {
 }
 
 // mode 0: rows -> grid (lowest row wins on duplicate coordinates); 1: the same cells back to empty; 2: rows -> grid by plain store
-// (after lidar_spconv_grid_outputs).  n_dev: optional device count (rows >= it are skipped).  The batch index of a row must be
-// smaller than the batch size the grid was allocated for (not checkable here).
-LIDAR_EXPORT int lidar_spconv_grid_rows(const int *indices, int n, const int *n_dev, int D, int H, int W, int *grid, int mode,
+// (after lidar_spconv_grid_outputs).  n_dev: optional device count (rows >= it are skipped).  batch: frames the grid was allocated
+// for — a row whose batch index is outside [0, batch) is skipped like a padding row, never an out-of-bounds store.
+LIDAR_EXPORT int lidar_spconv_grid_rows(const int *indices, int n, const int *n_dev, int batch, int D, int H, int W, int *grid, int mode,
                                         void *stream) {
-    if (n < 0 || D <= 0 || H <= 0 || W <= 0 || mode < 0 || mode > 2) return LIDAR_ERR_ARG;
+    if (n < 0 || batch <= 0 || D <= 0 || H <= 0 || W <= 0 || mode < 0 || mode > 2) return LIDAR_ERR_ARG;
     if (n == 0) return LIDAR_OK;
     if (!indices || !grid) return LIDAR_ERR_ARG;
-    hipLaunchKernelGGL(rg_scatter_rows_kernel, dim3(divup(n, 256)), dim3(256), 0, (hipStream_t)stream, indices, n, n_dev, D, H, W, grid,
-                       mode);
+    hipLaunchKernelGGL(rg_scatter_rows_kernel, dim3(divup(n, 256)), dim3(256), 0, (hipStream_t)stream, indices, n, n_dev, batch, D, H, W,
+                       grid, mode);
     return lidar_check_launch("lidar_spconv_grid_rows");
 }
 
 // forward table: SubM (stride 1, padding k / 2, out_indices = the input rows) or regular convolution; grid_in = input level
 // limit: number of rows of the tensor held by grid_in (grid values >= it read as "no row"; pass INT_MAX-like 0x7FFFFFFF for none)
-LIDAR_EXPORT int lidar_spconv_grid_table(const int *out_indices, int n_out, int D, int H, int W, int kD, int kH, int kW, int sD,
+LIDAR_EXPORT int lidar_spconv_grid_table(const int *out_indices, int n_out, int batch, int D, int H, int W, int kD, int kH, int kW, int sD,
                                          int sH, int sW, int pD, int pH, int pW, const int *grid_in, int limit, int *nbr, void *stream) {
     RgGeom g;
-    if (n_out < 0 || !rg_geom(g, D, H, W, kD, kH, kW, sD, sH, sW, pD, pH, pW)) return LIDAR_ERR_ARG;
+    if (n_out < 0 || !rg_geom(g, batch, D, H, W, kD, kH, kW, sD, sH, sW, pD, pH, pW)) return LIDAR_ERR_ARG;
     if (n_out == 0) return LIDAR_OK;
     if (!out_indices || !grid_in || !nbr) return LIDAR_ERR_ARG;
     hipLaunchKernelGGL(rg_table_kernel, dim3(divup((long long)n_out * g.K, 256)), dim3(256), 0, (hipStream_t)stream, out_indices, n_out,
@@ -234,10 +235,10 @@ LIDAR_EXPORT int lidar_spconv_grid_table(const int *out_indices, int n_out, int 
 }
 
 // transposed table nbr_t (n, K) of a regular convolution; grid_out = output level (rows scattered)
-LIDAR_EXPORT int lidar_spconv_grid_table_t(const int *indices, int n, int D, int H, int W, int kD, int kH, int kW, int sD, int sH,
+LIDAR_EXPORT int lidar_spconv_grid_table_t(const int *indices, int n, int batch, int D, int H, int W, int kD, int kH, int kW, int sD, int sH,
                                            int sW, int pD, int pH, int pW, const int *grid_out, int limit, int *nbr_t, void *stream) {
     RgGeom g;
-    if (n < 0 || !rg_geom(g, D, H, W, kD, kH, kW, sD, sH, sW, pD, pH, pW)) return LIDAR_ERR_ARG;
+    if (n < 0 || !rg_geom(g, batch, D, H, W, kD, kH, kW, sD, sH, sW, pD, pH, pW)) return LIDAR_ERR_ARG;
     if (n == 0) return LIDAR_OK;
     if (!indices || !grid_out || !nbr_t) return LIDAR_ERR_ARG;
     hipLaunchKernelGGL(rg_table_t_kernel, dim3(divup((long long)n * g.K, 256)), dim3(256), 0, (hipStream_t)stream, indices, n, g,
@@ -253,11 +254,11 @@ LIDAR_EXPORT size_t lidar_spconv_grid_outputs_workspace_bytes(int n, int K) {
 // unique output sites of SparseConv3d: out_indices (>= n * prod ceil(k / s) rows, 4) in first-touch order, *num_out (device).
 // grid_out: the OUTPUT level's grid, all empty on entry; on return it holds candidate ids — the caller reads *num_out and then
 // calls lidar_spconv_grid_rows(out_indices, ...) on it, which overwrites exactly those cells with the output rows.
-LIDAR_EXPORT int lidar_spconv_grid_outputs(const int *indices, int n, int D, int H, int W, int kD, int kH, int kW, int sD, int sH,
+LIDAR_EXPORT int lidar_spconv_grid_outputs(const int *indices, int n, int batch, int D, int H, int W, int kD, int kH, int kW, int sD, int sH,
                                            int sW, int pD, int pH, int pW, int *grid_out, int *out_indices, int *num_out, void *ws,
                                            size_t ws_bytes, void *stream) {
     RgGeom g;
-    if (n < 0 || !num_out || !rg_geom(g, D, H, W, kD, kH, kW, sD, sH, sW, pD, pH, pW)) return LIDAR_ERR_ARG;
+    if (n < 0 || !num_out || !rg_geom(g, batch, D, H, W, kD, kH, kW, sD, sH, sW, pD, pH, pW)) return LIDAR_ERR_ARG;
     hipStream_t s = (hipStream_t)stream;
     if (n == 0) return hipMemsetAsync(num_out, 0, 4, s) == hipSuccess ? LIDAR_OK : LIDAR_ERR_LAUNCH;
     if (!indices || !grid_out || !out_indices || !ws) return LIDAR_ERR_ARG;

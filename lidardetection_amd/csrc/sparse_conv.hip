@@ -19,6 +19,7 @@
 // 4 waves = 128 output rows; per offset the gathered rows (32 x Cin per wave) and W[k] (Cin x Cout, shared by
 // the workgroup) are staged in LDS; offsets with no neighbour in a wave's tile are skipped.
 #include "common.h"
+#include <stdlib.h>
 
 #define SC_EMPTY 0xFFFFFFFFFFFFFFFFull
 
@@ -602,6 +603,167 @@ __global__ __launch_bounds__(256) void sc_implicit_gemm_pipe_kernel(const float 
     }
 }
 
+// Register-A variant (r03; Cin = 4*C4*SL in {16, 32, 64, 128}, Cout % 4 == 0) — the kernel the launcher uses.
+// The MFMA's A operand wants lane (row r = lane & 31, half a = lane >> 5) to supply channel (step, a) of row r.  The
+// pipe kernel above gathers rows with coalescing lanes, transposes them through LDS (four ds_write_b32 per float4 at an odd
+// pitch) and reads them back one float per MFMA step, two barriers per offset.  Any fixed assignment of channels to
+// (step, half) gives the same products summed in a fixed order, so here half a of row r simply OWNS channels
+// [a * Cin/2, (a + 1) * Cin/2): lane (r, a) loads those Cin/2 floats of its gathered row straight into registers (contiguous
+// 128 B per lane at Cin = 64) and feeds them to the MFMAs — no LDS for A, no transpose, no cross-lane shuffles of the table
+// entries.  Only W[k] goes through LDS, double-buffered: the pieces of W[k+1] and the gathered rows of offset k+1 are in flight
+// while the MFMAs of offset k run, and ONE barrier per offset separates a buffer's last reader from its next writer.
+// Per output row the channels are accumulated in a different (but fixed) order than in the pipe kernel: results differ from
+// it in the last bits, and are bit-identical between table order and mask order as before (same kernel, same order).
+template <int NT, int C4, int SL = 1>
+__global__ __launch_bounds__(256) void sc_implicit_gemm_rega_kernel(const float *__restrict__ in, const int *__restrict__ nbr, int n_out,
+                                                                    int K, int Cout, const float *__restrict__ Wt,
+                                                                    const float *__restrict__ bias, const float *__restrict__ residual,
+                                                                    int relu, float *__restrict__ out,
+                                                                    const int *__restrict__ row_mask, const int *__restrict__ out_row) {
+    constexpr int Cin = C4 * 4, HALF = Cin / 2, CW = NT * 32, CW4 = CW / 4, CinT = Cin * SL;
+    constexpr int NG = HALF / 4;                          // float4 gathers per lane per stage
+    constexpr int NW = (Cin * CW4 + 255) / 256;           // float4 weight pieces per thread per stage
+    extern __shared__ float s_mem[];                      // W stage buffers: [2][Cin][CW]
+    const int t = threadIdx.x, l = t & 63, wv = t >> 6;
+    const int row0 = blockIdx.x * IG_ROWS + wv * 32;
+    const int ar = l & 31, ak = l >> 5;
+    const int myrow = row0 + ar;
+    const int trow = (out_row && myrow < n_out) ? out_row[myrow] : myrow;
+    const int Co4 = Cout >> 2;
+    f32x16 acc[NT];
+#pragma unroll
+    for (int q = 0; q < NT; ++q)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[q][r] = 0.f;
+    __shared__ unsigned s_wmask[4];
+    unsigned wave_mask = 0xffffffffu, wg_mask = 0xffffffffu;
+    if (row_mask) {                                       // mask-sorted tables: see the pipe kernel
+        unsigned m = (myrow < n_out) ? (unsigned)row_mask[trow] : 0u;
+#pragma unroll
+        for (int d = 1; d < 64; d <<= 1) m |= (unsigned)__shfl_xor((int)m, d, 64);
+        wave_mask = m;
+        if (l == 0) s_wmask[wv] = m;
+        __syncthreads();
+        wg_mask = s_wmask[0] | s_wmask[1] | s_wmask[2] | s_wmask[3];
+    }
+    auto next_k = [&](int k) {                            // next offset > k some row of the workgroup uses (K when none)
+        if (!row_mask) return k + 1;
+        const unsigned rest = (k + 1 < 32) ? (wg_mask >> (k + 1)) : 0u;
+        return rest ? k + 1 + __builtin_ctz(rest) : K;
+    };
+    auto load_src = [&](int k) { return (myrow < n_out && k < K) ? nbr[(size_t)trow * K + k] : -1; };
+    auto wave_uses = [&](int k, int src) { return row_mask ? ((wave_mask >> k) & 1u) != 0u : __ballot(src >= 0) != 0ull; };
+    float4 wr[NW], ga[NG], gn[NG];
+    auto fetch_w = [&](int k, int h) {
+#pragma unroll
+        for (int q = 0; q < NW; ++q) {
+            const int e = q * 256 + t, ci = e / CW4, q4 = e - ci * CW4;
+            wr[q] = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (e < Cin * CW4 && q4 < Co4) wr[q] = reinterpret_cast<const float4 *>(Wt + ((size_t)k * CinT + h * Cin + ci) * Cout)[q4];
+        }
+    };
+    auto store_w = [&](int buf) {
+        float4 *dst = reinterpret_cast<float4 *>(s_mem + (size_t)buf * Cin * CW);
+#pragma unroll
+        for (int q = 0; q < NW; ++q) {
+            const int e = q * 256 + t;
+            if (e < Cin * CW4) dst[e] = wr[q];
+        }
+    };
+    auto fetch_a = [&](float4 (&g)[NG], int h, int src, bool any) {
+        const float4 *rowp = reinterpret_cast<const float4 *>(in + (size_t)max(src, 0) * CinT + h * Cin + ak * HALF);
+#pragma unroll
+        for (int u = 0; u < NG; ++u) {
+            g[u] = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (any && src >= 0) g[u] = rowp[u];
+        }
+    };
+    int k = next_k(-1), h = 0, buf = 0;
+    if (k >= K) k = K;
+    int src_cur = load_src(k), src_ahead = -1;
+    bool any = false;
+    if (k < K) {
+        any = wave_uses(k, src_cur);
+        fetch_w(k, 0);
+        fetch_a(ga, 0, src_cur, any);
+        src_ahead = load_src(next_k(k));
+        store_w(0);
+    }
+    for (; k < K;) {
+        int kn = k, hn = h + 1;                           // the stage after this one
+        if (hn == SL) { kn = next_k(k); hn = 0; }
+        __syncthreads();                                  // W of this stage is visible; the other buffer's readers are done
+        int src_next = src_cur;
+        bool any_next = false;
+        if (kn < K) {                                     // in flight while the MFMAs below run
+            if (kn != k) {
+                src_next = src_ahead;
+                src_ahead = load_src(next_k(kn));
+            }
+            any_next = wave_uses(kn, src_next);
+            fetch_w(kn, hn);
+            fetch_a(gn, hn, src_next, any_next);
+        }
+        if (any) {
+            const float *Wb = s_mem + (size_t)buf * Cin * CW + (size_t)ak * HALF * CW + ar;
+#pragma unroll
+            for (int u = 0; u < NG; ++u) {
+                const float av[4] = {ga[u].x, ga[u].y, ga[u].z, ga[u].w};
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+#pragma unroll
+                    for (int q = 0; q < NT; ++q)
+                        acc[q] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[j], Wb[(u * 4 + j) * CW + q * 32], acc[q], 0, 0, 0);
+                }
+            }
+        }
+        if (kn < K) {
+            store_w(buf ^ 1);
+#pragma unroll
+            for (int u = 0; u < NG; ++u) ga[u] = gn[u];
+        }
+        src_cur = src_next;
+        any = any_next;
+        k = kn;
+        h = hn;
+        buf ^= 1;
+    }
+    const int last = n_out - 1;                           // n_out >= 1 (checked by the launcher)
+    // fused epilogue: (+ bias) (+ residual) (ReLU); sorted tables scatter rows (as in the pipe kernel)
+#pragma unroll
+    for (int hh = 0; hh < 2; ++hh) {
+        int orow[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            const int r = hh * 8 + j;
+            const int row = min(row0 + (r & 3) + 8 * (r >> 2) + 4 * (l >> 5), last);
+            orow[j] = out_row ? out_row[row] : row;
+        }
+#pragma unroll
+        for (int q = 0; q < NT; ++q) {
+            const int col = q * 32 + (l & 31);
+            const int cc = min(col, Cout - 1);
+            const float bv = bias ? bias[cc] : 0.f;
+            float res[8];
+#pragma unroll
+            for (int j = 0; j < 8; ++j) res[j] = 0.f;
+            if (residual) {
+#pragma unroll
+                for (int j = 0; j < 8; ++j) res[j] = residual[(size_t)orow[j] * Cout + cc];
+            }
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                const int r = hh * 8 + j;
+                const int row = row0 + (r & 3) + 8 * (r >> 2) + 4 * (l >> 5);
+                if (row < n_out && col < Cout) {
+                    const float v = acc[q][r] + bv + res[j];
+                    out[(size_t)orow[j] * Cout + col] = relu ? fmaxf(v, 0.f) : v;
+                }
+            }
+        }
+    }
+}
+
 // Input layer (Cin == 4: x, y, z, intensity means; K * 4 <= 128): all K offsets in ONE stage.  The per-offset kernels above
 // spend two barriers per offset on 2 MFMA steps of work here; this one gathers the wave's 32 x (K * 4) tile and the whole
 // (K * 4, Cout) weight once, then runs the K * 2 MFMA steps back to back.  Same operand pairs in the same order as the
@@ -706,8 +868,12 @@ static int sc_gemm_launch(const float *in_features, const int *nbr, int n_out, i
     const int cin_stage = (Cin == 128 && (Cout & 3) == 0) ? 64 : Cin;     // 128 input channels: two 64-channel stages per offset
     const size_t lds = ((size_t)cin_stage * nt * 32 + (size_t)4 * 32 * (cin_stage + 1)) * sizeof(float);
     const dim3 grid(divup(n_out, IG_ROWS));
-#define IGP(NT, C4) hipLaunchKernelGGL((sc_implicit_gemm_pipe_kernel<NT, C4>), grid, dim3(256), lds, s, in_features, nbr, n_out, K, Cout, weight, bias, residual, relu, out_features, row_mask, out_row)
-#define IGP2(NT, C4) hipLaunchKernelGGL((sc_implicit_gemm_pipe_kernel<NT, C4, 2>), grid, dim3(256), lds, s, in_features, nbr, n_out, K, Cout, weight, bias, residual, relu, out_features, row_mask, out_row)
+    static const bool use_pipe = getenv("LIDAR_SPCONV_PIPE_KERNEL") != nullptr;       // A/B switch: the r02 LDS-transposing kernel
+    const size_t lds_rega = (size_t)2 * cin_stage * nt * 32 * sizeof(float);          // two W stage buffers
+#define IGP(NT, C4) do { if (use_pipe) hipLaunchKernelGGL((sc_implicit_gemm_pipe_kernel<NT, C4>), grid, dim3(256), lds, s, in_features, nbr, n_out, K, Cout, weight, bias, residual, relu, out_features, row_mask, out_row); \
+                         else hipLaunchKernelGGL((sc_implicit_gemm_rega_kernel<NT, C4>), grid, dim3(256), lds_rega, s, in_features, nbr, n_out, K, Cout, weight, bias, residual, relu, out_features, row_mask, out_row); } while (0)
+#define IGP2(NT, C4) do { if (use_pipe) hipLaunchKernelGGL((sc_implicit_gemm_pipe_kernel<NT, C4, 2>), grid, dim3(256), lds, s, in_features, nbr, n_out, K, Cout, weight, bias, residual, relu, out_features, row_mask, out_row); \
+                          else hipLaunchKernelGGL((sc_implicit_gemm_rega_kernel<NT, C4, 2>), grid, dim3(256), lds_rega, s, in_features, nbr, n_out, K, Cout, weight, bias, residual, relu, out_features, row_mask, out_row); } while (0)
     const bool pipe = (Cout & 3) == 0 && (Cin == 16 || Cin == 32 || Cin == 64 || Cin == 128);
     if ((row_mask || out_row) && (!pipe || K > 32 || !row_mask || !out_row)) return LIDAR_ERR_ARG;
     if (pipe) {
@@ -833,7 +999,15 @@ __global__ void mg_init_kernel(MgWs w) {
     }
 }
 
-__device__ __forceinline__ int mg_bin(unsigned m, int K) { return (int)(K > MG_BIN_BITS ? (m >> (K - MG_BIN_BITS)) : m); }
+// group order along the GEMM's launch order: HEAVY masks first (a workgroup's time is proportional to the offsets its rows use, and
+// the hardware deals workgroups in launch order: with the heavy ones last, the launch ends on a long tail of half-empty CUs — measured
+// on the SECOND stack: offsets per workgroup 8 -> 19 along the r02 order (ascending top 12 mask bits), 19 -> 5 along this one),
+// similar masks next to each other inside a weight class: bin = (K - popcount) : 5 bits | top 7 mask bits.  Measured (SECOND stack,
+// register-A kernel): r02 order 2.141 ms, r02 order dealt back to front 2.041, this 2.025, 3 weight bits + 9 mask bits 2.084.
+__device__ __forceinline__ int mg_bin(unsigned m, int K) {
+    const unsigned top = K > 7 ? (m >> (K - 7)) : m;
+    return (int)((((unsigned)K - (unsigned)__popc(m)) & 31u) << 7 | (top & 127u));
+}
 
 // masks of 1024 consecutive rows (as sc_row_masks_kernel), then every row finds / claims the group of its mask and a rank in it.
 // Global atomics on a group / bin counter serialise at the L2 (~10 ns each on one address), and 40 % of a table's rows can carry

@@ -192,19 +192,30 @@ class PointPillarKITTI(nn.Module):
         return self.post_process_torch(*heads)
 
     def select_topk(self, masked, k):
-        """(B, N) masked scores -> the k best per frame, sorted descending: (scores (B, k), anchor indices (B, k))"""
+        """(B, N) masked scores (-1 below SCORE_THRESH) -> the k best per frame, sorted descending: (scores (B, k), anchor indices
+        (B, k)).  The HIP selection (csrc/topk.hip) breaks ties by ascending anchor index; torch.topk where it does not apply."""
+        if masked.is_cuda and anchor_post.topk_supported(masked.shape[1], k):
+            return anchor_post.topk_desc(masked, k, self.score_thresh)[:2]
         return torch.topk(masked, k, dim=1)
 
     def post_process_fused(self, head):
         a = self.num_anchor_per_loc
-        masked, labels_all = anchor_post.anchor_scores(head, a, self.num_class, self.score_thresh, cls_off=0)
-        k = min(self.nms_pre, masked.shape[1])
-        top_scores, top_idx = self.select_topk(masked, k)             # sorted descending == nms_gpu's sort
-        counts = (top_scores >= self.score_thresh).sum(dim=1).to(torch.int32)
+        n = head.shape[1] * head.shape[2] * a if head.dim() == 4 else head.shape[1] * a
+        k = min(self.nms_pre, n)
+        if anchor_post.topk_supported(n, k):   # scores + histogram, collect, finalize: 3 launches, ties by ascending anchor index
+            ws = anchor_post.topk_workspace(head.shape[0], n, head.device)
+            masked, labels_all = anchor_post.anchor_scores(head, a, self.num_class, self.score_thresh, cls_off=0, topk_ws=ws)
+            top_scores, top_idx, counts = anchor_post.topk_desc(masked, k, self.score_thresh, ws, hist_ready=True)
+        else:
+            masked, labels_all = anchor_post.anchor_scores(head, a, self.num_class, self.score_thresh, cls_off=0)
+            top_scores, top_idx = torch.topk(masked, k, dim=1)        # sorted descending == nms_gpu's sort
+            counts = (top_scores >= self.score_thresh).sum(dim=1).to(torch.int32)
         boxes = anchor_post.decode_topk(head, top_idx, self.anchors, a, box_off=a * self.num_class,
                                         dir_off=a * (self.num_class + 7), num_dir_bins=self.num_dir_bins,
                                         dir_offset=self.dir_offset, dir_limit_offset=self.dir_limit_offset)
-        return self._nms_and_gather(boxes, top_scores, top_idx, labels_all, counts, k)
+        post = min(self.nms_post, k)
+        keep, num = iou3d_nms_cuda.nms_batch(boxes, counts, self.nms_thresh, max_keep=post)   # survivors past `post` are dropped anyway
+        return anchor_post.post_nms_gather(boxes, top_scores, top_idx, labels_all, keep, num, post)   # one launch (was 13 torch kernels)
 
     def post_process_torch(self, cls, box, dirs):
         scores_all, labels_all = torch.sigmoid(cls).max(dim=-1)

@@ -247,6 +247,12 @@ def _run_stages_pipelined(stages, x):
             torch.cuda.set_stream(rb)
             if built < len(stages):
                 build_next()
+    except BaseException:
+        # a forward abandoned half-way (OOM in a stage, KeyboardInterrupt, LidarHipError) can leave candidate ids in an output-level
+        # grid that no wipe will ever visit: forget the grids, new ones are initialised on demand
+        torch.cuda.set_stream(feat)
+        ops.GRIDS.reset()
+        raise
     finally:
         torch.cuda.set_stream(feat)
     return outs

@@ -31,10 +31,11 @@ class GridPool:
     forward (`token`, kept in the rulebook dict), so a level's grid is scattered once and then serves the SubM table of the level,
     the strided convolution leaving it and the one entering it.  Levels too large for the budget fall back to the hash builder."""
     MAX_BYTES_PER_GRID = int(__import__("os").environ.get("LIDAR_SPCONV_GRID_MAX_GB", "8")) << 30
+    MAX_TOTAL_BYTES = int(__import__("os").environ.get("LIDAR_SPCONV_GRID_TOTAL_GB", "64")) << 30     # all grids of the pool together
     ENABLED = __import__("os").environ.get("LIDAR_SPCONV_GRID", "1") != "0"
 
     def __init__(self):
-        self.grids = {}        # (device, B, D, H, W) -> [grid, held coords copy or None, n held, token, stream event]
+        self.grids = {}        # (device, B, D, H, W) -> [grid, held coords copy or None, n held, token, stream event, B, last use]
         self.counter = 0
 
     def new_token(self):
@@ -58,16 +59,32 @@ class GridPool:
         torch.cuda.synchronize()
         self.grids.clear()
 
+    def _evict_for(self, nbytes):
+        """least-recently-used grids that hold no rows make room for a new one (another batch size or resolution: the last
+        partial eval batch, a bs-1 demo after bs-16): the pool never grows past MAX_TOTAL_BYTES.  Rare: waits for the device."""
+        total = sum(e[0].numel() * 4 for e in self.grids.values())
+        if total + nbytes <= self.MAX_TOTAL_BYTES:
+            return
+        torch.cuda.synchronize()                 # a grid may still be in use on any stream
+        for key in sorted((k for k, e in self.grids.items() if e[2] == 0), key=lambda k: self.grids[k][6]):
+            total -= self.grids.pop(key)[0].numel() * 4
+            if total + nbytes <= self.MAX_TOTAL_BYTES:
+                break
+
     def _entry(self, device, batch, shape):
         key = (str(device), int(batch), *[int(v) for v in shape])
         ent = self.grids.get(key)
+        self.counter += 1
+        if ent is not None:
+            ent[6] = self.counter                # last use (LRU)
         if ent is None:
             cells = int(batch) * int(shape[0]) * int(shape[1]) * int(shape[2])
             if not self.ENABLED or cells * 4 > self.MAX_BYTES_PER_GRID or cells <= 0:
                 return None
+            self._evict_for(cells * 4)
             grid = torch.empty(cells, dtype=torch.int32, device=device)
             _lib.check(_lib.lib().lidar_spconv_grid_init(_lib.ptr(grid), cells, _lib.stream()), "lidar_spconv_grid_init")
-            ent = self.grids[key] = [grid, None, 0, None, None]
+            ent = self.grids[key] = [grid, None, 0, None, None, int(batch), self.counter]
         return ent
 
     @staticmethod
@@ -85,11 +102,13 @@ class GridPool:
 
     def _rows(self, ent, coords, n, shape, mode):
         D, H, W = shape
-        _lib.check(_lib.lib().lidar_spconv_grid_rows(_lib.ptr(coords), n, None, D, H, W, _lib.ptr(ent[0]), mode, _lib.stream()),
+        _lib.check(_lib.lib().lidar_spconv_grid_rows(_lib.ptr(coords), n, None, ent[5], D, H, W, _lib.ptr(ent[0]), mode, _lib.stream()),
                    "lidar_spconv_grid_rows")
 
     def _wipe(self, ent, shape):
         if ent[1] is not None and ent[2] > 0:
+            if ent[1].is_cuda:
+                ent[1].record_stream(torch.cuda.current_stream(ent[1].device))     # allocated on another stream, released right after
             self._rows(ent, ent[1], ent[2], shape, 1)
         ent[1], ent[2], ent[3] = None, 0, None
 
@@ -102,6 +121,7 @@ class GridPool:
         if ent[3] != (token, indices.data_ptr(), indices.shape[0]):
             self._wipe(ent, shape)
             keep = indices.clone()                                      # the cells written, for the wipe: never the caller's buffer
+            keep.record_stream(torch.cuda.current_stream(keep.device))  # (and whichever stream wipes it later: _wipe records that one)
             self._rows(ent, keep, keep.shape[0], shape, 0)
             ent[1], ent[2], ent[3] = keep, keep.shape[0], (token, indices.data_ptr(), indices.shape[0])
         self._mark(ent)
@@ -155,7 +175,7 @@ def subm_rulebook(indices, spatial_shape, ksize, batch_size=None, indice_dict=No
     grid = GRIDS.loaded(indices, batch_size, spatial_shape, _grid_token(indice_dict)) if batch_size else None
     if grid is not None:
         pad = [k // 2 for k in ksize]
-        _lib.check(_lib.lib().lidar_spconv_grid_table(_lib.ptr(indices), n, *_geom_args(spatial_shape, ksize, (1, 1, 1), pad),
+        _lib.check(_lib.lib().lidar_spconv_grid_table(_lib.ptr(indices), n, int(batch_size), *_geom_args(spatial_shape, ksize, (1, 1, 1), pad),
                                                       _lib.ptr(grid), n, _lib.ptr(nbr), _lib.stream()), "lidar_spconv_grid_table")
         return nbr
     table, cap = _hash_table(indices, spatial_shape)
@@ -208,7 +228,7 @@ def conv_rulebook_begin(indices, batch_size, spatial_shape, ksize, stride, paddi
     if gin is not None and gout is not None and n * K <= 0x3FFFFFFF:
         wsb = L.lidar_spconv_grid_outputs_workspace_bytes(n, K)
         ws = torch.empty(wsb, dtype=torch.uint8, device=dev)
-        _lib.check(L.lidar_spconv_grid_outputs(_lib.ptr(indices), n, *_geom_args(spatial_shape, ksize, stride, padding), _lib.ptr(gout[0]),
+        _lib.check(L.lidar_spconv_grid_outputs(_lib.ptr(indices), n, int(batch_size), *_geom_args(spatial_shape, ksize, stride, padding), _lib.ptr(gout[0]),
                                                _lib.ptr(out_idx), _lib.ptr(num), _lib.ptr(ws), wsb, _lib.stream()),
                    "lidar_spconv_grid_outputs")
         GridPool._mark(gout)
@@ -255,8 +275,8 @@ def _finish_speculative(st, spec, need_t):
     L = _lib.lib()
     out_indices = st["out_idx"][:cap]                                   # a view of this rulebook's own buffer
     _lib.check(L.lidar_spconv_grid_pad_rows(_lib.ptr(out_indices), _lib.ptr(st["num"]), cap, _lib.stream()), "lidar_spconv_grid_pad_rows")
-    gin, gout, token, _ = st["grid"]
-    geom = _geom_args(st["shape"], st["ksize"], st["stride"], st["padding"])
+    gin, gout, token, bsz = st["grid"]
+    geom = [int(bsz)] + _geom_args(st["shape"], st["ksize"], st["stride"], st["padding"])
     go = GRIDS.adopt_outputs(gout, out_indices, st["out_shape"], token)
     nbr = torch.empty((cap, K), dtype=torch.int32, device=dev)
     _lib.check(L.lidar_spconv_grid_table(_lib.ptr(out_indices), cap, *geom, _lib.ptr(gin), n, _lib.ptr(nbr), _lib.stream()),
@@ -316,8 +336,8 @@ def conv_rulebook_finish(st, spec=None, need_t=True):
     out_indices = st["out_idx"][:n_out].clone()
     L = _lib.lib()
     if st["grid"] is not None:
-        gin, gout, token, _ = st["grid"]
-        geom = _geom_args(st["shape"], st["ksize"], st["stride"], st["padding"])
+        gin, gout, token, bsz = st["grid"]
+        geom = [int(bsz)] + _geom_args(st["shape"], st["ksize"], st["stride"], st["padding"])
         go = GRIDS.adopt_outputs(gout, out_indices, st["out_shape"], token)       # the output level's grid: rows instead of candidates
         _lib.check(L.lidar_spconv_grid_table(_lib.ptr(out_indices), n_out, *geom, _lib.ptr(gin), n, _lib.ptr(nbr), _lib.stream()),
                    "lidar_spconv_grid_table")
@@ -346,7 +366,11 @@ def ensure_table_t(datas):
 
 def conv_rulebook(indices, batch_size, spatial_shape, ksize, stride, padding, indice_dict=None):
     """-> out_indices (N_out, 4) int32, nbr (N_out, K), nbr_t (N_in, K).  One host read-back (N_out)."""
-    return conv_rulebook_finish(conv_rulebook_begin(indices, batch_size, spatial_shape, ksize, stride, padding, indice_dict))
+    try:
+        return conv_rulebook_finish(conv_rulebook_begin(indices, batch_size, spatial_shape, ksize, stride, padding, indice_dict))
+    except BaseException:
+        GRIDS.reset()          # between begin and finish the output level's grid holds candidate ids no wipe would visit
+        raise
 
 
 def cached_mask_order(datas, key, table):
@@ -385,6 +409,7 @@ def sorted_gemm_supported(K, Cin, Cout):
 
 
 _MG_WS = {}
+_MG_RETIRED = []             # (workspace, event on its stream): regrown workspaces stay alive until their stream has passed the event
 
 
 def _mask_group_workspace(n, device, stream):
@@ -395,6 +420,12 @@ def _mask_group_workspace(n, device, stream):
     key = (device.index, int(stream.value or 0))
     ws = _MG_WS.get(key)
     if ws is None or ws.numel() < need:
+        old = _MG_WS.get(key)
+        if old is not None:                       # kernels on the side stream may still be using it: keep it alive until they are done
+            _MG_RETIRED.append((old, torch.cuda.Event()))
+            _MG_RETIRED[-1][1].record(torch.cuda.ExternalStream(int(stream.value or 0), device=device))
+            while _MG_RETIRED and _MG_RETIRED[0][1].query():
+                _MG_RETIRED.pop(0)
         ws = torch.empty(need + need // 4, dtype=torch.uint8, device=device)
         _lib.check(L.lidar_spconv_mask_group_init(_lib.ptr(ws), ws.numel(), stream), "lidar_spconv_mask_group_init")
         _MG_WS[key] = ws

@@ -87,6 +87,36 @@ def sparse_conv(feats, idx, shape, weight, bias, ksize, stride, padding):
     return out, out_idx, osz, n_k
 
 
+def inverse_conv(feats_small, idx_small, shape_small, idx_orig, shape_orig, weight, bias, ksize, stride, padding):
+    """SparseInverseConv3d (Appendix A.3; reference call sites pcdet/models/backbones_3d/spconv_unet.py:113-123): the paired
+    SparseConv3d's rulebook with inputs and outputs swapped — for every pair (k, i -> o) of that convolution (o = (i + p - k) / s
+    integral and in bounds), out[i] += feats_small[o] @ W[k]; outputs are the paired convolution's INPUT sites idx_orig (N, 4), in
+    that row order.  feats_small (M, Cin) follows idx_small (M, 4) — any order; weight (kD, kH, kW, Cin, Cout).  -> (N, Cout) f64."""
+    feats_small = np.asarray(feats_small, np.float64)
+    idx_orig = np.asarray(idx_orig, np.int64)
+    w = np.asarray(weight, np.float64).reshape(-1, weight.shape[-2], weight.shape[-1])
+    skeys = _keys(idx_small, shape_small)
+    order = np.argsort(skeys, kind="stable")
+    skeys = skeys[order]
+    s = np.asarray(stride, np.int64)
+    out = np.zeros((idx_orig.shape[0], w.shape[2]), np.float64)
+    for k, off in enumerate(_offsets(ksize)):
+        t = idx_orig[:, 1:] + np.asarray(padding, np.int64) - np.asarray(off, np.int64)
+        ok = np.all((t >= 0) & (t % s == 0), axis=1)
+        o = t // s
+        ok &= np.all(o < np.asarray(shape_small, np.int64), axis=1)
+        rows_i = np.nonzero(ok)[0]
+        okeys = _keys(np.concatenate([idx_orig[rows_i, :1], o[rows_i]], axis=1), shape_small)
+        pos = np.searchsorted(skeys, okeys)
+        pos[pos >= skeys.size] = 0
+        hit = skeys[pos] == okeys                       # (every such o IS an output site of the paired conv; kept for safety)
+        if hit.any():
+            out[rows_i[hit]] += feats_small[order[pos[hit]]] @ w[k]
+    if bias is not None:
+        out += np.asarray(bias, np.float64)
+    return out
+
+
 def batchnorm_eval(x, weight, bias, mean, var, eps):
     return (x - np.asarray(mean, np.float64)) / np.sqrt(np.asarray(var, np.float64) + eps) * np.asarray(weight, np.float64) \
         + np.asarray(bias, np.float64)

@@ -13,8 +13,9 @@ step, on the buffers the model itself holds:
     SCORE_THRESH mask -> top-k (NMS_PRE_MAXSIZE) -> ResidualCoder decode + direction bins -> rotated NMS (C oracle) -> first
     NMS_POST_MAXSIZE (pcdet/models/detectors/detector3d_template.py:169-275, model_nms_utils.py:6-25).
 Top-k ties: an empty BEV region gives thousands of bit-equal scores, and the reference's torch.topk leaves the order among equal
-scores unspecified.  The test therefore checks the selection as a SET with the complete characterisation of a valid top-k (every
-score above the k-th selected, the rest equal to it, no duplicates, sorted) and replays decode + NMS on the device's own order."""
+scores unspecified.  The test checks the selection with the complete characterisation of a valid top-k (every score above the k-th
+selected, the rest equal to it, no duplicates, sorted) AND against the rule this repo's selection follows (csrc/topk.hip: ties by
+ascending anchor index = a stable CPU sort), then replays decode + NMS on that order."""
 import numpy as np
 import pytest
 import torch
@@ -81,13 +82,22 @@ def _check_post(m, head, out, tag):
     top_scores, top_idx = m.select_topk(got_masked, k)
     ties = 0
     for f in range(m.B):
-        s, i = top_scores[f], top_idx[f].long()
+        c = int((top_scores[f] >= m.score_thresh).sum())                 # valid entries (slots past them hold (-1, 0))
+        assert c == min(k, int((masked[f] >= m.score_thresh).sum())), f"{tag} frame {f}: number of candidates"
+        s, i = top_scores[f][:c], top_idx[f][:c].long()
         assert torch.equal(masked[f][i], s), f"{tag} frame {f}: reported scores are not the scores of the reported anchors"
         assert bool((s[:-1] >= s[1:]).all()), f"{tag} frame {f}: top-k not sorted"
-        assert int(torch.unique(i).numel()) == k, f"{tag} frame {f}: duplicate anchors in the top-k"
-        kth = s[-1]
-        assert int((masked[f] > kth).sum()) == int((s > kth).sum()), f"{tag} frame {f}: a score above the k-th was left out"
-        ties += int((masked[f] == kth).sum()) - int((s == kth).sum())
+        assert int(torch.unique(i).numel()) == c, f"{tag} frame {f}: duplicate anchors in the top-k"
+        if c == k:
+            kth = s[-1]
+            assert int((masked[f] > kth).sum()) == int((s > kth).sum()), f"{tag} frame {f}: a score above the k-th was left out"
+            ties += int((masked[f] == kth).sum()) - int((s == kth).sum())
+    # the HIP selection is deterministic: (score desc, anchor index asc) — exactly a stable CPU sort of the candidates
+    mc = masked.cpu().numpy()
+    for f in range(m.B):
+        valid = np.nonzero(mc[f] >= np.float32(m.score_thresh))[0]
+        order = valid[np.lexsort((valid, -mc[f][valid].astype(np.float64)))][:k]
+        assert np.array_equal(top_idx[f, :len(order)].cpu().numpy(), order), f"{tag} frame {f}: top-k order (ties by ascending index)"
     counts = (top_scores >= m.score_thresh).sum(dim=1)
     gi = top_idx.long().unsqueeze(-1)
     boxes = m.decode(torch.gather(box, 1, gi.expand(-1, -1, 7)), m.anchors[top_idx.long()],

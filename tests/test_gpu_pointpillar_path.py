@@ -434,10 +434,80 @@ def test_fused_anchor_post_processing_matches_torch_ops(dev):
         got_boxes = anchor_post.decode_topk(head, top_idx, m.anchors, a, a * m.num_class, a * (m.num_class + 7),
                                             m.num_dir_bins, m.dir_offset, m.dir_limit_offset)
         assert torch.equal(got_boxes, want_boxes)
+        # the HIP top-k (scores + histogram, collect, finalize) selects what torch.topk selects — and in the same order where
+        # scores are distinct; among equal scores the lower anchor index comes first (torch leaves that unspecified)
+        ws = anchor_post.topk_workspace(2, want_masked.shape[1], dev)
+        m2, l2 = anchor_post.anchor_scores(head, a, m.num_class, m.score_thresh, topk_ws=ws)
+        assert torch.equal(m2, want_masked) and torch.equal(l2, got_labels)
+        hs, hi, hc = anchor_post.topk_desc(m2, k, m.score_thresh, ws, hist_ready=True)
+        ts_o, ti_o, cnt_o = _topk_reference(want_masked.cpu().numpy(), k, m.score_thresh)
+        assert np.array_equal(hs.cpu().numpy(), ts_o) and np.array_equal(hi.cpu().numpy(), ti_o) and np.array_equal(hc.cpu().numpy(), cnt_o)
+        assert torch.equal(hs, top_scores)
+        distinct = torch.ones_like(top_scores, dtype=torch.bool)
+        distinct[:, 1:] &= top_scores[:, 1:] != top_scores[:, :-1]
+        distinct[:, :-1] &= top_scores[:, 1:] != top_scores[:, :-1]
+        assert torch.equal(hi[distinct], top_idx[distinct])
         fused = m.post_process(head)
-        plain = m.post_process(cls, box, dirs)
+    # final detections: the reference's op sequence on the HIP selection (ties resolved by index)
+    with torch.no_grad():
+        gi2 = hi.unsqueeze(-1)
+        boxes2 = m.decode(torch.gather(box, 1, gi2.expand(-1, -1, 7)), m.anchors[hi], torch.gather(dirs, 1, gi2.expand(-1, -1, m.num_dir_bins))).contiguous()
+        plain = m._nms_and_gather(boxes2, hs, hi, labels_all, hc, k)
     for x, y in zip(fused, plain):
         assert torch.equal(x, y)
+
+
+def _topk_reference(scores, k, valid_min):
+    """(score desc, index asc) over the scores >= valid_min; slots past the valid count are (-1, 0)"""
+    B, n = scores.shape
+    ts, ti, cnt = np.full((B, k), -1.0, np.float32), np.zeros((B, k), np.int64), np.zeros(B, np.int32)
+    for b in range(B):
+        valid = np.nonzero(scores[b] >= np.float32(valid_min))[0]
+        order = valid[np.lexsort((valid, -scores[b][valid].astype(np.float64)))][:k]
+        ts[b, :len(order)], ti[b, :len(order)], cnt[b] = scores[b][order], order, len(order)
+    return ts, ti, cnt
+
+
+@pytest.mark.parametrize("case", ["distinct", "quantised", "tie_mass", "tie_mass_plus", "few_valid", "none_valid", "big_bin_distinct", "small_k"])
+def test_topk_desc_exact_deterministic_with_ties(dev, case):
+    """lidar_topk_desc (csrc/topk.hip) against a stable CPU sort: descending score, ties by ascending index — the rule is
+    checked on tens of thousands of bit-equal scores (empty BEV regions), on a bin of > 8 192 DISTINCT keys around the k-th score
+    (the radix-select path), with fewer valid scores than k, with none, and for k < 4096; torch.topk agrees wherever scores are
+    distinct."""
+    from lidardetection_amd import anchor_post
+    r = np.random.default_rng(hash(case) % 1000)
+    B, n, k, thr = 3, 321408, 4096, 0.1
+    s = r.uniform(0.0, 1.0, (B, n)).astype(np.float32)
+    if case == "quantised":
+        s = (np.round(s * 200) / 200).astype(np.float32)                       # ~1 600 equal scores per level
+    elif case == "tie_mass":
+        s[:] = np.float32(0.3)                                                  # every score equal
+    elif case == "tie_mass_plus":
+        s = np.where(r.uniform(size=(B, n)) < 0.01, s * 0.5 + 0.5, np.float32(0.47)).astype(np.float32)   # 3 200 above one tie mass of 318 k
+    elif case == "few_valid":
+        s[:, 1000:] *= np.float32(0.05)                                         # 1 000 candidates, the rest below the threshold
+    elif case == "none_valid":
+        s *= np.float32(0.09)
+    elif case == "big_bin_distinct":
+        base = np.float32(0.5).view(np.uint32)
+        d = (base + r.permutation(12000).astype(np.uint32)).view(np.float32)     # 12 000 distinct scores inside ONE histogram bin
+        s[:] = np.float32(0.2) * s                                              # everything else far below (most under the threshold)
+        for b in range(B):
+            s[b, r.choice(n, 12000, replace=False)] = d
+        s[:, :500] = np.float32(0.9) + np.float32(1e-4) * r.uniform(size=(B, 500)).astype(np.float32)   # and 500 clearly above
+    elif case == "small_k":
+        k = 1000
+    s[s < thr] = -1.0                                                           # as anchor_scores masks them
+    ts_o, ti_o, cnt_o = _topk_reference(s, k, thr)
+    td = torch.from_numpy(s).to(dev)
+    for _ in range(2):                                                          # twice: the workspace cleans up after itself
+        ts, ti, cnt = anchor_post.topk_desc(td, k, thr)
+        assert np.array_equal(cnt.cpu().numpy(), cnt_o), case
+        assert np.array_equal(ts.cpu().numpy(), ts_o), case
+        assert np.array_equal(ti.cpu().numpy(), ti_o), case
+    if case == "distinct":
+        tt, it = torch.topk(td, k, dim=1)
+        assert torch.equal(tt, ts) and torch.equal(it, ti)
 
 
 def test_nms_batch_max_keep_is_a_prefix_of_the_full_result(dev):

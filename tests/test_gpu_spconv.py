@@ -283,8 +283,9 @@ def test_wgrad_mfma_matches_float64_and_the_scalar_kernel(dev, cin, cout, n_out,
 
 def test_mask_order_groups_equal_masks_bins_ascending(dev):
     """lidar_spconv_mask_group (hand-written: order-preserving hash of the distinct masks + scan + scatter, no sort): the masks are
-    exact, the order is a permutation, every distinct mask forms exactly ONE contiguous run, and the runs come in ascending
-    order of their top 12 mask bits (the grouping the mask-ordered GEMM needs: tools/group_order_probe.py).  Random tables (up to 150 k DISTINCT masks: far
+    exact, the order is a permutation, every distinct mask forms exactly ONE contiguous run, and the runs come HEAVY first —
+    ascending (K - popcount, top 7 mask bits): the workgroups with the most offsets are dealt first, similar masks stay
+    together (the grouping the mask-ordered GEMM needs: tools/group_order_probe.py, tools/mask_pop_probe.py).  Random tables (up to 150 k DISTINCT masks: far
     more than real rulebooks hold), a table dominated by one mask (atomic contention), tiny K, repeated calls on one workspace."""
     from lidardetection_amd.spconv import ops
     g = torch.Generator().manual_seed(5)
@@ -302,7 +303,10 @@ def test_mask_order_groups_equal_masks_bins_ascending(dev):
         seq = want[o]
         runs = int((seq[1:] != seq[:-1]).sum()) + 1 if n else 0
         assert runs == torch.unique(want).numel(), (n, K, "a mask is split over several runs")
-        top = seq >> max(K - 12, 0)
+        pop = torch.zeros_like(seq)
+        for k in range(K):
+            pop += (seq >> k) & 1
+        top = (((K - pop) & 31) << 7) | ((seq >> max(K - 7, 0)) & 127)
         assert bool((top[1:] >= top[:-1]).all()), (n, K)
     m0, o0 = ops.mask_order(torch.empty((0, 27), dtype=torch.int32, device=dev))
     assert m0.numel() == 0 and o0.numel() == 0
@@ -528,3 +532,47 @@ def test_graphed_forward_equals_eager_forward(dev):
     with torch.no_grad():
         out = m({"voxel_features": cases[0][0], "voxel_coords": cases[0][1], "batch_size": B})
     same([out["encoded_spconv_tensor"]], [eager(*cases[0])[-1]])
+
+
+def test_grid_rows_with_a_batch_index_outside_the_grid_are_padding_rows(dev):
+    """a coordinate row whose batch index is >= the batch size the grids were allocated for (stale / too small
+    batch_size) used to index past the grid.  It is now skipped like a padding row: no neighbours, reaches no output, and every
+    other row's tables are what they are without it."""
+    from lidardetection_amd.spconv import ops
+    B, shape = 2, [9, 14, 16]
+    idx = _sites(21, B, shape, 400)
+    bad = np.array([[B + 3, 1, 2, 3], [B, 0, 0, 0]], np.int32)
+    good = torch.from_numpy(idx).to(dev)
+    both = torch.from_numpy(np.concatenate([idx, bad], 0)).to(dev)
+    sub_g = ops.subm_rulebook(good, shape, [3, 3, 3], B, {})
+    sub_b = ops.subm_rulebook(both, shape, [3, 3, 3], B, {})
+    assert torch.equal(sub_b[:len(idx)], sub_g) and bool((sub_b[len(idx):] == -1).all())
+    og, ng, tg = ops.conv_rulebook(good, B, shape, [3, 3, 3], [2, 2, 2], [1, 1, 1], {})
+    ob, nb, tb = ops.conv_rulebook(both, B, shape, [3, 3, 3], [2, 2, 2], [1, 1, 1], {})
+    assert torch.equal(ob, og) and torch.equal(nb, ng)
+    assert torch.equal(tb[:len(idx)], tg) and bool((tb[len(idx):] == -1).all())
+
+
+def test_grid_pool_budget_evicts_least_recently_used_grids(dev):
+    """the pool used to keep one grid per (batch, shape) forever.  With a total budget, grids that hold no rows are
+    evicted least-recently-used first, and rulebooks built afterwards are unchanged."""
+    from lidardetection_amd.spconv import ops
+    keep = ops.GridPool.MAX_TOTAL_BYTES
+    ops.GRIDS.reset()
+    shapes = [[8, 10 + k, 12] for k in range(6)]
+    cells = lambda s: 2 * s[0] * s[1] * s[2] * 4
+    ops.GridPool.MAX_TOTAL_BYTES = cells(shapes[-1]) * 3 + 64
+    try:
+        want = {}
+        for s_ in shapes:
+            c = torch.from_numpy(_sites(5, 2, s_, 150)).to(dev)
+            want[tuple(s_)] = (c, ops.subm_rulebook(c, s_, [3, 3, 3], 2, {}))
+            ops.GRIDS.wipe_all()                                    # (a finished forward leaves nothing behind)
+            assert sum(e[0].numel() * 4 for e in ops.GRIDS.grids.values()) <= ops.GridPool.MAX_TOTAL_BYTES
+        assert len(ops.GRIDS.grids) <= 3 and (str(dev), 2, *shapes[-1]) in ops.GRIDS.grids and (str(dev), 2, *shapes[0]) not in ops.GRIDS.grids
+        for s_, (c, nbr) in want.items():                           # evicted levels are simply rebuilt
+            assert torch.equal(ops.subm_rulebook(c, list(s_), [3, 3, 3], 2, {}), nbr)
+            ops.GRIDS.wipe_all()
+    finally:
+        ops.GridPool.MAX_TOTAL_BYTES = keep
+        ops.GRIDS.reset()

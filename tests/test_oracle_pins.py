@@ -159,3 +159,27 @@ def test_sparse_oracle_equals_dense_conv_oracle(ksize, stride, padding, subm):
         want = so.conv_features(feats, idx, B, shape, w, bias, list(ksize), list(stride), list(padding), False, np.array(outs)).numpy()
     assert n_k == counts.tolist()
     np.testing.assert_allclose(got, want, rtol=0, atol=1e-12)
+
+
+@pytest.mark.parametrize("ksize,stride,padding", [((3, 3, 3), (2, 2, 2), (1, 1, 1)), ((3, 3, 3), (2, 2, 2), (0, 1, 1)), ((3, 1, 1), (2, 1, 1), (0, 0, 0))])
+def test_sparse_inverse_conv_oracle_equals_dense_transposed_conv_oracle(ksize, stride, padding):
+    """spconv_sparse_oracle.inverse_conv (the paired convolution's pairs, swapped) against the dense conv_transpose3d oracle
+    (oracle/spconv_oracle.py: inverse_conv_features) on a grid small enough to densify."""
+    from oracle import spconv_oracle as so, spconv_sparse_oracle as sp
+    r = np.random.default_rng(17)
+    shape, B, cin, cout = [9, 12, 10], 2, 6, 5
+    cells = shape[0] * shape[1] * shape[2]
+    pick = np.concatenate([np.sort(r.choice(cells, 170, replace=False)) + b * cells for b in range(B)])
+    b_, rem = np.divmod(pick, cells)
+    z, rem = np.divmod(rem, shape[1] * shape[2])
+    y, x = np.divmod(rem, shape[2])
+    idx = np.stack([b_, z, y, x], 1).astype(np.int64)[r.permutation(len(pick))]
+    _, oidx, oshape, _ = sp.sparse_conv(r.standard_normal((len(idx), 3)), idx, shape, r.standard_normal((*ksize, 3, 4)), None,
+                                        list(ksize), list(stride), list(padding))
+    oidx = oidx[r.permutation(len(oidx))]                  # the small tensor's rows in any order
+    feats = r.standard_normal((len(oidx), cin))
+    w = r.standard_normal((*ksize, cin, cout))
+    bias = r.standard_normal(cout)
+    got = sp.inverse_conv(feats, oidx, oshape, idx, shape, w, bias, list(ksize), list(stride), list(padding))
+    want = so.inverse_conv_features(feats, oidx, B, oshape, w, bias, list(ksize), list(stride), list(padding), idx, shape).numpy()
+    np.testing.assert_allclose(got, want, rtol=0, atol=1e-12)
