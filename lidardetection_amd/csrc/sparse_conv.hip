@@ -208,8 +208,8 @@ __global__ void sc_fill_tables_kernel(const int *__restrict__ cand_slot, const i
     if (s >= 0) {
         j = out_row[s];
         const int i = (int)(e / K), k = (int)(e - (long long)i * K);
-        nbr[(size_t)j * K + k] = i;
-    }
+        atomicMin(reinterpret_cast<unsigned *>(nbr) + (size_t)j * K + k, (unsigned)i);   // duplicate input coordinates: the lowest row
+    }                                                                                      // (the table arrives filled with -1)
     if (nbr_t) nbr_t[e] = j;
 }
 

@@ -120,7 +120,7 @@ static size_t vx_carve(void *base, int B, int n_max, int max_voxels, VxWs *w) {
     p = take((size_t)B * G * VXL_CAP * 16); if (w) w->stg4 = (float4 *)p;
     p = take(65536); if (w) w->err = (int *)p;  // [0] sticky error flag (+ debug stamps)
     p = take((size_t)B * G * 32 * 4 + 256); if (w) w->tcnt = (int *)p;                               // [B][G][32]
-    p = take((size_t)B * ((n_max + 1023) & ~1023) * 4 + 256); if (w) w->pkey = (uint32_t *)p;
+    p = take((size_t)B * ((n_max + 1023) & ~1023) * 4 + 1280 * 4 + 256); if (w) w->pkey = (uint32_t *)p;   // (+ one phase-A1 round of slack)
     p = take(B * H * 4); if (w) w->keys = (uint32_t *)p;
     p = take(B * H * 4); if (w) w->first = (int *)p;
     p = take(B * H * 4); if (w) w->cnt = (int *)p;
@@ -448,8 +448,7 @@ __global__ __launch_bounds__(256) void vx_rows_kernel(const float *__restrict__ 
 #define VXL_MBITS 14        // per-point word: m = min(count, P) in the low 14 bits, list position above
 #define VXL_MMASK ((1 << VXL_MBITS) - 1)
 #define VXL_MAX_ITEMS 32    // n_max <= 32 * 1024 (a point index fits 15 bits)
-#define VXL_A_U 10          // keys per thread requested together in phase A1 (20 spill at the 64-VGPR budget; hand-written `nt`
-                            // loads, 16 in flight on one address register, measured slower than these sc1 loads: 16.2 vs 12.1 k cycles)
+#define VXL_A_KEYS 1280     // keys per wave and round in phase A1: 20 per lane, five 16-byte sc1 loads in flight on one address register
 #define VXL_FILL_F4_PER_WG (1024 * 4)      // 64 KiB of zeros per fill chunk
 #define VXL_WAIT_TICKS 20000               // 200 us of the 100 MHz wall clock: how long a wave re-reads a key that has not arrived
 #define VX_NOKEY 0xFFFFFFFFu               // a shared key that has not been published (never a valid key: vx_key2)
@@ -606,6 +605,25 @@ __device__ __forceinline__ void vxl_count_firsts(int *s_tc, bool isfirst, int j,
         if (l == lead) atomicAdd(&s_tc[t0], __popcll(m));
         rem &= ~m;
     }
+}
+
+// 20 keys of one lane — uint4 number r * 64 + lane of the wave's run, r = 0..4 — with five L1-bypassing (`sc1`) 16-byte loads issued
+// together and waited for once.  Hand-written: __hip_atomic_load has no 16-byte form, the polling loop must re-issue the loads every
+// time, and the saddr + immediate-offset form needs ONE address VGPR for all five (ten dword loads with their own 64-bit addresses
+// were the register limit of this kernel, and two dependent rounds of them cost 2.5 us each).
+typedef unsigned vx_u4 __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ void vxl_load_keys20(const uint32_t *base, uint32_t voff, vx_u4 (&k)[5]) {
+    const uint32_t vmid = voff + 2048u;                   // immediate offsets are 13-bit signed
+    asm volatile(
+        "global_load_dwordx4 %0, %5, %6 offset:-2048 sc1\n"
+        "global_load_dwordx4 %1, %5, %6 offset:-1024 sc1\n"
+        "global_load_dwordx4 %2, %5, %6 sc1\n"
+        "global_load_dwordx4 %3, %5, %6 offset:1024 sc1\n"
+        "global_load_dwordx4 %4, %5, %6 offset:2048 sc1\n"
+        "s_waitcnt vmcnt(0)"
+        : "=&v"(k[0]), "=&v"(k[1]), "=&v"(k[2]), "=&v"(k[3]), "=&v"(k[4])
+        : "v"(vmid), "s"(base)
+        : "memory");
 }
 
 struct VxlShared {
@@ -818,43 +836,57 @@ __global__ __launch_bounds__(1024, 8) void vxl_keybin_kernel(const float *__rest
         // per-entry stores of a wave close together); point (u, lane) of wave wv = wbase + u * 64 + lane
         const int wbase = wv * nt * 64;
         const long long deadline = wall_clock64() + VXL_WAIT_TICKS;
-        for (int u0 = 0; u0 < nt; u0 += VXL_A_U) {
-            uint32_t key[VXL_A_U];
+        for (int u0 = 0; u0 < nt * 64; u0 += VXL_A_KEYS) {         // rounds of 1 280 keys per wave: one for frames up to 20 480 points
+            vx_u4 kq[5];
+            const int kb = wbase + u0;                              // key (r, lane, c) of the round = kb + (r * 64 + lane) * 4 + c
+            uint32_t live = 0;                  // bit (r * 4 + c): key (r, lane, c) is a point of the frame in this wave's run
+#pragma unroll
+            for (int r = 0; r < 5; ++r)
+#pragma unroll
+                for (int c = 0; c < 4; ++c) {
+                    const int j = kb + (r * 64 + l) * 4 + c;
+                    live |= (uint32_t)((j < n) & (j - wbase < nt * 64)) << (r * 4 + c);
+                }
             for (;;) {
-                bool missing = false;
+                vxl_load_keys20(pkey, (uint32_t)(kb + l * 4) * 4u, kq);     // (the row has VXL_A_KEYS entries of slack behind it)
+                uint32_t miss = 0;
 #pragma unroll
-                for (int u = 0; u < VXL_A_U; ++u)                       // global_load_dword sc1: L1 bypassed, re-issued every time
-                    key[u] = __hip_atomic_load(pkey + wbase + (u0 + u) * 64 + l, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                for (int r = 0; r < 5; ++r)
 #pragma unroll
-                for (int u = 0; u < VXL_A_U; ++u)                       // (rows past the frame read as VX_NOKEY: masked)
-                    missing |= (key[u] == VX_NOKEY) & (wbase + (u0 + u) * 64 + l < n) & (u0 + u < nt);
-                if (__ballot(missing) == 0ull) break;                  // wave-uniform
+                    for (int c = 0; c < 4; ++c) miss |= (uint32_t)(kq[r][c] == VX_NOKEY) << (r * 4 + c);
+                if (__ballot((miss & live) != 0) == 0ull) break;       // wave-uniform
                 if (wall_clock64() > deadline) {                       // the frame's other workgroups are not (all) running beside
                     s_slow = 1;                                        // this one: the workgroup redoes its bin from the points
-                    break;                                             // themselves (streaming variant) after the barrier
+                    live = 0;                                          // themselves (streaming variant) after the barrier
+                    break;
                 }
                 __builtin_amdgcn_s_sleep(4);
             }
-            uint32_t bits = 0;                  // bit u: that point goes to my bin
+            uint32_t bits = 0;                  // bit (r * 4 + c): that point goes to my bin
             int wtotal = 0;                     // wave-uniform: entries of this wave in this round
 #pragma unroll
-            for (int u = 0; u < VXL_A_U; ++u) {
-                const int j = wbase + (u0 + u) * 64 + l;
-                const bool mine = (vxl_bin_of24(key[u], gsh) == g) & (j < n) & (u0 + u < nt);
-                bits |= (uint32_t)mine << u;
-                wtotal += __popcll(__ballot(mine));
-            }
+            for (int r = 0; r < 5; ++r)
+#pragma unroll
+                for (int c = 0; c < 4; ++c) {
+                    const bool mine = (vxl_bin_of24(kq[r][c], gsh) == g) & ((live >> (r * 4 + c)) & 1u);
+                    bits |= (uint32_t)mine << (r * 4 + c);
+                    wtotal += __popcll(__ballot(mine));
+                }
             int base = 0;
             if (l == 0 && wtotal) base = atomicAdd(&s_nent, wtotal);
             base = __shfl(base, 0, 64);
+            int j0 = kb + l * 4;                // (opaque to the optimiser: the twenty point numbers are re-derived from this one
+            asm volatile("" : "+v"(j0));        //  register at the store, not kept in twenty registers since the `live` loop above)
 #pragma unroll
-            for (int u = 0; u < VXL_A_U; ++u) {
-                const bool mine = (bits >> u) & 1u;
-                const unsigned long long bal = __ballot(mine);
-                const int pos = base + __popcll(bal & lanemask_lt());
-                if (mine && pos < VXL_CAP) s_q[pos] = make_int2(wbase + (u0 + u) * 64 + l, (int)key[u]);
-                base += __popcll(bal);
-            }
+            for (int r = 0; r < 5; ++r)
+#pragma unroll
+                for (int c = 0; c < 4; ++c) {
+                    const bool mine = (bits >> (r * 4 + c)) & 1u;
+                    const unsigned long long bal = __ballot(mine);
+                    const int pos = base + __popcll(bal & lanemask_lt());
+                    if (mine && pos < VXL_CAP) s_q[pos] = make_int2(j0 + r * 256 + c, (int)kq[r][c]);
+                    base += __popcll(bal);
+                }
         }
         VXL_STAMP(2);
         __syncthreads();
@@ -1029,6 +1061,17 @@ __global__ __launch_bounds__(1024, 8) void vxl_emit_kernel(const float *__restri
         }
     }
     const long long cleared_rows = p.compact ? (long long)w.fillst[1] : 0x7fffffffll;
+    // slots 1 and 2 of a multi-point voxel: their staged points are requested NOW, in the shadow of the ranking below (95 % of the
+    // multi-point pillars of a uniform cloud hold two points, nearly all the rest three): most workgroups then skip the
+    // flattened copy further down altogether
+    const size_t fbase = (size_t)f * G * VXL_CAP;
+    float4 pre1 = make_float4(0.f, 0.f, 0.f, 0.f), pre2 = pre1;
+    if (C4 && word != 0) {
+        const int c0 = word & VXL_MMASK;
+        const float4 *sp = w.stg4 + fbase + (word >> VXL_MBITS);
+        if (c0 >= 2) pre1 = sp[1];
+        if (c0 >= 3) pre2 = sp[2];
+    }
     const unsigned long long bal = __ballot(word != 0);
     if (l == 0) s_wcnt[wv] = __popcll(bal);
     __syncthreads();
@@ -1046,6 +1089,8 @@ __global__ __launch_bounds__(1024, 8) void vxl_emit_kernel(const float *__restri
         if (C4) {
             float4 *out4 = reinterpret_cast<float4 *>(voxels) + row * p.P;
             out4[0] = me;
+            if (cnt >= 2) out4[1] = pre1;
+            if (cnt >= 3) out4[2] = pre2;
             if ((long long)row >= cleared_rows)            // beyond what the fill role cleared: this thread owns the row's zeros
                 for (int sl = cnt; sl < p.P; ++sl) out4[sl] = make_float4(0.f, 0.f, 0.f, 0.f);
             x0 = me.x; y0 = me.y; z0 = me.z;
@@ -1063,8 +1108,10 @@ __global__ __launch_bounds__(1024, 8) void vxl_emit_kernel(const float *__restri
         reinterpret_cast<int4 *>(coords)[row] = make_int4(f, (int)(key / (nx * ny)), (int)((key / nx) % ny), (int)(key % nx));
         num_points[row] = cnt;
     }
-    // ---- slots 1 .. cnt-1 of the multi-point voxels, flattened over the workgroup
-    const int extra = first ? cnt - 1 : 0;
+    // ---- the further slots of the multi-point voxels (from slot 3 when C == 4: 1 and 2 were prefetched; else from slot 1),
+    // flattened over the workgroup
+    constexpr int S0 = C4 ? 3 : 1;
+    const int extra = first ? max(cnt - S0, 0) : 0;
     const unsigned long long bal2 = __ballot(extra > 0);
     const int inc2 = wave_incl_scan(extra);
     if (l == 63) s_e2[wv] = inc2;
@@ -1083,7 +1130,6 @@ __global__ __launch_bounds__(1024, 8) void vxl_emit_kernel(const float *__restri
     }
     if (extra > 0) s_desc[dbase + __popcll(bal2 & lanemask_lt())] = make_int4((int)row, lpos, ibase + inc2 - extra, extra);
     __syncthreads();
-    const size_t fbase = (size_t)f * G * VXL_CAP;
     for (int it = t; it < ne; it += 1024) {
         int lo = 0, hi = nd - 1;                               // the last descriptor whose first item is <= it
         while (lo < hi) {
@@ -1091,7 +1137,7 @@ __global__ __launch_bounds__(1024, 8) void vxl_emit_kernel(const float *__restri
             if (s_desc[mid].z <= it) lo = mid; else hi = mid - 1;
         }
         const int4 d = s_desc[lo];
-        const int s = it - d.z + 1;
+        const int s = it - d.z + S0;
         if (C4) {
             reinterpret_cast<float4 *>(voxels)[(size_t)d.x * p.P + s] = w.stg4[fbase + d.y + s];
         } else {
