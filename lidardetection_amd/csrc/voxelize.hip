@@ -749,7 +749,9 @@ __global__ __launch_bounds__(1024, 8) void vxl_keybin_kernel(const float *__rest
                     // clock at the start / end of EVERY workgroup of both launches, into the error page
 #define VXL_STAMP(k) do { if (id == 0 && t == 0) w.err[16 + (k)] = (int)clock64(); } while (0)
 #define VXL_WALL(slot) do { if (t == 0) w.err[64 + (slot)] = (int)wall_clock64(); } while (0)
+#define VXL_ESTAMP(k) do { if (f == p.batch - 1 && tile == 5 && t == 0) w.err[32 + (k)] = (int)clock64(); } while (0)   // one emit workgroup's phases
 #else
+#define VXL_ESTAMP(k) do { } while (0)
 #define VXL_STAMP(k) do { } while (0)
 #define VXL_WALL(slot) do { } while (0)
 #endif
@@ -1009,10 +1011,13 @@ __global__ __launch_bounds__(1024, 8) void vxl_emit_kernel(const float *__restri
     const int id = 1024 + f * (int)gridDim.x + tile;        // (stamp slot, -DVXL_STAMPS builds only)
     (void)id;
     VXL_WALL(2 * id);
+    VXL_ESTAMP(0);
+    const int i = tile * 1024 + t;
+    // requested before anything else, at an address that does not depend on the frame's offsets: inside a detector step both are
+    // cold misses (~1.5 us each) and the word heads the longest dependency chain of the launch (start -> word: 6.7 k -> 4.4 k cycles)
+    const int wd = w.flagw[(size_t)f * p.n_max + min(i, p.n_max - 1)];        // unconditional load, masked below
     const int start = offsets[f];
     const int n = min(offsets[f + 1] - start, p.n_max);
-    const int i = tile * 1024 + t;
-    const int wd = w.flagw[(size_t)f * p.n_max + min(i, max(n - 1, 0))];      // unconditional load, masked below
     const int word = (i < n) ? wd : 0;
     // this thread's own point, requested together with its word: for a first point it IS slot 0 of the voxel's row
     float4 me = make_float4(0.f, 0.f, 0.f, 0.f);
@@ -1072,9 +1077,11 @@ __global__ __launch_bounds__(1024, 8) void vxl_emit_kernel(const float *__restri
         if (c0 >= 2) pre1 = sp[1];
         if (c0 >= 3) pre2 = sp[2];
     }
+    VXL_ESTAMP(1);
     const unsigned long long bal = __ballot(word != 0);
     if (l == 0) s_wcnt[wv] = __popcll(bal);
     __syncthreads();
+    VXL_ESTAMP(2);
     int r = 0;
     for (int k = 0; k < (G * 32 + 63) / 64 && k < 16; ++k) r += s_part[k];
     for (int k = 0; k < wv; ++k) r += s_wcnt[k];
@@ -1108,6 +1115,7 @@ __global__ __launch_bounds__(1024, 8) void vxl_emit_kernel(const float *__restri
         reinterpret_cast<int4 *>(coords)[row] = make_int4(f, (int)(key / (nx * ny)), (int)((key / nx) % ny), (int)(key % nx));
         num_points[row] = cnt;
     }
+    VXL_ESTAMP(3);
     // ---- the further slots of the multi-point voxels (from slot 3 when C == 4: 1 and 2 were prefetched; else from slot 1),
     // flattened over the workgroup
     constexpr int S0 = C4 ? 3 : 1;

@@ -41,6 +41,14 @@ for it in range(6):
     print(f"   bin roles  start {q(us(b[:, 0]))} | end {q(us(b[:, 1]))} | dur {q((b[:, 1] - b[:, 0]) / 100.0)}")
     print(f"   fill roles start {q(us(fl[:, 0]))} | end {q(us(fl[:, 1]))} | dur {q((fl[:, 1] - fl[:, 0]) / 100.0)}")
     print(f"   emit wgs   start {q(us(em[:, 0]))} | end {q(us(em[:, 1]))} | dur {q((em[:, 1] - em[:, 0]) / 100.0)}")
+    if it == 5:
+        es = page[32:36]
+        en = ["start -> word arrived + prefetches issued", "first barrier", "rank + first-point stores issued"]
+        print("   emit wg (last frame, tile 5): " + "  ".join(f"{n} {int((es[i + 1] - es[i]) & 0xFFFFFFFF)}" for i, n in enumerate(en)))
+        d = ((em[:, 1] - em[:, 0]) / 100.0).reshape(B, ntile)
+        print("   emit dur by tile (mean over frames): " + " ".join(f"{x:.1f}" for x in d.mean(0)))
+        print("   emit dur by frame (mean over tiles): " + " ".join(f"{x:.1f}" for x in d.mean(1)))
+        print("   emit start by frame (mean): " + " ".join(f"{x:.1f}" for x in us(em[:, 0]).reshape(B, ntile).mean(1)))
     if it == 5 and "--emit-detail" in sys.argv:
         e0 = em[:, 0].min()
         order = np.argsort(em[:, 0])
