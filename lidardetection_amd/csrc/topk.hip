@@ -241,37 +241,66 @@ __global__ __launch_bounds__(1024, 8) void tk_collect_kernel(const float *__rest
 }
 
 // ------------------------------------------------------------------ launch 3: finalize
-// bitonic sort, descending, of s[0 .. n) in LDS (n a power of two, 32 <= n <= 8192), 1024 threads.  A stage whose partner
-// distance fits inside a wave's own n / 16-element chunk needs no workgroup barrier: the 64 lanes of the wave exchange through
-// LDS, whose operations a wave issues and completes in order (68 of the 78 stages at n = 4096; the 10 wide stages keep the barrier)
-__device__ __forceinline__ void tk_bitonic_desc(tk_u64 *s, int n, int t) {
-    const int chunk = n >> 4, wv = t >> 6, l = t & 63;
-    bool wide_before = true;                                       // (entry: other threads wrote the list)
+// Bitonic sort, descending, of s[0 .. 1024 * EPT) (LDS), 1024 threads, the elements held in REGISTERS: thread t owns elements
+// EPT * t .. EPT * t + EPT - 1.  A stage whose partner distance is below EPT is a register compare-exchange inside the thread;
+// below 64 * EPT the partner sits in another lane of the same wave (two 32-bit lane exchanges per element); only the stages
+// with a partner in another wave (10 of the 78 at 4096 elements) go through LDS — written in a lane-contiguous layout, one
+// barrier pair each.  (The first version kept the list in LDS and did one read-compare-write round trip per stage and pair:
+// 930 cycles per stage, 72 k cycles for the 4096-element sort.)
+__device__ __forceinline__ tk_u64 tk_shfl_xor64(tk_u64 v, int lane_mask) {
+    const unsigned lo = (unsigned)__shfl_xor((int)(unsigned)v, lane_mask, 64);
+    const unsigned hi = (unsigned)__shfl_xor((int)(unsigned)(v >> 32), lane_mask, 64);
+    return ((tk_u64)hi << 32) | lo;
+}
+// An element at stage (size, stride) keeps the larger of (own, partner) when its subsequence runs descending and it is the lower
+// index of the pair, or the subsequence runs ascending and it is the upper one.  For partners in other threads (stride >= EPT)
+// that verdict is the same for all EPT elements of a thread: computed once per stage (`want_max`), which leaves one 64-bit
+// compare and two selects per element — the sort is bound by the instruction rate of the ONE CU a frame's workgroup runs on
+// (4 waves per SIMD: 15 instructions per element and stage were 1 000 cycles per stage).
+__device__ __forceinline__ tk_u64 tk_keep(tk_u64 own, tk_u64 other, bool want_max) { return ((own > other) == want_max) ? own : other; }
+template <int EPT, int S>
+__device__ __forceinline__ void tk_local_stage(tk_u64 (&v)[EPT], int size, int e0) {
+#pragma unroll
+    for (int r = 0; r < EPT; ++r)
+        if ((r & S) == 0) {
+            const tk_u64 a = v[r], b = v[r | S];
+            const bool desc = size < EPT ? ((r & size) == 0) : ((e0 & size) == 0);
+            const bool sw = (a > b) != desc;               // exchange when the pair is not in the subsequence's order
+            v[r] = sw ? b : a;
+            v[r | S] = sw ? a : b;
+        }
+}
+template <int EPT>
+__device__ __forceinline__ void tk_sort_desc_regs(tk_u64 *s, int t) {
+    constexpr int n = 1024 * EPT;
+    tk_u64 v[EPT];
+    const int e0 = EPT * t;
+    __syncthreads();                                               // (other threads wrote the list)
+#pragma unroll
+    for (int r = 0; r < EPT; ++r) v[r] = s[e0 + r];
     for (int size = 2; size <= n; size <<= 1)
         for (int stride = size >> 1; stride > 0; stride >>= 1) {
-            if (2 * stride > chunk) {                              // partners in different waves' chunks
+            if (stride >= 64 * EPT) {                              // partner in another wave
+                __syncthreads();                                   // (the last readers of the exchange buffer are done)
+#pragma unroll
+                for (int r = 0; r < EPT; ++r) s[r * 1024 + t] = v[r];
                 __syncthreads();
-                for (int p = t; p < (n >> 1); p += 1024) {
-                    const int i = 2 * p - (p & (stride - 1)), j = i + stride;
-                    const bool up = (i & size) == 0;
-                    const tk_u64 a = s[i], b = s[j];
-                    if ((a < b) == up) { s[i] = b; s[j] = a; }
-                }
-                wide_before = true;
-            } else {
-                if (wide_before) __syncthreads();
-                wide_before = false;
-                __builtin_amdgcn_wave_barrier();                   // (compiler: keep the LDS accesses of two stages in order)
-                for (int q = l; q < (chunk >> 1); q += 64) {
-                    const int p = wv * (chunk >> 1) + q;
-                    const int i = 2 * p - (p & (stride - 1)), j = i + stride;
-                    const bool up = (i & size) == 0;
-                    const tk_u64 a = s[i], b = s[j];
-                    if ((a < b) == up) { s[i] = b; s[j] = a; }
-                }
-                __builtin_amdgcn_wave_barrier();
-            }
+                const int tp = t ^ (stride / EPT);
+                const bool want_max = ((e0 & size) == 0) == ((e0 & stride) == 0);
+#pragma unroll
+                for (int r = 0; r < EPT; ++r) v[r] = tk_keep(v[r], s[r * 1024 + tp], want_max);
+            } else if (stride >= EPT) {                            // partner in another lane
+                const int lm = stride / EPT;
+                const bool want_max = ((e0 & size) == 0) == ((e0 & stride) == 0);
+#pragma unroll
+                for (int r = 0; r < EPT; ++r) v[r] = tk_keep(v[r], tk_shfl_xor64(v[r], lm), want_max);
+            } else if (EPT > 1 && stride == 1) tk_local_stage<EPT, 1>(v, size, e0);
+            else if (EPT > 2 && stride == 2) tk_local_stage<EPT, 2>(v, size, e0);
+            else if (EPT > 4 && stride == 4) tk_local_stage<EPT, 4>(v, size, e0);
         }
+    __syncthreads();
+#pragma unroll
+    for (int r = 0; r < EPT; ++r) s[e0 + r] = v[r];
     __syncthreads();
 }
 
@@ -285,6 +314,12 @@ __global__ __launch_bounds__(1024) void tk_finalize_kernel(long long n, int k, u
     __shared__ int s_cnt, s_digit, s_above;
     __shared__ unsigned s_min, s_max;
     const int t = threadIdx.x, l = t & 63, wv = t >> 6, f = blockIdx.x;
+#ifdef TK_STAMPS   // tools/topk_phase_probe.py: shader-clock stamps of frame 0's phases, over frame 1's (already consumed) min/max words
+#define TK_STAMP(k) do { if (f == 0 && t == 0) w.mm[TK_W * 2 + (k)] = (unsigned)clock64(); } while (0)
+#else
+#define TK_STAMP(k) do { } while (0)
+#endif
+    TK_STAMP(0);
     for (int q = t; q < TK_BINS; q += 1024) {
         s_h[q] = w.hist[(size_t)f * TK_BINS + q];
         w.hist[(size_t)f * TK_BINS + q] = 0;                       // clean for the next call
@@ -307,16 +342,19 @@ __global__ __launch_bounds__(1024) void tk_finalize_kernel(long long n, int k, u
         }
     }
     __syncthreads();
+    TK_STAMP(1);
     tk_select_bin(s_h, s_w, s_sel, k, t);
+    TK_STAMP(2);
     const int above = s_sel[0] >= 0 ? s_sel[1] : 0, kk = s_sel[2];
     const int need = kk - above, totalB = s_pref[TK_W];
     const tk_u64 *segs = w.seg + (size_t)f * TK_W * w.per;
     for (int q = t; q < TK_KMAX; q += 1024) s_list[q] = (q < above) ? w.A[(size_t)f * TK_KMAX + q] : 0ull;
     __syncthreads();
+    TK_STAMP(3);
     if (need > 0) {
         if (totalB <= TK_LB) {
             // ---- the usual case: the whole bin fits in LDS — sort it, keep its `need` best
-            int np2 = 32;
+            int np2 = 1024;
             while (np2 < totalB) np2 <<= 1;
             for (int q = t; q < np2; q += 1024) {
                 tk_u64 e = 0ull;
@@ -328,7 +366,12 @@ __global__ __launch_bounds__(1024) void tk_finalize_kernel(long long n, int k, u
                 }
                 s_b[q] = e;
             }
-            tk_bitonic_desc(s_b, np2, t);
+            TK_STAMP(4);
+            if (np2 == 1024) tk_sort_desc_regs<1>(s_b, t);
+            else if (np2 == 2048) tk_sort_desc_regs<2>(s_b, t);
+            else if (np2 == 4096) tk_sort_desc_regs<4>(s_b, t);
+            else tk_sort_desc_regs<8>(s_b, t);
+            TK_STAMP(5);
             for (int q = t; q < need; q += 1024) s_list[above + q] = s_b[q];
         } else if (s_min == s_max) {
             // ---- one tie mass: every key of the bin is equal — the first `need` in index order (segments are index-ordered)
@@ -401,7 +444,9 @@ __global__ __launch_bounds__(1024) void tk_finalize_kernel(long long n, int k, u
             }
         }
     }
-    tk_bitonic_desc(s_list, TK_KMAX, t);
+    TK_STAMP(6);
+    tk_sort_desc_regs<TK_KMAX / 1024>(s_list, t);
+    TK_STAMP(7);
     for (int q = t; q < k; q += 1024) {
         const tk_u64 e = s_list[q];
         const bool ok = q < kk;
@@ -409,6 +454,7 @@ __global__ __launch_bounds__(1024) void tk_finalize_kernel(long long n, int k, u
         top_idx[(size_t)f * k + q] = ok ? (long long)(0xFFFFFFFFu - (unsigned)(e & 0xFFFFFFFFull)) : 0ll;
     }
     if (t == 0) counts[f] = kk;
+    TK_STAMP(8);
 }
 
 __global__ void tk_zero_kernel(int *p, long long n) {
