@@ -20,7 +20,7 @@ import torch
 import torch.nn as nn
 import torch.nn.functional as F
 
-from . import pillar_ops, synth
+from . import anchor_post, pillar_ops, synth
 from .bev_backbone import FoldedBEVBackbone, bias_act_, collect_params, params_key
 from .bev_backbone import _fold as fold_bn
 from .ext import iou3d_nms_cuda
@@ -224,7 +224,11 @@ class SECONDMultiHeadNuScenes(nn.Module):
             lab += list(labels)
             c0 += c_h
             off += n_h
-        scores, idx = torch.topk(masked, k, dim=2)                           # sorted descending == nms_gpu's own sort
+        if anchor_post.topk_supported(n_max, k):                             # csrc/topk.hip: exact, ties by ascending anchor index; slots
+            scores, idx, _ = anchor_post.topk_desc(masked.view(B * n_cols, n_max), k, self.score_thresh)   # past the valid ones hold (-1, 0)
+            scores, idx = scores.view(B, n_cols, k), idx.view(B, n_cols, k)
+        else:
+            scores, idx = torch.topk(masked, k, dim=2)                       # sorted descending == nms_gpu's own sort
         gidx = idx + torch.tensor(col_off, device=dev).view(1, -1, 1)        # row in the heads' concatenated anchor order
         boxes_all = torch.cat([box for _, box in head_out], dim=1)           # (B, sum n_h, 10)
         anchors_all = self._anchors_cat()

@@ -231,7 +231,10 @@ def test_pvrcnn_kitti_bs8(dev):
         before, fused = m.set_abstraction(pts, sizes, kp, multi_scale, bev)
         assert before.shape == (B * 2048, 640) and fused.shape == (B * 2048, 128)
         np.testing.assert_allclose(before[:2048, :256].cpu().numpy(), bf[0].cpu().numpy(), rtol=0, atol=0)     # the bev slice
-        point_scores = torch.sigmoid(m.point_cls_layers(before)).max(dim=-1)[0]
+        # (the forward's own function for the keypoint scores: the folded chain, not the module sequence — feeding the RoI head the
+        # module sequence's scores, 1.4e-7 away, is what made r02's assembled-vs-staged comparison differ in the last bits;
+        # tools/pvrcnn_stage_equal_probe.py prints the per-stage verdicts)
+        point_scores = torch.sigmoid(m._dense["point_cls_layers"](before)).max(dim=-1)[0]
         # the folded GEMM chains the forward uses for the FC stacks (pvrcnn.DenseChain) vs the module sequences themselves
         for name, x in (("point_cls_layers", before), ("vsa_point_feature_fusion", before)):
             want = getattr(m, name)(x)
@@ -268,23 +271,7 @@ def test_pvrcnn_kitti_bs8(dev):
                 assert np.array_equal(fl[f, :len(e)].cpu().numpy(), roi_labels[f].cpu().numpy()[e])
         # ---- and the assembled forward gives the same thing
         out = m(pts, offs, sizes)
-    # same functions, same inputs — but the dense layers (MIOpen / hipBLASLt) may pick another kernel when the free workspace
-    # differs between the two passes, so fp32 sums can differ in their last bits: counts and labels exact, values to 1e-4
+    # same functions, same inputs, same order of accumulation: bit-identical
     assert torch.equal(out[3], fn)
-    # (box sizes are exp() of a regression output: compared relative to their own magnitude; two RoIs whose scores differ
-    # in the last bit may swap places between the passes, so each frame's rows are put in a canonical order first)
-    def canon(boxes, scores, labels, n):
-        res = ([], [], [])
-        for f in range(boxes.shape[0]):
-            k = int(n[f])
-            order = torch.from_numpy(np.lexsort(np.round(boxes[f, :k].cpu().numpy()[:, :3].T, 2))).to(boxes.device)
-            for dst, t in zip(res, (boxes, scores, labels)):
-                dst.append(torch.cat([t[f, :k][order], t.new_zeros((boxes.shape[1] - k,) + t.shape[2:])]))
-        return [torch.stack(r) for r in res]
-    out = canon(out[0], out[1], out[2], fn)
-    fb, fs, fl = canon(fb, fs, fl, fn)
-    assert torch.equal(out[2], fl)
-    rel = float(((out[0] - fb).abs() / fb.abs().clamp(min=1.0)).max())
-    print(f"assembled vs staged forward: max box diff relative to max(1, |box|) {rel:.2e} (max |box| {float(fb.abs().max()):.2e}), "
-          f"max |score diff| {float((out[1] - fs).abs().max()):.2e}")
-    assert rel <= 1e-4 and float((out[1] - fs).abs().max()) <= 1e-4
+    for got, want, what in zip(out[:3], (fb, fs, fl), ("boxes", "scores", "labels")):
+        assert torch.equal(got, want), f"assembled vs staged forward: {what}"
