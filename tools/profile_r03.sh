@@ -1,12 +1,16 @@
 # Everything profiles/r03/ holds, collected on one box (gpurun_out/ is scratch; copy what is judged into profiles/r03/).
+# usage: bash tools/profile_r03.sh tests | rest   (two gpurun calls: each stays under the 1200 s limit)
 set -e
 R=$GRAFT_REPO_ROOT; O=$R/gpurun_out/r03; mkdir -p $O
 cd $R
+if [ "$1" = tests ]; then
 timeout -k 10 900 python -m pytest tests -m gpu -x -q -s > $O/pytest.log 2>&1 || { tail -40 $O/pytest.log; exit 1; }
 grep -E "passed|failed" $O/pytest.log | tail -1
 grep "ref shapes\|bs16" $O/pytest.log > $O/reference_shapes.log || true
 timeout -k 10 600 python bench.py --stages > $O/bench.log 2>&1
 tail -1 $O/bench.log | cut -c1-400
+exit 0
+fi
 timeout -k 10 200 python tools/second_bench.py > $O/second.log 2>&1
 timeout -k 10 200 python tools/sorted_gemm_bench.py > $O/spconv_gemm_layers.log 2>&1
 timeout -k 10 200 python tools/spconv_fwd_bench.py > $O/spconv_forward.log 2>&1 || true
