@@ -764,6 +764,159 @@ __global__ __launch_bounds__(256) void sc_implicit_gemm_rega_kernel(const float 
     }
 }
 
+// Wave-private variant of the register-A kernel (r03 experiment, LIDAR_SPCONV_WAVE_KERNEL=1; needs 4 waves x Cin x CW floats <= 64 KB
+// of LDS, i.e. two workgroups per CU).  MEASURED SLOWER than the register-A kernel (64->64: 418-424 vs 382-384 us, SECOND stack
+// 2.18 vs 2.01 ms): the per-offset barrier is NOT what holds the matrix pipe at 49 %.  The register-A kernel shares each W[k] stage among the four waves of a workgroup: one barrier per
+// offset, and a wave whose 32 rows skip an offset still waits for the waves that use it — the matrix pipe was busy 49 % of the
+// time.  Here every wave stages ITS OWN copy of W[k] (single-buffered in LDS, the next stage prefetched into registers while the
+// MFMAs of the current one run), walks only the offsets its own rows use, and never meets a barrier: a wave's LDS operations
+// execute in order, so the stores of stage s + 1 follow the last read of stage s by themselves.  The price is 4 x the W
+// traffic (L2 hits: a layer's 27 slices are 0.4 MB) and 64 more registers at Cin = Cout = 64 (2 waves per SIMD instead of 3).
+// Same channel ownership, same summation order: results are bit-identical to the register-A kernel's.
+template <int NT, int C4, int SL = 1>
+__global__ __launch_bounds__(256, 2) void sc_implicit_gemm_wave_kernel(const float *__restrict__ in, const int *__restrict__ nbr, int n_out,
+                                                                       int K, int Cout, const float *__restrict__ Wt,
+                                                                       const float *__restrict__ bias, const float *__restrict__ residual,
+                                                                       int relu, float *__restrict__ out,
+                                                                       const int *__restrict__ row_mask, const int *__restrict__ out_row) {
+    constexpr int Cin = C4 * 4, HALF = Cin / 2, CW = NT * 32, CW4 = CW / 4, CinT = Cin * SL;
+    constexpr int NG = HALF / 4;                          // float4 gathers per lane per stage
+    constexpr int NW = (Cin * CW4 + 63) / 64;             // float4 weight pieces per lane per stage
+    extern __shared__ float s_mem[];                      // [4 waves][Cin][CW]: each wave's own W stage
+    const int t = threadIdx.x, l = t & 63, wv = t >> 6;
+    float *Wl = s_mem + (size_t)wv * Cin * CW;
+    const int row0 = blockIdx.x * IG_ROWS + wv * 32;
+    const int ar = l & 31, ak = l >> 5;
+    const int myrow = row0 + ar;
+    const int trow = (out_row && myrow < n_out) ? out_row[myrow] : myrow;
+    const int Co4 = Cout >> 2;
+    f32x16 acc[NT];
+#pragma unroll
+    for (int q = 0; q < NT; ++q)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[q][r] = 0.f;
+    unsigned wave_mask = 0xffffffffu;
+    if (row_mask) {                                       // mask-sorted tables: the offsets some row of THIS wave uses
+        unsigned m = (myrow < n_out) ? (unsigned)row_mask[trow] : 0u;
+#pragma unroll
+        for (int d = 1; d < 64; d <<= 1) m |= (unsigned)__shfl_xor((int)m, d, 64);
+        wave_mask = m;
+    }
+    auto next_k = [&](int k) {                            // next offset > k some row of the wave uses (K when none)
+        if (!row_mask) return k + 1;
+        const unsigned rest = (k + 1 < 32) ? (wave_mask >> (k + 1)) : 0u;
+        return rest ? k + 1 + __builtin_ctz(rest) : K;
+    };
+    auto load_src = [&](int k) { return (myrow < n_out && k < K) ? nbr[(size_t)trow * K + k] : -1; };
+    float4 wr[NW], ga[NG], gn[NG];
+    auto fetch_w = [&](int k, int h) {
+#pragma unroll
+        for (int q = 0; q < NW; ++q) {
+            const int e = q * 64 + l, ci = e / CW4, q4 = e - ci * CW4;
+            wr[q] = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (e < Cin * CW4 && q4 < Co4) wr[q] = reinterpret_cast<const float4 *>(Wt + ((size_t)k * CinT + h * Cin + ci) * Cout)[q4];
+        }
+    };
+    auto store_w = [&]() {
+        float4 *dst = reinterpret_cast<float4 *>(Wl);
+#pragma unroll
+        for (int q = 0; q < NW; ++q) {
+            const int e = q * 64 + l;
+            if (e < Cin * CW4) dst[e] = wr[q];
+        }
+    };
+    auto fetch_a = [&](float4 (&g)[NG], int h, int src, bool any) {
+        const float4 *rowp = reinterpret_cast<const float4 *>(in + (size_t)max(src, 0) * CinT + h * Cin + ak * HALF);
+#pragma unroll
+        for (int u = 0; u < NG; ++u) {
+            g[u] = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (any && src >= 0) g[u] = rowp[u];
+        }
+    };
+    int k = next_k(-1), h = 0;
+    if (k >= K) k = K;
+    int src_cur = load_src(k), src_ahead = -1;
+    bool any = false;
+    if (k < K) {
+        any = __ballot(src_cur >= 0) != 0ull;
+        fetch_w(k, 0);
+        fetch_a(ga, 0, src_cur, any);
+        src_ahead = load_src(next_k(k));
+        store_w();
+    }
+    for (; k < K;) {
+        int kn = k, hn = h + 1;                           // the stage after this one
+        if (hn == SL) { kn = next_k(k); hn = 0; }
+        int src_next = src_cur;
+        bool any_next = false;
+        if (kn < K) {                                     // in flight while the MFMAs below run
+            if (kn != k) {
+                src_next = src_ahead;
+                src_ahead = load_src(next_k(kn));
+            }
+            any_next = __ballot(src_next >= 0) != 0ull;
+            fetch_w(kn, hn);
+            fetch_a(gn, hn, src_next, any_next);
+        }
+        if (any) {
+            const float *Wb = Wl + (size_t)ak * HALF * CW + ar;
+#pragma unroll
+            for (int u = 0; u < NG; ++u) {
+                const float av[4] = {ga[u].x, ga[u].y, ga[u].z, ga[u].w};
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+#pragma unroll
+                    for (int q = 0; q < NT; ++q)
+                        acc[q] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[j], Wb[(u * 4 + j) * CW + q * 32], acc[q], 0, 0, 0);
+                }
+            }
+        }
+        if (kn < K) {
+            store_w();                                    // (after this stage's last LDS read, in the wave's own order)
+#pragma unroll
+            for (int u = 0; u < NG; ++u) ga[u] = gn[u];
+        }
+        src_cur = src_next;
+        any = any_next;
+        k = kn;
+        h = hn;
+    }
+    const int last = n_out - 1;                           // n_out >= 1 (checked by the launcher)
+    // fused epilogue: (+ bias) (+ residual) (ReLU); sorted tables scatter rows (as in the pipe kernel)
+#pragma unroll
+    for (int hh = 0; hh < 2; ++hh) {
+        int orow[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            const int r = hh * 8 + j;
+            const int row = min(row0 + (r & 3) + 8 * (r >> 2) + 4 * (l >> 5), last);
+            orow[j] = out_row ? out_row[row] : row;
+        }
+#pragma unroll
+        for (int q = 0; q < NT; ++q) {
+            const int col = q * 32 + (l & 31);
+            const int cc = min(col, Cout - 1);
+            const float bv = bias ? bias[cc] : 0.f;
+            float res[8];
+#pragma unroll
+            for (int j = 0; j < 8; ++j) res[j] = 0.f;
+            if (residual) {
+#pragma unroll
+                for (int j = 0; j < 8; ++j) res[j] = residual[(size_t)orow[j] * Cout + cc];
+            }
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                const int r = hh * 8 + j;
+                const int row = row0 + (r & 3) + 8 * (r >> 2) + 4 * (l >> 5);
+                if (row < n_out && col < Cout) {
+                    const float v = acc[q][r] + bv + res[j];
+                    out[(size_t)orow[j] * Cout + col] = relu ? fmaxf(v, 0.f) : v;
+                }
+            }
+        }
+    }
+}
+
 // Input layer (Cin == 4: x, y, z, intensity means; K * 4 <= 128): all K offsets in ONE stage.  The per-offset kernels above
 // spend two barriers per offset on 2 MFMA steps of work here; this one gathers the wave's 32 x (K * 4) tile and the whole
 // (K * 4, Cout) weight once, then runs the K * 2 MFMA steps back to back.  Same operand pairs in the same order as the
@@ -870,7 +1023,11 @@ static int sc_gemm_launch(const float *in_features, const int *nbr, int n_out, i
     const dim3 grid(divup(n_out, IG_ROWS));
     static const bool use_pipe = getenv("LIDAR_SPCONV_PIPE_KERNEL") != nullptr;       // A/B switch: the r02 LDS-transposing kernel
     const size_t lds_rega = (size_t)2 * cin_stage * nt * 32 * sizeof(float);          // two W stage buffers
+    static const bool want_wave = getenv("LIDAR_SPCONV_WAVE_KERNEL") != nullptr;      // A/B switch: the barrier-free wave-private kernel
+    const size_t lds_wave = (size_t)4 * cin_stage * nt * 32 * sizeof(float);          // one W stage per wave
+    const bool use_wave = want_wave && lds_wave <= 65536;                             // (two workgroups per CU)
 #define IGP(NT, C4) do { if (use_pipe) hipLaunchKernelGGL((sc_implicit_gemm_pipe_kernel<NT, C4>), grid, dim3(256), lds, s, in_features, nbr, n_out, K, Cout, weight, bias, residual, relu, out_features, row_mask, out_row); \
+                         else if (use_wave && NT <= 2) hipLaunchKernelGGL((sc_implicit_gemm_wave_kernel<(NT <= 2 ? NT : 1), C4>), grid, dim3(256), lds_wave, s, in_features, nbr, n_out, K, Cout, weight, bias, residual, relu, out_features, row_mask, out_row); \
                          else hipLaunchKernelGGL((sc_implicit_gemm_rega_kernel<NT, C4>), grid, dim3(256), lds_rega, s, in_features, nbr, n_out, K, Cout, weight, bias, residual, relu, out_features, row_mask, out_row); } while (0)
 #define IGP2(NT, C4) do { if (use_pipe) hipLaunchKernelGGL((sc_implicit_gemm_pipe_kernel<NT, C4, 2>), grid, dim3(256), lds, s, in_features, nbr, n_out, K, Cout, weight, bias, residual, relu, out_features, row_mask, out_row); \
                           else hipLaunchKernelGGL((sc_implicit_gemm_rega_kernel<NT, C4, 2>), grid, dim3(256), lds_rega, s, in_features, nbr, n_out, K, Cout, weight, bias, residual, relu, out_features, row_mask, out_row); } while (0)
