@@ -35,8 +35,9 @@ def make_batch(batch, rank, device):
     frames = [synth.cloud_uniform(1000 + rank * batch + f) for f in range(batch)]
     sizes = [len(f) for f in frames]
     pts = torch.from_numpy(np.concatenate(frames, 0)).to(device)
-    offs = torch.tensor(np.concatenate([[0], np.cumsum(sizes)]), dtype=torch.int32, device=device)
-    return frames, pts, offs, max(sizes)
+    hoffs = [int(v) for v in np.concatenate([[0], np.cumsum(sizes)])]       # the collate step knows the offsets on the host too
+    offs = torch.tensor(hoffs, dtype=torch.int32, device=device)
+    return frames, pts, offs, hoffs, max(sizes)
 
 
 def _hot_path_stages_cpu(frame, boxes, w, bn, max_voxels, nms_thresh, clk=time.perf_counter):
@@ -264,7 +265,7 @@ def main():
     # deterministic across ranks and runs)
     torch.backends.cudnn.benchmark = os.environ.get("LIDAR_BENCH_MIOPEN_FIND", "1") != "0"
 
-    frames, pts, offs, n_max = make_batch(args.batch, rank, device)
+    frames, pts, offs, hoffs, n_max = make_batch(args.batch, rank, device)
     torch.manual_seed(0)
     model = PointPillarKITTI(batch_size=args.batch, max_voxels=16000, n_max=n_max, device=device).randomize_for_bench(0)
 
@@ -273,7 +274,7 @@ def main():
 
     with torch.no_grad():
         for _ in range(args.warmup):
-            out = model(pts, offs)
+            out = model(pts, offs, hoffs)
         barrier()
         ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(args.steps)]
         ev0 = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(args.steps)]
@@ -286,7 +287,7 @@ def main():
             ev0[k][0].record()                      # empty bracket: what a HIP event pair costs by itself at this point
             ev0[k][1].record()
             ev[k][0].record()                       # same stream the kernels are launched on
-            vox = model.voxelize(pts, offs)
+            vox = model.voxelize(pts, offs, hoffs)
             ev[k][1].record()
             canvas = model.vfe_scatter(vox)
             out = model.post_process(*model.backbone_head(canvas))
@@ -301,16 +302,16 @@ def main():
         model.resident_voxels = False
         with torch.no_grad():
             evc = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(max(args.steps // 2, 5))]
-            model(pts, offs)
+            model(pts, offs, hoffs)
             for a, b in evc:
                 a.record()
-                v2 = model.voxelize(pts, offs)
+                v2 = model.voxelize(pts, offs, hoffs)
                 b.record()
                 model.post_process(*model.backbone_head(model.vfe_scatter(v2)))
             torch.cuda.synchronize()
         contract_ms = float(np.mean([a.elapsed_time(b) for a, b in evc]))
         model.resident_voxels = True
-        model(pts, offs)
+        model(pts, offs, hoffs)
     vox_ms = float(np.mean([a.elapsed_time(b) for a, b in ev]))
     ev_overhead_ms = float(np.mean([a.elapsed_time(b) for a, b in ev0]))
     total_rows = int(vox["voxel_offsets"][-1].item())
@@ -388,7 +389,7 @@ def main():
             torch.cuda.synchronize()
             return float(np.median([a.elapsed_time(b) for a, b in evs])), r
         with torch.no_grad():
-            tv, vox = gpu_time(lambda: model.voxelize(pts, offs))
+            tv, vox = gpu_time(lambda: model.voxelize(pts, offs, hoffs))
             ts, canvas = gpu_time(lambda: model.vfe_scatter(vox))
             tb, hb = gpu_time(lambda: model.backbone_head(canvas))
             tp, outp = gpu_time(lambda: model.post_process(*hb))
@@ -401,7 +402,7 @@ def main():
         try:
             res["extra"] = bench_extra.pp_kernels(model, pts, offs)
             res["extra"].update(bench_extra.pp_ring(model))
-            model(pts, offs)
+            model(pts, offs, hoffs)
         except Exception as e:
             res["extra"] = dict(res.get("extra") or {}, pp_kernels_error=repr(e)[:200])
         torch.cuda.empty_cache()

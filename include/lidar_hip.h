@@ -61,6 +61,14 @@ int lidar_voxelize(const float *points, const int *point_offsets, int batch, int
                    const float *range6, const float *voxel_size3, const int *grid3, int max_points,
                    int max_voxels, int compact, int algo, float *voxels, int *coords, int *num_points,
                    int *voxel_offsets, void *ws, size_t ws_bytes, void *stream);
+/* lidar_voxelize for a caller that also knows the frame offsets on the HOST — the reference's collate_batch does
+ * (pcdet/datasets/dataset.py:153-185 builds the batch index from the per-sample lengths): host_offsets = batch + 1 ints in host
+ * memory with the same contents as point_offsets (nullptr = none).  Up to 64 frames they travel as kernel arguments, and the
+ * LDS-binned launches (algo 3 / 4) issue their first point read without a dependent load of the offsets; results identical. */
+int lidar_voxelize_hostoff(const float *points, const int *point_offsets, const int *host_offsets, int batch, int n_max,
+                           int num_features, const float *range6, const float *voxel_size3, const int *grid3, int max_points,
+                           int max_voxels, int compact, int algo, float *voxels, int *coords, int *num_points,
+                           int *voxel_offsets, void *ws, size_t ws_bytes, void *stream);
 /* optional: a device-visible HOST int (pinned + mapped memory) that receives the same error bits, so the caller can poll
  * the flag without a copy or a synchronisation (nullptr unregisters).  Cleared by the caller. */
 int lidar_voxelize_set_error_mirror(void *ws, size_t ws_bytes, int batch, int n_max, int max_voxels, int *host_flag,

@@ -16,6 +16,7 @@ SIGNATURES = {
     "lidar_voxelize_workspace_bytes": (sz, [i32, i32, i32]),
     "lidar_voxelize_workspace_init": (i32, [vp, sz, i32, i32, i32, vp]),
     "lidar_voxelize": (i32, [vp, vp, i32, i32, i32, vp, vp, vp, i32, i32, i32, i32, vp, vp, vp, vp, vp, sz, vp]),
+    "lidar_voxelize_hostoff": (i32, [vp, vp, vp, i32, i32, i32, vp, vp, vp, i32, i32, i32, i32, vp, vp, vp, vp, vp, sz, vp]),
     "lidar_voxelize_error_flag": (i32, [vp, sz, i32, i32, i32]),
     "lidar_voxelize_set_error_mirror": (i32, [vp, sz, i32, i32, i32, vp, vp]),
     "lidar_pillar_vfe": (i32, [vp, vp, vp, i32, vp, i32, i32, vp, vp, vp, i32, vp, vp, i32, i32, i32, vp, vp]),

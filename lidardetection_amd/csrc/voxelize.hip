@@ -43,6 +43,8 @@ __device__ __forceinline__ void vx_store_nt(float4 *dst, float4 v) {
     __builtin_nontemporal_store(t, reinterpret_cast<vx_f4 *>(dst));
 }
 
+#define VX_HOFF_MAX 64    // frames whose offsets travel as kernel arguments (lidar_voxelize_hostoff)
+
 struct VxParams {
     float lo[3];
     float vs[3];
@@ -51,6 +53,8 @@ struct VxParams {
     int grid[3];  // nx, ny, nz
     int C, P, max_voxels, batch, n_max, compact;
     int H, hshift, ntiles;
+    int hoff_n;           // > 0: hoff[0 .. batch] holds the frame offsets (the caller knew them on the host): the LDS-binned launches
+    int hoff[VX_HOFF_MAX + 1];   // take them from the kernel arguments instead of a dependent (cold, ~1.5 us) load in front of the first point read
 };
 
 struct VxWs {
@@ -81,6 +85,10 @@ struct VxWs {
     int **mirror;    // [1] optional device-visible HOST address (pinned, mapped) that also receives the error bits, so the
                      //     host can poll the flag without a copy or a sync (lidar_voxelize_set_error_mirror); null = none
 };
+
+__device__ __forceinline__ int vx_offset(const VxParams &p, const int *__restrict__ offsets, int f) {
+    return p.hoff_n ? p.hoff[f] : offsets[f];
+}
 
 // error bits: 1 = LDS table full, 2 = bin entry / list capacity exceeded.  Only ever reached on degenerate input, so the
 // extra pointer load and the system-scope atomic cost nothing on the normal path.
@@ -796,8 +804,8 @@ __global__ __launch_bounds__(1024, 8) void vxl_keybin_kernel(const float *__rest
     const int f = (id & 7) + 8 * (q8 >> lg), g = q8 & (G - 1);
     VXL_STAMP(0);
     if (f < p.batch) {
-        const int start = offsets[f];
-        const int n = min(offsets[f + 1] - start, p.n_max);
+        const int start = vx_offset(p, offsets, f);
+        const int n = min(vx_offset(p, offsets, f + 1) - start, p.n_max);
         const int nt = (n + 1023) >> 10;
         int *pinfo = w.flagw + (size_t)f * p.n_max;
         const int kstride = (p.n_max + 1023) & ~1023;
@@ -1016,8 +1024,8 @@ __global__ __launch_bounds__(1024, 8) void vxl_emit_kernel(const float *__restri
     // requested before anything else, at an address that does not depend on the frame's offsets: inside a detector step both are
     // cold misses (~1.5 us each) and the word heads the longest dependency chain of the launch (start -> word: 6.7 k -> 4.4 k cycles)
     const int wd = w.flagw[(size_t)f * p.n_max + min(i, p.n_max - 1)];        // unconditional load, masked below
-    const int start = offsets[f];
-    const int n = min(offsets[f + 1] - start, p.n_max);
+    const int start = vx_offset(p, offsets, f);
+    const int n = min(vx_offset(p, offsets, f + 1) - start, p.n_max);
     const int word = (i < n) ? wd : 0;
     // this thread's own point, requested together with its word: for a first point it IS slot 0 of the voxel's row
     float4 me = make_float4(0.f, 0.f, 0.f, 0.f);
@@ -1230,11 +1238,29 @@ LIDAR_EXPORT int lidar_voxelize_error_flag(void *ws, size_t ws_bytes, int batch,
     return v;
 }
 
+LIDAR_EXPORT int lidar_voxelize_hostoff(const float *points, const int *point_offsets, const int *host_offsets, int batch, int n_max,
+                                        int num_features, const float *range6, const float *voxel_size3,
+                                        const int *grid3, int max_points, int max_voxels, int compact, int algo, float *voxels,
+                                        int *coords, int *num_points, int *voxel_offsets, void *ws, size_t ws_bytes,
+                                        void *stream);
+
 LIDAR_EXPORT int lidar_voxelize(const float *points, const int *point_offsets, int batch, int n_max,
                                 int num_features, const float *range6, const float *voxel_size3,
                                 const int *grid3, int max_points, int max_voxels, int compact, int algo, float *voxels,
                                 int *coords, int *num_points, int *voxel_offsets, void *ws, size_t ws_bytes,
                                 void *stream) {
+    return lidar_voxelize_hostoff(points, point_offsets, nullptr, batch, n_max, num_features, range6, voxel_size3, grid3, max_points,
+                                  max_voxels, compact, algo, voxels, coords, num_points, voxel_offsets, ws, ws_bytes, stream);
+}
+
+// The same call for a caller that ALSO knows the frame offsets on the host (a collate function always does): host_offsets =
+// batch + 1 ints in host memory, equal to the device array's contents (null: none).  Up to VX_HOFF_MAX frames they travel as kernel
+// arguments to the LDS-binned launches, which then start their first point read without waiting for a load of the offsets.
+LIDAR_EXPORT int lidar_voxelize_hostoff(const float *points, const int *point_offsets, const int *host_offsets, int batch, int n_max,
+                                        int num_features, const float *range6, const float *voxel_size3,
+                                        const int *grid3, int max_points, int max_voxels, int compact, int algo, float *voxels,
+                                        int *coords, int *num_points, int *voxel_offsets, void *ws, size_t ws_bytes,
+                                        void *stream) {
     if (!points || !point_offsets || !voxels || !coords || !num_points || !voxel_offsets || !ws) return LIDAR_ERR_ARG;
     if (batch <= 0 || num_features < 3 || max_points <= 0 || max_voxels <= 0 || n_max < 0) return LIDAR_ERR_ARG;
     if ((double)grid3[0] * grid3[1] * grid3[2] >= 4294967295.0) return LIDAR_ERR_ARG;
@@ -1258,6 +1284,11 @@ LIDAR_EXPORT int lidar_voxelize(const float *points, const int *point_offsets, i
     while ((1 << hb) < p.H) ++hb;
     p.hshift = 32 - hb;
     p.ntiles = divup(n_max, VX_TILE);
+    p.hoff_n = 0;
+    if (host_offsets && batch <= VX_HOFF_MAX) {
+        p.hoff_n = batch + 1;
+        for (int k = 0; k <= batch; ++k) p.hoff[k] = host_offsets[k];
+    }
     VxWs w;
     if (vx_carve(ws, batch, n_max, max_voxels, &w) > ws_bytes) return LIDAR_ERR_WORKSPACE;
     hipStream_t s = (hipStream_t)stream;

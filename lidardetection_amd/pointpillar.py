@@ -136,8 +136,10 @@ class PointPillarKITTI(nn.Module):
         return self._bev
 
     # ---- stages (kept separate so bench.py can time them) ------------------------------------
-    def voxelize(self, points, point_offsets):
-        return self.voxelizer(points, point_offsets, self.n_max, compact=True, out=self._vox_out, resident=self.resident_voxels)
+    def voxelize(self, points, point_offsets, host_offsets=None):
+        """host_offsets: the same offsets on the host, when the caller has them (kernel arguments instead of a dependent load)"""
+        return self.voxelizer(points, point_offsets, self.n_max, compact=True, out=self._vox_out, resident=self.resident_voxels,
+                              host_offsets=host_offsets)
 
     def vfe_scatter(self, vox):
         w, s, t = self._pfn_folded()
@@ -241,7 +243,7 @@ class PointPillarKITTI(nn.Module):
         return out_boxes, out_scores, out_labels, num
 
     @torch.no_grad()
-    def forward(self, points, point_offsets):
-        vox = self.voxelize(points, point_offsets)
+    def forward(self, points, point_offsets, host_offsets=None):
+        vox = self.voxelize(points, point_offsets, host_offsets)
         canvas = self.vfe_scatter(vox)
         return self.post_process(*self.backbone_head(canvas))

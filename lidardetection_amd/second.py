@@ -44,8 +44,9 @@ class SECONDKitti(PointPillarKITTI):
         self._folded = self._bev = None
 
     # ---- stages --------------------------------------------------------------------------------
-    def voxelize_vfe(self, points, point_offsets):
-        vox = self.voxelizer(points, point_offsets, self.n_max, compact=True, out=self._vox_out, resident=self.resident_voxels)
+    def voxelize_vfe(self, points, point_offsets, host_offsets=None):
+        vox = self.voxelizer(points, point_offsets, self.n_max, compact=True, out=self._vox_out, resident=self.resident_voxels,
+                             host_offsets=host_offsets)
         total = int(vox["voxel_offsets"][self.B])               # the sparse stack needs exact row counts (one read-back)
         feats = pillar_ops.mean_vfe(vox["voxels"][:total], vox["voxel_num_points"][:total])
         return feats, vox["voxel_coords"][:total]
@@ -58,7 +59,7 @@ class SECONDKitti(PointPillarKITTI):
         return (self._bev_folded().merged(canvas),)
 
     @torch.no_grad()
-    def forward(self, points, point_offsets):
-        feats, coords = self.voxelize_vfe(points, point_offsets)
+    def forward(self, points, point_offsets, host_offsets=None):
+        feats, coords = self.voxelize_vfe(points, point_offsets, host_offsets)
         canvas = self.sparse_backbone(feats, coords)
         return self.post_process(*self.backbone_head(canvas))

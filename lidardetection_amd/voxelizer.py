@@ -5,6 +5,8 @@ inside DataLoader workers: spconv's VoxelGeneratorV2.generate (pcdet/datasets/pr
 data_processor.py:48-80) followed by collate_batch's concatenation + batch-index column
 (pcdet/datasets/dataset.py:153-185).  Output is identical to that sequential path.
 """
+import ctypes
+
 import numpy as np
 import torch
 
@@ -71,13 +73,15 @@ class BatchVoxelizer:
             "voxel_offsets": torch.empty((batch + 1,), dtype=torch.int32, device=device),
         }
 
-    def __call__(self, points, point_offsets, n_max, compact=True, out=None, resident=False):
+    def __call__(self, points, point_offsets, n_max, compact=True, out=None, resident=False, host_offsets=None):
         """points (sum N, C) f32 cuda; point_offsets (B+1) int32 cuda; n_max >= max frame size (host int).
         Returns dict(voxels, voxel_coords [b,z,y,x], voxel_num_points, voxel_offsets); rows beyond
         voxel_offsets[-1] are unspecified.  No host synchronisation.
         resident=True (with a persistent `out` that nobody else writes to between calls): the zero padding of `out` is kept
         from call to call and only the previous call's occupied slots are re-zeroed (include/lidar_hip.h, algo 4); the result is
-        bit-identical, and rows beyond voxel_offsets[-1] are then all zero."""
+        bit-identical, and rows beyond voxel_offsets[-1] are then all zero.
+        host_offsets: the same B+1 offsets as a host sequence / numpy array, when the caller has them (a collate function does):
+        they are handed to the launches as kernel arguments (lidar_voxelize_hostoff); results identical."""
         _lib.require_cuda(points, point_offsets)
         if points.dtype != torch.float32 or point_offsets.dtype != torch.int32:
             raise _lib.LidarHipError("points must be float32 and point_offsets int32")
@@ -91,11 +95,16 @@ class BatchVoxelizer:
             out = self.alloc_outputs(batch, points.device)
         L = _lib.lib()
         algo = 4 if (resident and compact and self.algo in (0, 1, 3, 4) and n_max <= 32768) else self.algo
-        _lib.check(L.lidar_voxelize(_lib.ptr(points), _lib.ptr(point_offsets), batch, n_max, self.C, self._range_h,
-                                    self._vs_h, self._grid_h, self.max_num_points, self.max_voxels, int(bool(compact)), algo,
-                                    _lib.ptr(out["voxels"]), _lib.ptr(out["voxel_coords"]),
-                                    _lib.ptr(out["voxel_num_points"]), _lib.ptr(out["voxel_offsets"]), _lib.ptr(ws),
-                                    nbytes, _lib.stream()), "lidar_voxelize")
+        hoff = None
+        if host_offsets is not None:
+            if len(host_offsets) != batch + 1:
+                raise _lib.LidarHipError("host_offsets must hold batch + 1 entries")
+            hoff = (ctypes.c_int * (batch + 1))(*[int(v) for v in host_offsets])
+        _lib.check(L.lidar_voxelize_hostoff(_lib.ptr(points), _lib.ptr(point_offsets), hoff, batch, n_max, self.C, self._range_h,
+                                            self._vs_h, self._grid_h, self.max_num_points, self.max_voxels, int(bool(compact)),
+                                            algo, _lib.ptr(out["voxels"]), _lib.ptr(out["voxel_coords"]),
+                                            _lib.ptr(out["voxel_num_points"]), _lib.ptr(out["voxel_offsets"]), _lib.ptr(ws),
+                                            nbytes, _lib.stream()), "lidar_voxelize")
         return out
 
     def error_flag(self, batch, n_max, device):

@@ -123,8 +123,9 @@ def test_pointpillar_kitti_bs16_timed_path_over_successive_batches(dev):
     n = m.pfn_norm
     for tag, frames in _batches(synth.PP_RANGE).items():
         pts, offs = _to_device(frames, dev)
+        hoffs = np.concatenate([[0], np.cumsum([len(f) for f in frames])]).tolist()   # as bench.py: the offsets on the host too
         with torch.no_grad():                                            # bench.py's timed loop, stage by stage
-            vox = m.voxelize(pts, offs)
+            vox = m.voxelize(pts, offs, hoffs)
             canvas = m.vfe_scatter(vox)
             (head,) = m.backbone_head(canvas)
             out = m.post_process(head)
@@ -150,7 +151,7 @@ def test_pointpillar_kitti_bs16_timed_path_over_successive_batches(dev):
         assert max(info["kept"]) > 0
     # the whole forward in one call gives the same detections as the staged calls of the last batch
     with torch.no_grad():
-        again = m(pts, offs)
+        again = m(pts, offs)                 # (device offsets only: the other entry of the voxeliser, same bits)
     for a, b in zip(again, out):
         assert torch.equal(a, b)
 
@@ -163,8 +164,9 @@ def test_second_kitti_bs16_timed_path_over_successive_batches(dev):
     bb = m.backbone3d
     for tag, frames in _batches(synth.SEC_RANGE).items():
         pts, offs = _to_device(frames, dev)
+        hoffs = np.concatenate([[0], np.cumsum([len(f) for f in frames])]).tolist()
         with torch.no_grad():                                            # tools/second_bench.py's timed loop
-            feats, coords = m.voxelize_vfe(pts, offs)
+            feats, coords = m.voxelize_vfe(pts, offs, hoffs)
             canvas = m.sparse_backbone(feats, coords)
             (head,) = m.backbone_head(canvas)
             out = m.post_process(head)
@@ -194,6 +196,6 @@ def test_second_kitti_bs16_timed_path_over_successive_batches(dev):
         print(f"[second bs16 {tag}] voxels {total} out sites {len(idx)} dense err/scale {err:.1e} kept/frame min {min(info['kept'])} "
               f"max {max(info['kept'])} ties left out at the k-th score {info['excluded_ties_at_kth']}")
     with torch.no_grad():
-        again = m(pts, offs)
+        again = m(pts, offs)                 # (device offsets only: the other entry of the voxeliser, same bits)
     for a, b in zip(again, out):
         assert torch.equal(a, b)

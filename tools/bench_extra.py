@@ -150,24 +150,25 @@ def pp_ring(model):
     a third of the points outside the grid) — the headline uses the uniform cloud; both output modes"""
     dev = model.anchors.device
     pts, offs, sizes = _batch([synth.cloud_ring(2000 + f) for f in range(model.B)], dev)
+    hoffs = [int(v) for v in np.concatenate([[0], np.cumsum(sizes)])]
     out = {}
     keep = model.resident_voxels
     with torch.no_grad():
         for mode, resident in (("resident", True), ("contract", False)):
             model.resident_voxels = resident
             for _ in range(2):
-                model(pts, offs)
+                model(pts, offs, hoffs)
             evs = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(10)]
             for a, b in evs:
                 a.record()
-                vox = model.voxelize(pts, offs)
+                vox = model.voxelize(pts, offs, hoffs)
                 b.record()
                 model.post_process(*model.backbone_head(model.vfe_scatter(vox)))
             torch.cuda.synchronize()
             out[f"{mode}_us"] = float(np.mean([a.elapsed_time(b) for a, b in evs])) * 1e3
         out["rows"] = int(vox["voxel_offsets"][-1].item())
     model.resident_voxels = keep
-    model(pts, offs)
+    model(pts, offs, hoffs)
     return {"voxelize_ring_cloud": dict(out, note="HIP-event bracket of lidar_voxelize inside full steps, cloud_ring(2000..2015), 16 frames")}
 
 
