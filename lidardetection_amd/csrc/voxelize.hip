@@ -498,8 +498,15 @@ __device__ __forceinline__ uint32_t vx_key2(const VxParams &p, float x, float y,
 
 // rows (= voxels kept) of frame k: one count per bin, left by the bin workgroups with plain stores
 __device__ __forceinline__ int vxl_frame_rows(const VxParams &p, const VxWs &w, int G, int k) {
+    // G is 8, 16 or 32: all of a frame's counts are requested together, as 16-byte loads (a scalar loop over G entries is G
+    // dependent round trips — the emit workgroups' first barrier waited 3 k cycles for the wave that sums the earlier frames)
+    const int4 *q = reinterpret_cast<const int4 *>(w.bvox + k * VXL_GMAX);
+    int4 v[VXL_GMAX / 4];
+#pragma unroll
+    for (int i = 0; i < VXL_GMAX / 4; ++i) v[i] = (i * 4 < G) ? q[i] : make_int4(0, 0, 0, 0);
     int c = 0;
-    for (int g = 0; g < G; ++g) c += w.bvox[k * VXL_GMAX + g];
+#pragma unroll
+    for (int i = 0; i < VXL_GMAX / 4; ++i) c += v[i].x + v[i].y + v[i].z + v[i].w;
     return min(c, p.max_voxels);
 }
 
@@ -1037,16 +1044,17 @@ __global__ __launch_bounds__(1024, 8) void vxl_emit_kernel(const float *__restri
         const int c = w.tcnt[(size_t)f * G * 32 + t];
         v = (tau < tile) ? c : 0;
     }
+    // rows of the earlier frames (every frame's count is complete: the first launch has finished) — requested by wave 15 BEFORE
+    // anybody waits for the per-tile counts above, so that the two are one round trip, not two
+    int part = 0;
+    if (wv == 15 && p.compact)
+        for (int k0 = 0; k0 < f; k0 += 64) {
+            const int k = k0 + l;
+            part += (k < f) ? vxl_frame_rows(p, w, G, k) : 0;
+        }
     v = wave_sum(v);
     if (l == 0) s_part[wv] = v;
-    // rows of the earlier frames (every frame's count is complete: the first launch has finished)
     if (wv == 15) {
-        int part = 0;
-        if (p.compact)
-            for (int k0 = 0; k0 < f; k0 += 64) {
-                const int k = k0 + l;
-                part += (k < f) ? vxl_frame_rows(p, w, G, k) : 0;
-            }
         part = wave_sum(part);
         if (l == 0) s_base = p.compact ? part : f * p.max_voxels;
     }
