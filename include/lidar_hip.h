@@ -24,6 +24,7 @@ extern "C" {
 #define LIDAR_ERR_ARG (-1)
 #define LIDAR_ERR_LAUNCH (-2)
 #define LIDAR_ERR_WORKSPACE (-3)
+#define LIDAR_ERR_UNSUPPORTED (-4) /* an optional library-backed path is not available: keep the other path */
 
 /* ------------------------------------------------------------------ voxelisation
  * Replaces spconv.utils.VoxelGeneratorV2.generate (external, un-vendored; call site
@@ -342,6 +343,13 @@ int lidar_bias_act_nhwc(const float *in, const float *bias, long long n_pix, int
  * in (batch*h*w, s*s*C) with column order (ky, kx, c); out[b][s*y+ky][s*x+kx][out_off + c] = act(in + bias[c]). */
 int lidar_bias_act_upsample_nhwc(const float *in, const float *bias, int batch, int h, int w, int s, int C, int relu,
                                  float *out, int out_C, int out_off, void *stream);
+/* A ConvTranspose2d / Conv2d with kernel == stride == 1 (the first deblock, base_bev_backbone.py:58-77) + folded BatchNorm +
+ * ReLU as ONE library GEMM (hipBLASLt, RELU_BIAS epilogue) writing with a leading dimension:
+ * D[m][0..N) = act(A (M, K) @ W (K, N) + bias (N)), row m of D at D + m * ldd — i.e. straight into the layer's channel slice
+ * of the concatenated NHWC map (base_bev_backbone.py:103).  ws: scratch for the library (may be null / 0).  Returns
+ * LIDAR_ERR_UNSUPPORTED when the library is not loadable or has no kernel for the problem. */
+int lidar_dense_gemm_bias_act(const float *A, long long M, int K, const float *W, int N, const float *bias, int relu,
+                              float *D, int ldd, void *ws, size_t ws_bytes, void *stream);
 
 /* ------------------------------------------------------------------ anchor-head post-processing feeding NMS (8f rank 1)
  * head: (n_loc = B*H*W, row_stride) rows of the merged head output [cls | box | dir] as the 1x1 heads emit it

@@ -87,6 +87,7 @@ SIGNATURES = {
     "lidar_sparse_to_bev_nhwc": (i32, [vp, vp, i32, i32, i32, i32, i32, i32, vp, vp, sz, vp]),
     "lidar_bias_act_nhwc": (i32, [vp, vp, C.c_longlong, i32, i32, vp, i32, i32, vp]),
     "lidar_bias_act_upsample_nhwc": (i32, [vp, vp, i32, i32, i32, i32, i32, i32, vp, i32, i32, vp]),
+    "lidar_dense_gemm_bias_act": (i32, [vp, C.c_longlong, i32, vp, i32, vp, i32, vp, i32, vp, sz, vp]),
     "lidar_anchor_scores": (i32, [vp, C.c_longlong, i32, i32, i32, i32, f32, vp, vp, vp]),
     "lidar_decode_topk": (i32, [vp, i32, C.c_longlong, i32, i32, i32, i32, i32, vp, i32, vp, f32, f32, f32, vp, vp]),
     "lidar_topk_workspace_bytes": (sz, [i32, C.c_longlong]),

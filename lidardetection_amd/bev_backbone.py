@@ -13,11 +13,14 @@ The convolutions stay stock torch (MIOpen, fp32, channels-last).  What changes i
     384-channel map once (one merged GEMM, torch.addmm) instead of three times.
 Results match the unfolded modules to fp32 rounding (folding re-associates one multiply); tests assert 1e-4.
 """
+import ctypes as C
+import os
+
 import torch
 import torch.nn as nn
 import torch.nn.functional as F
 
-from . import _lib
+from . import _lib, workspace
 
 
 def bias_act_(x, bias, relu=True, out=None, out_offset=0):
@@ -34,6 +37,32 @@ def bias_act_(x, bias, relu=True, out=None, out_offset=0):
     _lib.check(_lib.lib().lidar_bias_act_nhwc(_lib.ptr(x), _lib.ptr(bias), B * H * W, C, int(bool(relu)), _lib.ptr(out),
                                               out.shape[1], int(out_offset), _lib.stream()), "lidar_bias_act_nhwc")
     return out
+
+
+_LT_GEMM = [os.environ.get("LIDAR_BEV_LT_GEMM", "1") != "0"]      # the fused stride-1 deblock (csrc/dense_gemm.hip); A/B switch
+
+
+def gemm_bias_act_into_(x, w_kn, bias, out, out_offset, relu=True):
+    """x (B, K, h, w) channels-last, w_kn (K, N), bias (N): out[:, out_offset:out_offset+N] = act(x_rows @ w_kn + bias) with `out`
+    (B, C_out, h, w) channels-last — one hipBLASLt GEMM whose epilogue writes at the map's row pitch (lidar_dense_gemm_bias_act).
+    Returns False when the library path is not available (nothing written)."""
+    _lib.require_cuda(w_kn, bias)
+    if not (x.is_cuda and out.is_cuda and x.dtype == torch.float32 and out.dtype == torch.float32):
+        raise _lib.LidarHipError("gemm_bias_act_into_: expected float32 CUDA (ROCm) tensors")
+    B, K, h, w = x.shape
+    N = w_kn.shape[1]
+    if (not x.is_contiguous(memory_format=torch.channels_last) or not out.is_contiguous(memory_format=torch.channels_last)
+            or out.shape[0] != B or out.shape[2:] != x.shape[2:] or w_kn.shape[0] != K or bias.numel() != N
+            or out_offset + N > out.shape[1] or not w_kn.is_contiguous()):
+        raise _lib.LidarHipError("gemm_bias_act_into_: shapes / layouts do not match")
+    ws = workspace.get("dense_gemm", 32 << 20, x.device)
+    st = _lib.lib().lidar_dense_gemm_bias_act(_lib.ptr(x), B * h * w, K, _lib.ptr(w_kn), N, _lib.ptr(bias), int(bool(relu)),
+                                              C.c_void_p(out.data_ptr() + 4 * out_offset), out.shape[1], _lib.ptr(ws), ws.numel(),
+                                              _lib.stream())
+    if st == -4:                                   # LIDAR_ERR_UNSUPPORTED
+        return False
+    _lib.check(st, "lidar_dense_gemm_bias_act")
+    return True
 
 
 def bias_act_upsample_(y2d, bias, batch, h, w, s, out, out_offset=0, relu=True):
@@ -129,9 +158,11 @@ class FoldedBEVBackbone:
                     x = x.contiguous(memory_format=torch.channels_last)
                 bias_act_(x, b)
             B, _, h, w = x.shape
+            y = None
             if kind == "gemm":
-                y = torch.mm(x.permute(0, 2, 3, 1).reshape(B * h * w, -1), uw)      # the NHWC map IS the row-major A
                 oh, ow = h * ustride, w * ustride
+                if not (ustride == 1 and _LT_GEMM[0]):
+                    y = torch.mm(x.permute(0, 2, 3, 1).reshape(B * h * w, -1), uw)  # the NHWC map IS the row-major A
             else:
                 y = F.conv_transpose2d(x, uw, None, ustride) if kind == "deconv" else F.conv2d(x, uw, None, ustride)
                 if not y.is_contiguous(memory_format=torch.channels_last):
@@ -143,8 +174,14 @@ class FoldedBEVBackbone:
                     self._cat = torch.empty(shape, dtype=torch.float32, device=x.device,
                                             memory_format=torch.channels_last)
                 cat = self._cat
+            if kind == "gemm" and y is None:
+                # stride 1: GEMM + shift + ReLU + concat in ONE hipBLASLt call writing with the map's row pitch
+                if not gemm_bias_act_into_(x, uw, ub, cat, off):
+                    _LT_GEMM[0] = False                                             # not available here: the two-step path from now on
+                    y = torch.mm(x.permute(0, 2, 3, 1).reshape(B * h * w, -1), uw)
             if kind == "gemm":
-                bias_act_upsample_(y, ub, B, h, w, ustride, cat, off)
+                if y is not None:
+                    bias_act_upsample_(y, ub, B, h, w, ustride, cat, off)
             else:
                 bias_act_(y, ub, out=cat, out_offset=off)
             off += ub.numel()

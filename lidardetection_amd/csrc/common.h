@@ -8,6 +8,7 @@
 #define LIDAR_ERR_ARG (-1)
 #define LIDAR_ERR_LAUNCH (-2)
 #define LIDAR_ERR_WORKSPACE (-3)
+#define LIDAR_ERR_UNSUPPORTED (-4)   // an optional library path is not available here: the caller keeps its other path
 
 #define LIDAR_EXPORT extern "C" __attribute__((visibility("default")))
 

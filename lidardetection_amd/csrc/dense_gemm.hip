@@ -1,0 +1,119 @@
+// Deblock 1 of BaseBEVBackbone (ConvTranspose2d with kernel == stride == 1, i.e. a 1x1 convolution followed by BatchNorm + ReLU:
+// pcdet/models/backbones_2d/base_bev_backbone.py:58-77,96-103) as ONE plain library GEMM whose epilogue adds the folded shift,
+// applies ReLU and writes with a leading dimension — straight into the layer's channel slice of the concatenated NHWC map.
+// torch.mm cannot take a strided output (it writes a temporary and copies), so the GEMM + this repo's bias/ReLU/concat pass were
+// 214 + 176 us; hipBLASLt with the RELU_BIAS epilogue and ldd = 384 does both in the GEMM's time.  "hipBLASLt only for plain
+// library GEMMs": this is one.  The library is the copy already loaded in the process (PyTorch's), resolved at run time — no
+// link-time dependency; when it cannot be found or refuses the problem the call returns LIDAR_ERR_UNSUPPORTED and the host keeps
+// the two-step path.
+#include "common.h"
+#include <dlfcn.h>
+#include <hipblaslt/hipblaslt.h>
+#include <mutex>
+#include <vector>
+
+namespace {
+struct LtApi {
+    decltype(&hipblasLtCreate) create = nullptr;
+    decltype(&hipblasLtMatmulDescCreate) desc_create = nullptr;
+    decltype(&hipblasLtMatmulDescSetAttribute) desc_set = nullptr;
+    decltype(&hipblasLtMatrixLayoutCreate) layout_create = nullptr;
+    decltype(&hipblasLtMatmulPreferenceCreate) pref_create = nullptr;
+    decltype(&hipblasLtMatmulPreferenceSetAttribute) pref_set = nullptr;
+    decltype(&hipblasLtMatmulAlgoGetHeuristic) heuristic = nullptr;
+    decltype(&hipblasLtMatmul) matmul = nullptr;
+    bool ok = false;
+};
+
+LtApi *lt_api() {
+    static LtApi api;
+    static std::once_flag once;
+    std::call_once(once, [] {
+        void *h = dlopen("libhipblaslt.so.1", RTLD_NOW | RTLD_NOLOAD);      // the copy the process already uses, if any
+        if (!h) h = dlopen("libhipblaslt.so.1", RTLD_NOW);
+        if (!h) h = dlopen("libhipblaslt.so", RTLD_NOW);
+        if (!h) return;
+#define LT_SYM(field, name) api.field = reinterpret_cast<decltype(api.field)>(dlsym(h, name))
+        LT_SYM(create, "hipblasLtCreate");
+        LT_SYM(desc_create, "hipblasLtMatmulDescCreate");
+        LT_SYM(desc_set, "hipblasLtMatmulDescSetAttribute");
+        LT_SYM(layout_create, "hipblasLtMatrixLayoutCreate");
+        LT_SYM(pref_create, "hipblasLtMatmulPreferenceCreate");
+        LT_SYM(pref_set, "hipblasLtMatmulPreferenceSetAttribute");
+        LT_SYM(heuristic, "hipblasLtMatmulAlgoGetHeuristic");
+        LT_SYM(matmul, "hipblasLtMatmul");
+#undef LT_SYM
+        api.ok = api.create && api.desc_create && api.desc_set && api.layout_create && api.pref_create && api.pref_set &&
+                 api.heuristic && api.matmul;
+    });
+    return &api;
+}
+
+struct LtPlan {
+    long long M;
+    int K, N, ldd, relu;
+    size_t ws_bytes;
+    hipblasLtMatmulDesc_t desc;
+    hipblasLtMatrixLayout_t la, lb, ld;
+    hipblasLtMatmulAlgo_t algo;
+    size_t algo_ws;
+    bool usable;
+};
+std::mutex g_mu;
+std::vector<LtPlan> g_plans;           // a handful of shapes per process, kept for its lifetime
+hipblasLtHandle_t g_handle = nullptr;
+}  // namespace
+
+// D (M x N, row-major, row pitch ldd floats) = act(A (M x K, row-major, dense) @ W (K x N, row-major, dense) + bias (N)).
+// In the library's column-major terms: D^T (N x M, ld = ldd) = W^T (N x K, ld = N) * A^T (K x M, ld = K).
+LIDAR_EXPORT int lidar_dense_gemm_bias_act(const float *A, long long M, int K, const float *W, int N, const float *bias, int relu,
+                                           float *D, int ldd, void *ws, size_t ws_bytes, void *stream) {
+    if (!A || !W || !bias || !D || M <= 0 || K <= 0 || N <= 0 || ldd < N) return LIDAR_ERR_ARG;
+    LtApi *api = lt_api();
+    if (!api->ok) return LIDAR_ERR_UNSUPPORTED;
+    std::lock_guard<std::mutex> lock(g_mu);
+    if (!g_handle && api->create(&g_handle) != HIPBLAS_STATUS_SUCCESS) return LIDAR_ERR_UNSUPPORTED;
+    LtPlan *plan = nullptr;
+    for (auto &q : g_plans)
+        if (q.M == M && q.K == K && q.N == N && q.ldd == ldd && q.relu == (relu != 0) && q.ws_bytes == ws_bytes) plan = &q;
+    if (!plan) {
+        LtPlan q{};
+        q.M = M; q.K = K; q.N = N; q.ldd = ldd; q.relu = relu != 0; q.ws_bytes = ws_bytes; q.usable = false;
+        bool ok = api->desc_create(&q.desc, HIPBLAS_COMPUTE_32F, HIP_R_32F) == HIPBLAS_STATUS_SUCCESS;
+        const hipblasOperation_t opn = HIPBLAS_OP_N;
+        const hipblasLtEpilogue_t epi = relu ? HIPBLASLT_EPILOGUE_RELU_BIAS : HIPBLASLT_EPILOGUE_BIAS;
+        const int32_t bias_type = (int32_t)HIP_R_32F;
+        ok = ok && api->desc_set(q.desc, HIPBLASLT_MATMUL_DESC_TRANSA, &opn, sizeof(opn)) == HIPBLAS_STATUS_SUCCESS;
+        ok = ok && api->desc_set(q.desc, HIPBLASLT_MATMUL_DESC_TRANSB, &opn, sizeof(opn)) == HIPBLAS_STATUS_SUCCESS;
+        ok = ok && api->desc_set(q.desc, HIPBLASLT_MATMUL_DESC_EPILOGUE, &epi, sizeof(epi)) == HIPBLAS_STATUS_SUCCESS;
+        ok = ok && api->desc_set(q.desc, HIPBLASLT_MATMUL_DESC_BIAS_DATA_TYPE, &bias_type, sizeof(bias_type)) == HIPBLAS_STATUS_SUCCESS;
+        ok = ok && api->layout_create(&q.la, HIP_R_32F, (uint64_t)N, (uint64_t)K, (int64_t)N) == HIPBLAS_STATUS_SUCCESS;
+        ok = ok && api->layout_create(&q.lb, HIP_R_32F, (uint64_t)K, (uint64_t)M, (int64_t)K) == HIPBLAS_STATUS_SUCCESS;
+        ok = ok && api->layout_create(&q.ld, HIP_R_32F, (uint64_t)N, (uint64_t)M, (int64_t)ldd) == HIPBLAS_STATUS_SUCCESS;
+        if (ok) {
+            // the heuristic looks at the epilogue's bias pointer being set, not at its value
+            ok = api->desc_set(q.desc, HIPBLASLT_MATMUL_DESC_BIAS_POINTER, &bias, sizeof(bias)) == HIPBLAS_STATUS_SUCCESS;
+            hipblasLtMatmulPreference_t pref = nullptr;
+            ok = ok && api->pref_create(&pref) == HIPBLAS_STATUS_SUCCESS;
+            const uint64_t max_ws = ws ? (uint64_t)ws_bytes : 0;
+            ok = ok && api->pref_set(pref, HIPBLASLT_MATMUL_PREF_MAX_WORKSPACE_BYTES, &max_ws, sizeof(max_ws)) == HIPBLAS_STATUS_SUCCESS;
+            hipblasLtMatmulHeuristicResult_t res[1];
+            int found = 0;
+            ok = ok && api->heuristic(g_handle, q.desc, q.la, q.lb, q.ld, q.ld, pref, 1, res, &found) == HIPBLAS_STATUS_SUCCESS;
+            if (ok && found > 0 && res[0].workspaceSize <= max_ws) {
+                q.algo = res[0].algo;
+                q.algo_ws = res[0].workspaceSize;
+                q.usable = true;
+            }
+        }
+        g_plans.push_back(q);
+        plan = &g_plans.back();
+    }
+    if (!plan->usable) return LIDAR_ERR_UNSUPPORTED;
+    if (api->desc_set(plan->desc, HIPBLASLT_MATMUL_DESC_BIAS_POINTER, &bias, sizeof(bias)) != HIPBLAS_STATUS_SUCCESS)
+        return LIDAR_ERR_UNSUPPORTED;
+    const float alpha = 1.f, beta = 0.f;
+    const hipblasStatus_t st = api->matmul(g_handle, plan->desc, &alpha, W, plan->la, A, plan->lb, &beta, D, plan->ld, D, plan->ld,
+                                           &plan->algo, ws, plan->algo_ws, (hipStream_t)stream);
+    return st == HIPBLAS_STATUS_SUCCESS ? LIDAR_OK : LIDAR_ERR_LAUNCH;
+}
