@@ -42,9 +42,21 @@ def bias_act_(x, bias, relu=True, out=None, out_offset=0):
 _LT_GEMM = [os.environ.get("LIDAR_BEV_LT_GEMM", "1") != "0"]      # the fused stride-1 deblock (csrc/dense_gemm.hip); A/B switch
 
 
+def _lt_gemm(a_ptr, M, K, w_kn, bias, relu, d_ptr, ldd, device):
+    """D (M rows at pitch ldd) = act(A (M, K) @ w_kn (K, N) + bias): lidar_dense_gemm_bias_act (hipBLASLt, candidates timed once
+    per shape).  False: the library path is not available (nothing written)."""
+    ws = workspace.get("dense_gemm", 32 << 20, device)
+    st = _lib.lib().lidar_dense_gemm_bias_act(a_ptr, M, K, _lib.ptr(w_kn), w_kn.shape[1], _lib.ptr(bias), int(bool(relu)), d_ptr, ldd,
+                                              _lib.ptr(ws), ws.numel(), _lib.stream())
+    if st == -4:                                   # LIDAR_ERR_UNSUPPORTED
+        return False
+    _lib.check(st, "lidar_dense_gemm_bias_act")
+    return True
+
+
 def gemm_bias_act_into_(x, w_kn, bias, out, out_offset, relu=True):
     """x (B, K, h, w) channels-last, w_kn (K, N), bias (N): out[:, out_offset:out_offset+N] = act(x_rows @ w_kn + bias) with `out`
-    (B, C_out, h, w) channels-last — one hipBLASLt GEMM whose epilogue writes at the map's row pitch (lidar_dense_gemm_bias_act).
+    (B, C_out, h, w) channels-last — one hipBLASLt GEMM whose epilogue writes at the map's row pitch.
     Returns False when the library path is not available (nothing written)."""
     _lib.require_cuda(w_kn, bias)
     if not (x.is_cuda and out.is_cuda and x.dtype == torch.float32 and out.dtype == torch.float32):
@@ -55,14 +67,18 @@ def gemm_bias_act_into_(x, w_kn, bias, out, out_offset, relu=True):
             or out.shape[0] != B or out.shape[2:] != x.shape[2:] or w_kn.shape[0] != K or bias.numel() != N
             or out_offset + N > out.shape[1] or not w_kn.is_contiguous()):
         raise _lib.LidarHipError("gemm_bias_act_into_: shapes / layouts do not match")
-    ws = workspace.get("dense_gemm", 32 << 20, x.device)
-    st = _lib.lib().lidar_dense_gemm_bias_act(_lib.ptr(x), B * h * w, K, _lib.ptr(w_kn), N, _lib.ptr(bias), int(bool(relu)),
-                                              C.c_void_p(out.data_ptr() + 4 * out_offset), out.shape[1], _lib.ptr(ws), ws.numel(),
-                                              _lib.stream())
-    if st == -4:                                   # LIDAR_ERR_UNSUPPORTED
-        return False
-    _lib.check(st, "lidar_dense_gemm_bias_act")
-    return True
+    return _lt_gemm(_lib.ptr(x), B * h * w, K, w_kn, bias, relu, C.c_void_p(out.data_ptr() + 4 * out_offset), out.shape[1], x.device)
+
+
+def rows_gemm(a2d, w_kn, bias=None):
+    """a2d (M, K) @ w_kn (K, N) (+ bias) -> (M, N): the library GEMM with its candidates timed once per shape; torch.mm / addmm
+    when that path is not available."""
+    if _LT_GEMM[0] and a2d.is_cuda and a2d.dtype == torch.float32 and a2d.is_contiguous() and w_kn.is_contiguous():
+        out = torch.empty((a2d.shape[0], w_kn.shape[1]), dtype=torch.float32, device=a2d.device)
+        if _lt_gemm(_lib.ptr(a2d), a2d.shape[0], a2d.shape[1], w_kn, bias, False, _lib.ptr(out), w_kn.shape[1], a2d.device):
+            return out
+        _LT_GEMM[0] = False
+    return torch.mm(a2d, w_kn) if bias is None else torch.addmm(bias, a2d, w_kn)
 
 
 def bias_act_upsample_(y2d, bias, batch, h, w, s, out, out_offset=0, relu=True):
@@ -162,7 +178,7 @@ class FoldedBEVBackbone:
             if kind == "gemm":
                 oh, ow = h * ustride, w * ustride
                 if not (ustride == 1 and _LT_GEMM[0]):
-                    y = torch.mm(x.permute(0, 2, 3, 1).reshape(B * h * w, -1), uw)  # the NHWC map IS the row-major A
+                    y = rows_gemm(x.permute(0, 2, 3, 1).reshape(B * h * w, -1), uw)  # the NHWC map IS the row-major A
             else:
                 y = F.conv_transpose2d(x, uw, None, ustride) if kind == "deconv" else F.conv2d(x, uw, None, ustride)
                 if not y.is_contiguous(memory_format=torch.channels_last):
@@ -178,7 +194,7 @@ class FoldedBEVBackbone:
                 # stride 1: GEMM + shift + ReLU + concat in ONE hipBLASLt call writing with the map's row pitch
                 if not gemm_bias_act_into_(x, uw, ub, cat, off):
                     _LT_GEMM[0] = False                                             # not available here: the two-step path from now on
-                    y = torch.mm(x.permute(0, 2, 3, 1).reshape(B * h * w, -1), uw)
+                    y = rows_gemm(x.permute(0, 2, 3, 1).reshape(B * h * w, -1), uw)
             if kind == "gemm":
                 if y is not None:
                     bias_act_upsample_(y, ub, B, h, w, ustride, cat, off)
@@ -194,7 +210,7 @@ class FoldedBEVBackbone:
         """-> the merged head output (B, H, W, sum C_head), channels [cls | box | dir] as the heads were given."""
         cat = self.features(canvas)
         B, C, H, W = cat.shape
-        out = torch.addmm(self.head_b, cat.permute(0, 2, 3, 1).reshape(B * H * W, C), self.head_wt)   # 1x1 heads = one GEMM
+        out = rows_gemm(cat.permute(0, 2, 3, 1).reshape(B * H * W, C), self.head_wt, self.head_b)     # 1x1 heads = one GEMM
         return out.view(B, H, W, -1)
 
     def __call__(self, canvas):
