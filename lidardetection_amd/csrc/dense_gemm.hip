@@ -110,7 +110,9 @@ LIDAR_EXPORT int lidar_dense_gemm_bias_act(const float *A, long long M, int K, c
             // every candidate is run on the caller's own operands (the result is the same whichever runs last) and timed with
             // events; that call synchronises the stream.  LIDAR_LT_AUTOTUNE=0 keeps the first pick.
             static const bool autotune = !(getenv("LIDAR_LT_AUTOTUNE") && atoi(getenv("LIDAR_LT_AUTOTUNE")) == 0);
-            if (best >= 0 && autotune && found > 1) {
+            hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;      // (a capturing stream must not be synchronised: first pick)
+            (void)hipStreamIsCapturing((hipStream_t)stream, &cap);
+            if (best >= 0 && autotune && found > 1 && cap == hipStreamCaptureStatusNone) {
                 hipStream_t s = (hipStream_t)stream;
                 hipEvent_t e0, e1;
                 const float one = 1.f, zero = 0.f;
