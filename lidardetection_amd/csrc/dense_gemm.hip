@@ -62,7 +62,8 @@ struct LtPlan {
 };
 std::mutex g_mu;
 std::vector<LtPlan> g_plans;           // a handful of shapes per process, kept for its lifetime
-hipblasLtHandle_t g_handle = nullptr;
+std::vector<std::pair<void *, hipblasLtHandle_t>> g_handles;   // one library handle per stream: a handle's internal buffers are not
+                                                                // meant for two streams at once (the split backbone runs two)
 }  // namespace
 
 // D (M x N, row-major, row pitch ldd floats) = act(A (M x K, row-major, dense) @ W (K x N, row-major, dense) + bias (N)).
@@ -73,7 +74,13 @@ LIDAR_EXPORT int lidar_dense_gemm_bias_act(const float *A, long long M, int K, c
     LtApi *api = lt_api();
     if (!api->ok) return LIDAR_ERR_UNSUPPORTED;
     std::lock_guard<std::mutex> lock(g_mu);
-    if (!g_handle && api->create(&g_handle) != HIPBLAS_STATUS_SUCCESS) return LIDAR_ERR_UNSUPPORTED;
+    hipblasLtHandle_t g_handle = nullptr;
+    for (auto &hs : g_handles)
+        if (hs.first == stream) g_handle = hs.second;
+    if (!g_handle) {
+        if (api->create(&g_handle) != HIPBLAS_STATUS_SUCCESS) return LIDAR_ERR_UNSUPPORTED;
+        g_handles.emplace_back(stream, g_handle);
+    }
     LtPlan *plan = nullptr;
     for (auto &q : g_plans)
         if (q.M == M && q.K == K && q.N == N && q.ldd == ldd && q.relu == (relu != 0) && q.has_bias == (bias != nullptr) && q.ws_bytes == ws_bytes) plan = &q;
