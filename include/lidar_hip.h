@@ -70,6 +70,14 @@ int lidar_voxelize_hostoff(const float *points, const int *point_offsets, const 
                            int num_features, const float *range6, const float *voxel_size3, const int *grid3, int max_points,
                            int max_voxels, int compact, int algo, float *voxels, int *coords, int *num_points,
                            int *voxel_offsets, void *ws, size_t ws_bytes, void *stream);
+/* Measurement only: a timer = two HIP events carried by the launches themselves (hipExtLaunchKernel's start / stop events):
+ * the time from the start of the call's first kernel to the end of its last one, as a kernel trace would report it, without the
+ * marker / queue overhead of a hipEventRecord bracket around the call.  lidar_voxelize_time_next arms `timer` for the calling
+ * thread's next lidar_voxelize(_hostoff) call (LDS-binned path); lidar_timer_elapsed_ms waits for the stop event. */
+void *lidar_timer_create(void);
+void lidar_timer_destroy(void *timer);
+void lidar_voxelize_time_next(void *timer);
+float lidar_timer_elapsed_ms(void *timer);
 /* optional: a device-visible HOST int (pinned + mapped memory) that receives the same error bits, so the caller can poll
  * the flag without a copy or a synchronisation (nullptr unregisters).  Cleared by the caller. */
 int lidar_voxelize_set_error_mirror(void *ws, size_t ws_bytes, int batch, int n_max, int max_voxels, int *host_flag,

@@ -18,6 +18,10 @@ SIGNATURES = {
     "lidar_voxelize": (i32, [vp, vp, i32, i32, i32, vp, vp, vp, i32, i32, i32, i32, vp, vp, vp, vp, vp, sz, vp]),
     "lidar_voxelize_hostoff": (i32, [vp, vp, vp, i32, i32, i32, vp, vp, vp, i32, i32, i32, i32, vp, vp, vp, vp, vp, sz, vp]),
     "lidar_voxelize_error_flag": (i32, [vp, sz, i32, i32, i32]),
+    "lidar_timer_create": (vp, []),
+    "lidar_timer_destroy": (None, [vp]),
+    "lidar_voxelize_time_next": (None, [vp]),
+    "lidar_timer_elapsed_ms": (C.c_float, [vp]),
     "lidar_voxelize_set_error_mirror": (i32, [vp, sz, i32, i32, i32, vp, vp]),
     "lidar_pillar_vfe": (i32, [vp, vp, vp, i32, vp, i32, i32, vp, vp, vp, i32, vp, vp, i32, i32, i32, vp, vp]),
     "lidar_mean_vfe": (i32, [vp, vp, i32, i32, i32, i32, vp, vp]),

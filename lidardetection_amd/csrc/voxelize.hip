@@ -18,6 +18,7 @@
 //   vx_rows   : writes every padded voxel row exactly once with 16-B/lane stores (zeros included),
 //               coords + counts, and restores the workspace (hash table, lists) to its clean state
 #include "common.h"
+#include <hip/hip_ext.h>
 #include <stdlib.h>
 #include <type_traits>
 
@@ -1178,6 +1179,9 @@ static int vxl_env_int(const char *name, int dflt) {
     return e ? atoi(e) : dflt;
 }
 
+struct VxTimer { hipEvent_t a, b; };
+static thread_local VxTimer *g_next_timer = nullptr;
+
 // bin + fill launch, then emit: 2 launches
 static void vxl_run_fused(const float *points, const int *point_offsets, const VxParams &p, const VxWs &w, bool c4,
                           float *voxels, int *coords, int *num_points, int *voxel_offsets, hipStream_t s, int resident) {
@@ -1198,12 +1202,19 @@ static void vxl_run_fused(const float *points, const int *point_offsets, const V
 #else
     const bool emit_only = false;
 #endif
+    // a timer armed for this call (lidar_voxelize_time_next): the first launch carries its start event, the second its stop event —
+    // timestamps of the dispatches themselves (what a kernel trace reports), free of the event-marker and queue overhead that a
+    // hipEventRecord bracket around the call adds (4.7-5.5 us, more when other streams are alive in the process)
+    VxTimer *tm = g_next_timer;
+    g_next_timer = nullptr;
+    hipEvent_t ev_a = tm ? tm->a : nullptr, ev_b = tm ? tm->b : nullptr;
+    const dim3 g1(nbinwg + nfillwg), blk(1024);
     if (emit_only) {}
-    else if (c4) hipLaunchKernelGGL(vxl_keybin_kernel<true>, dim3(nbinwg + nfillwg), dim3(1024), 0, s, points, point_offsets, p, w, G, nbinwg, nfillwg, voxels, total_f4, tf, help16, resident, num_points);
-    else hipLaunchKernelGGL(vxl_keybin_kernel<false>, dim3(nbinwg + nfillwg), dim3(1024), 0, s, points, point_offsets, p, w, G, nbinwg, nfillwg, voxels, total_f4, tf, help16, resident, num_points);
+    else if (c4) hipExtLaunchKernelGGL(vxl_keybin_kernel<true>, g1, blk, 0, s, ev_a, nullptr, 0, points, point_offsets, p, w, G, nbinwg, nfillwg, voxels, total_f4, tf, help16, resident, (const int *)num_points);
+    else hipExtLaunchKernelGGL(vxl_keybin_kernel<false>, g1, blk, 0, s, ev_a, nullptr, 0, points, point_offsets, p, w, G, nbinwg, nfillwg, voxels, total_f4, tf, help16, resident, (const int *)num_points);
     const dim3 ge(ntiles, p.batch);
-    if (c4) hipLaunchKernelGGL(vxl_emit_kernel<true>, ge, dim3(1024), 0, s, points, point_offsets, p, w, G, voxels, coords, num_points, voxel_offsets, resident);
-    else hipLaunchKernelGGL(vxl_emit_kernel<false>, ge, dim3(1024), 0, s, points, point_offsets, p, w, G, voxels, coords, num_points, voxel_offsets, resident);
+    if (c4) hipExtLaunchKernelGGL(vxl_emit_kernel<true>, ge, blk, 0, s, nullptr, ev_b, 0, points, point_offsets, p, w, G, voxels, coords, num_points, voxel_offsets, resident);
+    else hipExtLaunchKernelGGL(vxl_emit_kernel<false>, ge, blk, 0, s, nullptr, ev_b, 0, points, point_offsets, p, w, G, voxels, coords, num_points, voxel_offsets, resident);
 }
 
 // ------------------------------------------------------------------ C ABI
@@ -1332,4 +1343,28 @@ LIDAR_EXPORT int lidar_voxelize_hostoff(const float *points, const int *point_of
         hipLaunchKernelGGL(vx_rows_kernel<false>, grow, dim3(256), 0, s, points, point_offsets, p, w, voxels, coords,
                            num_points, voxel_offsets, row_blocks);
     return lidar_check_launch("lidar_voxelize");
+}
+
+// ------------------------------------------------------------------ launch timer (measurement only)
+LIDAR_EXPORT void *lidar_timer_create(void) {
+    VxTimer *t = new VxTimer{nullptr, nullptr};
+    if (hipEventCreate(&t->a) != hipSuccess || hipEventCreate(&t->b) != hipSuccess) { delete t; return nullptr; }
+    return t;
+}
+LIDAR_EXPORT void lidar_timer_destroy(void *timer) {
+    VxTimer *t = (VxTimer *)timer;
+    if (!t) return;
+    (void)hipEventDestroy(t->a);
+    (void)hipEventDestroy(t->b);
+    delete t;
+}
+// the calling thread's NEXT lidar_voxelize / lidar_voxelize_hostoff call (LDS-binned path) records its first launch's start and its
+// last launch's end into `timer`
+LIDAR_EXPORT void lidar_voxelize_time_next(void *timer) { g_next_timer = (VxTimer *)timer; }
+// waits for the stop event; milliseconds from the start of the first launch to the end of the last one (< 0: not recorded)
+LIDAR_EXPORT float lidar_timer_elapsed_ms(void *timer) {
+    VxTimer *t = (VxTimer *)timer;
+    float ms = -1.f;
+    if (!t || hipEventSynchronize(t->b) != hipSuccess || hipEventElapsedTime(&ms, t->a, t->b) != hipSuccess) return -1.f;
+    return ms;
 }

@@ -136,10 +136,10 @@ class PointPillarKITTI(nn.Module):
         return self._bev
 
     # ---- stages (kept separate so bench.py can time them) ------------------------------------
-    def voxelize(self, points, point_offsets, host_offsets=None):
+    def voxelize(self, points, point_offsets, host_offsets=None, timer=None):
         """host_offsets: the same offsets on the host, when the caller has them (kernel arguments instead of a dependent load)"""
         return self.voxelizer(points, point_offsets, self.n_max, compact=True, out=self._vox_out, resident=self.resident_voxels,
-                              host_offsets=host_offsets)
+                              host_offsets=host_offsets, timer=timer)
 
     def vfe_scatter(self, vox):
         w, s, t = self._pfn_folded()

@@ -73,7 +73,7 @@ class BatchVoxelizer:
             "voxel_offsets": torch.empty((batch + 1,), dtype=torch.int32, device=device),
         }
 
-    def __call__(self, points, point_offsets, n_max, compact=True, out=None, resident=False, host_offsets=None):
+    def __call__(self, points, point_offsets, n_max, compact=True, out=None, resident=False, host_offsets=None, timer=None):
         """points (sum N, C) f32 cuda; point_offsets (B+1) int32 cuda; n_max >= max frame size (host int).
         Returns dict(voxels, voxel_coords [b,z,y,x], voxel_num_points, voxel_offsets); rows beyond
         voxel_offsets[-1] are unspecified.  No host synchronisation.
@@ -81,7 +81,8 @@ class BatchVoxelizer:
         from call to call and only the previous call's occupied slots are re-zeroed (include/lidar_hip.h, algo 4); the result is
         bit-identical, and rows beyond voxel_offsets[-1] are then all zero.
         host_offsets: the same B+1 offsets as a host sequence / numpy array, when the caller has them (a collate function does):
-        they are handed to the launches as kernel arguments (lidar_voxelize_hostoff); results identical."""
+        they are handed to the launches as kernel arguments (lidar_voxelize_hostoff); results identical.
+        timer: a handle from lidar_timer_create — this call's launches record their start / end into it (measurement only)."""
         _lib.require_cuda(points, point_offsets)
         if points.dtype != torch.float32 or point_offsets.dtype != torch.int32:
             raise _lib.LidarHipError("points must be float32 and point_offsets int32")
@@ -100,6 +101,8 @@ class BatchVoxelizer:
             if len(host_offsets) != batch + 1:
                 raise _lib.LidarHipError("host_offsets must hold batch + 1 entries")
             hoff = (ctypes.c_int * (batch + 1))(*[int(v) for v in host_offsets])
+        if timer is not None:
+            L.lidar_voxelize_time_next(timer)
         _lib.check(L.lidar_voxelize_hostoff(_lib.ptr(points), _lib.ptr(point_offsets), hoff, batch, n_max, self.C, self._range_h,
                                             self._vs_h, self._grid_h, self.max_num_points, self.max_voxels, int(bool(compact)),
                                             algo, _lib.ptr(out["voxels"]), _lib.ptr(out["voxel_coords"]),
