@@ -1209,10 +1209,18 @@ static void vxl_run_fused(const float *points, const int *point_offsets, const V
     g_next_timer = nullptr;
     hipEvent_t ev_a = tm ? tm->a : nullptr, ev_b = tm ? tm->b : nullptr;
     const dim3 g1(nbinwg + nfillwg), blk(1024);
+    const dim3 ge(ntiles, p.batch);
+    if (!tm) {                           // the ordinary path: plain launches (the event-carrying form costs ~5 us of queue time per launch)
+        if (emit_only) {}
+        else if (c4) hipLaunchKernelGGL(vxl_keybin_kernel<true>, g1, blk, 0, s, points, point_offsets, p, w, G, nbinwg, nfillwg, voxels, total_f4, tf, help16, resident, (const int *)num_points);
+        else hipLaunchKernelGGL(vxl_keybin_kernel<false>, g1, blk, 0, s, points, point_offsets, p, w, G, nbinwg, nfillwg, voxels, total_f4, tf, help16, resident, (const int *)num_points);
+        if (c4) hipLaunchKernelGGL(vxl_emit_kernel<true>, ge, blk, 0, s, points, point_offsets, p, w, G, voxels, coords, num_points, voxel_offsets, resident);
+        else hipLaunchKernelGGL(vxl_emit_kernel<false>, ge, blk, 0, s, points, point_offsets, p, w, G, voxels, coords, num_points, voxel_offsets, resident);
+        return;
+    }
     if (emit_only) {}
     else if (c4) hipExtLaunchKernelGGL(vxl_keybin_kernel<true>, g1, blk, 0, s, ev_a, nullptr, 0, points, point_offsets, p, w, G, nbinwg, nfillwg, voxels, total_f4, tf, help16, resident, (const int *)num_points);
     else hipExtLaunchKernelGGL(vxl_keybin_kernel<false>, g1, blk, 0, s, ev_a, nullptr, 0, points, point_offsets, p, w, G, nbinwg, nfillwg, voxels, total_f4, tf, help16, resident, (const int *)num_points);
-    const dim3 ge(ntiles, p.batch);
     if (c4) hipExtLaunchKernelGGL(vxl_emit_kernel<true>, ge, blk, 0, s, nullptr, ev_b, 0, points, point_offsets, p, w, G, voxels, coords, num_points, voxel_offsets, resident);
     else hipExtLaunchKernelGGL(vxl_emit_kernel<false>, ge, blk, 0, s, nullptr, ev_b, 0, points, point_offsets, p, w, G, voxels, coords, num_points, voxel_offsets, resident);
 }
