@@ -55,17 +55,20 @@ def _lt_gemm(a_ptr, M, K, w_kn, bias, relu, d_ptr, ldd, device):
     return True
 
 
-_SIDE_STREAMS = {}
-
-
 def _side_streams(device, n):
-    """the n side streams of the split forward, shared by every backbone in the process (a process holds only a few hardware queues:
-    streams beyond them share queues and serialise — each model owning its own pair slowed the three-stream sparse forward that ran
-    next to them in bench.py's `extra` from 3.15 to 4.3 ms)"""
-    key = (str(device), n)
-    if key not in _SIDE_STREAMS:
-        _SIDE_STREAMS[key] = [torch.cuda.Stream(device) for _ in range(n)]
-    return _SIDE_STREAMS[key]
+    """the n (<= 2) side streams of the split forward: the SAME two streams the sparse forward uses for its mask orders and rulebooks
+    (spconv/conv.py, spconv/modules.py — never busy at the same time as a dense backbone).  A process drives only a few hardware
+    queues (4 by default); streams beyond them share queues and serialise falsely: with each subsystem owning its own streams
+    (7 in bench.py's `extra` process) the three-stream sparse forward measured there went from 3.15 to 4.4 ms."""
+    from .spconv import conv as _sc, modules as _sm
+    dev = torch.device(device)
+    out = []
+    for pool in (_sc._SIDE_STREAMS, _sm._RULEBOOK_STREAMS)[:n]:
+        st = pool.get(dev)
+        if st is None:
+            st = pool[dev] = torch.cuda.Stream(dev, priority=-1)
+        out.append(st)
+    return out
 
 
 def gemm_bias_act_into_(x, w_kn, bias, out, out_offset, relu=True):
@@ -229,7 +232,7 @@ class FoldedBEVBackbone:
     def merged(self, canvas):
         """-> the merged head output (B, H, W, sum C_head), channels [cls | box | dir] as the heads were given."""
         B = canvas.shape[0]
-        if _SPLIT[0] > 1 and canvas.is_cuda and B % _SPLIT[0] == 0 and B // _SPLIT[0] >= 8:     # (4-frame parts lose: PV-RCNN bs 8 16.0 -> 17.5 ms)
+        if 1 < _SPLIT[0] <= 2 and canvas.is_cuda and B % _SPLIT[0] == 0 and B // _SPLIT[0] >= 8:     # (4-frame parts lose: PV-RCNN bs 8 16.0 -> 17.5 ms)
             return self._merged_split(canvas, _SPLIT[0])
         cat = self.features(canvas)
         B, C, H, W = cat.shape
