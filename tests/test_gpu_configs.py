@@ -271,7 +271,27 @@ def test_pvrcnn_kitti_bs8(dev):
                 assert np.array_equal(fl[f, :len(e)].cpu().numpy(), roi_labels[f].cpu().numpy()[e])
         # ---- and the assembled forward gives the same thing
         out = m(pts, offs, sizes)
-    # same functions, same inputs, same order of accumulation: bit-identical
+    # Same functions, same inputs.  The one SYSTEMATIC difference r02 had here is gone (the staged pass fed the RoI head keypoint
+    # scores from the unfolded module sequence, see above: with the folded chain the two passes agree bit for bit in most runs,
+    # tools/pvrcnn_stage_equal_probe.py).  What remains is run-to-run: MIOpen's global-K-split convolution kernels (and the library
+    # GEMM candidates that reduce split partial sums) accumulate with atomics, so the dense trunk's output can move in its last bit
+    # from call to call when another stream — here: furthest-point sampling under the trunk — shares the GPU
+    # (tools/split_determinism_probe.py: 2e-7 on the 8-frame SECOND backbone).  Hence: counts and labels exact, values to 1e-4.
     assert torch.equal(out[3], fn)
-    for got, want, what in zip(out[:3], (fb, fs, fl), ("boxes", "scores", "labels")):
-        assert torch.equal(got, want), f"assembled vs staged forward: {what}"
+    # (box sizes are exp() of a regression output: compared relative to their own magnitude; two RoIs whose scores differ
+    # in the last bit may swap places between the passes, so each frame's rows are put in a canonical order first)
+    def canon(boxes, scores, labels, n):
+        res = ([], [], [])
+        for f in range(boxes.shape[0]):
+            k = int(n[f])
+            order = torch.from_numpy(np.lexsort(np.round(boxes[f, :k].cpu().numpy()[:, :3].T, 2))).to(boxes.device)
+            for dst, t in zip(res, (boxes, scores, labels)):
+                dst.append(torch.cat([t[f, :k][order], t.new_zeros((boxes.shape[1] - k,) + t.shape[2:])]))
+        return [torch.stack(r) for r in res]
+    out = canon(out[0], out[1], out[2], fn)
+    fb, fs, fl = canon(fb, fs, fl, fn)
+    assert torch.equal(out[2], fl)
+    rel = float(((out[0] - fb).abs() / fb.abs().clamp(min=1.0)).max())
+    print(f"assembled vs staged forward: max box diff relative to max(1, |box|) {rel:.2e} (max |box| {float(fb.abs().max()):.2e}), "
+          f"max |score diff| {float((out[1] - fs).abs().max()):.2e}")
+    assert rel <= 1e-4 and float((out[1] - fs).abs().max()) <= 1e-4
