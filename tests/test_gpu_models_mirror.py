@@ -248,3 +248,29 @@ def test_pipelined_stage_runner_equals_prebuilt_pass(dev):
             for a, b in zip(got, want):
                 assert a.spatial_shape == b.spatial_shape and torch.equal(a.indices, b.indices)
                 assert torch.equal(a.features, b.features)
+
+
+def test_dense_gemm_with_strided_bias_relu_epilogue_matches_fp64(dev):
+    """lidar_dense_gemm_bias_act (csrc/dense_gemm.hip; the stride-1 deblock of BaseBEVBackbone, base_bev_backbone.py:58-77,103):
+    D[:, off:off+N] = relu(A @ W + b) written at the concatenated map's row pitch, the other channels untouched; plus the plain
+    (M, N) form with and without bias the other backbone GEMMs use.  fp32 within 1e-4 of the fp64 result."""
+    from lidardetection_amd import bev_backbone
+    torch.manual_seed(5)
+    B, K, N, CT, h, w, off = 3, 64, 128, 384, 20, 24, 128
+    x = torch.randn(B, K, h, w, device=dev).contiguous(memory_format=torch.channels_last)
+    wkn = (torch.randn(K, N, device=dev) * 0.2).contiguous()
+    bias = torch.randn(N, device=dev)
+    cat = torch.full((B, CT, h, w), 7.0, device=dev).contiguous(memory_format=torch.channels_last)
+    rows = x.permute(0, 2, 3, 1).reshape(-1, K)
+    want = torch.relu(rows.double() @ wkn.double() + bias.double())
+    if not bev_backbone.gemm_bias_act_into_(x, wkn, bias, cat, off):
+        pytest.skip("hipBLASLt path not available in this process")
+    got = cat.permute(0, 2, 3, 1).reshape(-1, CT)
+    assert float((got[:, off:off + N].double() - want).abs().max()) <= 1e-4 * max(1.0, float(want.abs().max()))
+    assert bool((got[:, :off] == 7.0).all()) and bool((got[:, off + N:] == 7.0).all())          # neighbours of the slice untouched
+    for b in (None, bias):
+        y = bev_backbone.rows_gemm(rows.contiguous(), wkn, b)
+        ref = rows.double() @ wkn.double() + (0 if b is None else b.double())
+        assert float((y.double() - ref).abs().max()) <= 1e-4 * max(1.0, float(ref.abs().max()))
+    with pytest.raises(Exception):
+        bev_backbone.gemm_bias_act_into_(x, wkn, bias, cat, CT - 8)                              # slice past the map's channels
