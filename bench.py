@@ -188,6 +188,34 @@ def cpu_baseline(frames, model, nframes, nruns=20, warmups=3, procs_cap=16):
                       f"with {nproc} threads), {dt:.1f} s; hot-path columns: {warmups}+{nruns} frames each; whole baseline {clk() - t_begin:.0f} s"}
 
 
+def h2d_inclusive(model, frames, steps, device, resident_fps):
+    """the same step with the raw clouds arriving from HOST memory every step — copied into pinned staging,
+    H2D on a side stream, overlapped with the previous step (lidardetection_amd/feeder.py).  `value` stays the resident figure;
+    this is the PCIe-inclusive one beside it."""
+    from lidardetection_amd.feeder import PinnedPointFeeder
+    B = len(frames)
+    feeder = PinnedPointFeeder(sum(len(f) for f in frames), frames[0].shape[1], max_batch=B, device=device, depth=2)
+    with torch.no_grad():
+        feeder.submit(frames)
+        for _ in range(3):
+            feeder.submit(frames)
+            fb = feeder.get()
+            model(fb.points, fb.offsets, fb.host_offsets)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            feeder.submit(frames)                   # next batch: host copy into pinned memory + async H2D, under this step's kernels
+            fb = feeder.get()
+            model(fb.points, fb.offsets, fb.host_offsets)
+        torch.cuda.synchronize()
+        dt = time.perf_counter() - t0
+        feeder.get()
+    fps = B * steps / dt
+    return {"h2d_inclusive_frames_per_s": fps, "h2d_inclusive_ms_per_step": dt / steps * 1e3, "h2d_inclusive_vs_resident": fps / resident_fps,
+            "h2d_bytes_per_step": int(sum(f.nbytes for f in frames)),
+            "h2d_note": "raw (N, 4) clouds from host numpy arrays every step: pinned double-buffered staging + copy stream (feeder.py)"}
+
+
 def launch_ranks(n, argv):
     """`python bench.py --gpus N` without a torch.distributed launcher: start N fresh rank processes, one per GPU, with
     RANK / LOCAL_RANK / WORLD_SIZE / MASTER_* set (what tools/scripts/dist_train.sh:7 + pcdet/utils/common_utils.py:170-184
@@ -237,6 +265,12 @@ def main():
     ap.add_argument("--no-extra", action="store_true", help="skip the SECOND / sparse-GEMM / NMS / PFN side measurements")
     ap.add_argument("--no-full-rewrite", action="store_true", help="skip the extra steps that time the non-resident voxeliser path "
                     "(profiles: keeps the per-kernel averages of the timed path unmixed)")
+    ap.add_argument("--contract-only", action="store_true", help="run EVERY step (warm-up, timed, armed) on the voxeliser's contract path "
+                    "(algo 3, fresh-buffer semantics: all priced bytes written) — profiles: a kernel trace of this run holds the "
+                    "launches roofline.frac is priced on and nothing else under their names")
+    ap.add_argument("--roofline-launches", type=int, default=100, help="armed launches behind roofline.ms_per_launch (SURVEY 8d: >= 100)")
+    ap.add_argument("--mode", choices=["infer", "train-ddp"], default="infer", help="train-ddp: BASELINE configs[4]'s DDP leg — "
+                    "SECOND-MultiHead NuScenes bs 4 / GPU, forward + backward + DistributedDataParallel step (tools/ddp_train_bench.py)")
     ap.add_argument("--dry-run", action="store_true", help="N-rank plumbing only, CPU / gloo, no kernels (tests)")
     ap.add_argument("--stages", action="store_true", help="also print per-stage GPU times (stderr)")
     args = ap.parse_args()
@@ -248,14 +282,19 @@ def main():
         print(f"bench.py: --gpus {args.gpus} but WORLD_SIZE={world}: launch one rank per GPU "
               f"(torch.distributed.run --nproc-per-node {args.gpus}, or no launcher at all)", file=sys.stderr)
         sys.exit(2)
+    if args.mode == "train-ddp":
+        sys.path.insert(0, os.path.join(ROOT, "tools"))
+        import ddp_train_bench
+        return ddp_train_bench.run(args, rank, local, world)
     if args.dry_run:
         return dry_run(args, rank, world)
     from lidardetection_amd.pointpillar import PointPillarKITTI
     if world > 1 and "MIOPEN_USER_DB_PATH" not in os.environ:
-        # every rank runs MIOpen's find pass during warm-up and records the result in the user database: one directory per
-        # rank keeps N processes from queueing on the same SQLite file (the find results themselves are per process anyway)
+        # ONE user database for all ranks of this job: rank 0 runs MIOpen's find pass first (staged warm-up below) and records its
+        # picks there; the other ranks then find those records instead of timing the candidates again, so that every rank runs the
+        # same solver (N independent timing decisions could differ, and the max-over-ranks clock reports the unluckiest)
         import tempfile
-        db = os.path.join(tempfile.gettempdir(), f"lidar_miopen_udb_{os.getuid()}_rank{local}")
+        db = os.path.join(tempfile.gettempdir(), f"lidar_miopen_udb_{os.getuid()}_{os.environ.get('MASTER_PORT', '0')}")
         os.makedirs(db, exist_ok=True)
         os.environ["MIOPEN_USER_DB_PATH"] = db
     torch.cuda.set_device(local)
@@ -272,8 +311,21 @@ def main():
     def barrier():
         dist_utils.barrier(dist, cuda=True)
 
+    if args.contract_only:
+        model.resident_voxels = False
     with torch.no_grad():
-        for _ in range(args.warmup):
+        # staged warm-up for N > 1: rank 0 first — its convolution find results land in the shared MIOpen user database and its
+        # library-GEMM picks are broadcast (lidar_dense_gemm_export / import_choices) — then everybody else with those choices
+        if world > 1 and rank == 0:
+            for _ in range(args.warmup):
+                out = model(pts, offs, hoffs)
+            torch.cuda.synchronize()
+        if world > 1:
+            picks = [dist_utils.export_gemm_choices()] if rank == 0 else [None]
+            dist.broadcast_object_list(picks, src=0)
+            if rank != 0:
+                dist_utils.import_gemm_choices(picks[0])
+        for _ in range(args.warmup if not (world > 1 and rank == 0) else 1):
             out = model(pts, offs, hoffs)
         barrier()
         ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(args.steps)]
@@ -297,11 +349,14 @@ def main():
         dt = time.perf_counter() - t0
     dt = dist_utils.max_over_ranks(dt, dist, device)
 
-    # the same bracket with the resident-output mode switched off (every call rewrites the whole padded buffer — what a caller
-    # that hands over fresh buffers gets), measured inside full steps AFTER the timed region
-    # launch-timestamp timing (the kernels' own start / stop events) runs on extra steps AFTER the timed region, so that the timed
-    # steps carry nothing but the two HIP-event brackets they always had
-    def timed_extra_steps(n):
+    # Voxeliser durations for the roofline: the kernels' own start / stop events (lidar_timer_*: hipExtLaunchKernel carries them, the
+    # timestamps a kernel trace reports) on extra full detector steps AFTER the timed region, >= 100 launches per path, split into
+    # first kernel / inter-kernel gap / last kernel.  The hipEventRecord bracket around the same call is measured on separate
+    # extra steps with PLAIN launches (an event-carrying launch adds queue time of its own, which is what made the r03 bracket
+    # read 54 us): bracket_ms = kernel span + one event pair + dispatch.
+    import ctypes
+
+    def armed_steps(n):
         tms = [Lh.lidar_timer_create() for _ in range(n)]
         evs = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(n)]
         with torch.no_grad():
@@ -312,19 +367,49 @@ def main():
                 b.record()
                 model.post_process(*model.backbone_head(model.vfe_scatter(v2)))
             torch.cuda.synchronize()
-        ms = float(np.mean([Lh.lidar_timer_elapsed_ms(tm) for tm in tms]))
+        spans, parts = [], []
+        buf = (ctypes.c_float * 3)()
         for tm in tms:
+            ms = Lh.lidar_timer_elapsed_ms(tm)
+            if ms >= 0 and Lh.lidar_timer_parts_ms(tm, buf) == 0:
+                spans.append(ms)
+                parts.append([buf[0], buf[1], buf[2]])
             Lh.lidar_timer_destroy(tm)
-        return ms, float(np.mean([a.elapsed_time(b) for a, b in evs]))
+        pa = np.asarray(parts, np.float64)
+        return {"ms": float(np.mean(spans)), "median_ms": float(np.median(spans)), "p10_ms": float(np.percentile(spans, 10)),
+                "p90_ms": float(np.percentile(spans, 90)), "launches": len(spans), "first_kernel_us": float(pa[:, 0].mean() * 1e3),
+                "gap_us": float(pa[:, 1].mean() * 1e3), "last_kernel_us": float(pa[:, 2].mean() * 1e3),
+                "kernel_sum_us": float((pa[:, 0] + pa[:, 2]).mean() * 1e3),
+                "bracket_armed_ms": float(np.mean([a.elapsed_time(b) for a, b in evs]))}
 
-    n_extra = max(args.steps // 2, 5)
-    vox_ms, _ = timed_extra_steps(n_extra)                   # the timed path (resident output), launch timestamps
-    contract_ms = contract_bracket_ms = None
-    if getattr(model, "resident_voxels", False) and not args.no_full_rewrite:
-        model.resident_voxels = False
-        contract_ms, contract_bracket_ms = timed_extra_steps(n_extra)
-        model.resident_voxels = True
-        model(pts, offs, hoffs)
+    def plain_bracket_steps(n):
+        evs = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(n)]
+        with torch.no_grad():
+            model(pts, offs, hoffs)
+            for a, b in evs:
+                a.record()
+                v2 = model.voxelize(pts, offs, hoffs)
+                b.record()
+                model.post_process(*model.backbone_head(model.vfe_scatter(v2)))
+            torch.cuda.synchronize()
+        return float(np.mean([a.elapsed_time(b) for a, b in evs]))
+
+    n_arm = max(args.roofline_launches, 5)
+    contract = resident = None
+    contract_bracket_ms = None
+    if args.contract_only:
+        contract = armed_steps(n_arm)
+        contract_bracket_ms = plain_bracket_steps(min(n_arm, 40))
+    else:
+        resident = armed_steps(n_arm)                 # the timed path (resident output)
+        if getattr(model, "resident_voxels", False) and not args.no_full_rewrite:
+            model.resident_voxels = False
+            contract = armed_steps(n_arm)
+            contract_bracket_ms = plain_bracket_steps(min(n_arm, 40))
+            model.resident_voxels = True
+            model(pts, offs, hoffs)
+    vox_ms = (resident or contract)["ms"]
+    contract_ms = contract["ms"] if contract else None
     vox_bracket_ms = float(np.mean([a.elapsed_time(b) for a, b in ev]))          # timed region: hipEventRecord bracket
     ev_overhead_ms = float(np.mean([a.elapsed_time(b) for a, b in ev0]))
     total_rows = int(vox["voxel_offsets"][-1].item())
@@ -336,20 +421,24 @@ def main():
     slots = int(vox["voxel_num_points"][:total_rows].sum().item())
     own_bytes = 16 * npts + 2 * 16 * slots + 20 * total_rows
     # HBM traffic of the same launch sequences: rocprofv3 PMC counters cannot be collected from inside this run, so the figures
-    # come from the committed passes (profiles/r03/voxelize_pmc.json) and are only reported when that file was taken from the
+    # come from the committed passes (profiles/rNN/voxelize_pmc.json) and are only reported when that file was taken from the
     # SAME kernel source (sha256 of csrc/voxelize.hip recorded beside it); otherwise null — never a stale number.
     traffic = {"full": None, "resident": None}
     traffic_src = None
-    pmc = os.path.join(ROOT, "profiles", "r03", "voxelize_pmc.json")
-    if os.path.exists(pmc) and args.batch == 16:
-        import hashlib
+    import glob
+    import hashlib
+    with open(os.path.join(ROOT, "lidardetection_amd", "csrc", "voxelize.hip"), "rb") as fh:
+        sha = hashlib.sha256(fh.read()).hexdigest()[:16]
+    for pmc in sorted(glob.glob(os.path.join(ROOT, "profiles", "r*", "voxelize_pmc.json")), reverse=True):     # newest round first
+        if args.batch != 16:
+            break
         with open(pmc) as fh:
             rec = json.load(fh)
-        with open(os.path.join(ROOT, "lidardetection_amd", "csrc", "voxelize.hip"), "rb") as fh:
-            sha = hashlib.sha256(fh.read()).hexdigest()[:16]
         if rec.get("kernel_source_sha256_16") == sha:
             traffic = {k: rec[k]["traffic_bytes_per_launch_high"] for k in ("full", "resident")}
-            traffic_src = f"profiles/r03/voxelize_pmc.json (voxelize.hip sha256 {sha}; FETCH_SIZE upper bracket + WRITE_SIZE, separate --pmc passes)"
+            traffic_src = (f"{os.path.relpath(pmc, ROOT)} (voxelize.hip sha256 {sha}; FETCH_SIZE upper bracket + WRITE_SIZE, "
+                           "separate --pmc passes)")
+            break
     frames_total = args.batch * args.steps * world
     gbs = lambda nbytes, ms: nbytes / (ms * 1e-3) / 1e9
     ratio = lambda tr, nbytes: None if tr is None else tr / nbytes
@@ -357,12 +446,20 @@ def main():
     # buffer rewritten, include/lidar_hip.h algo 3), bracketed with the same HIP events inside full steps right after the timed
     # region.  The timed region itself runs the resident-output mode (algo 4: same output bits, a quarter of the traffic); it is
     # reported under `timed_path` with the bytes IT has to move and, for comparison, the contract bytes over its time.
-    if contract_ms is not None:
-        roof = {"achieved": gbs(alg_bytes, contract_ms), "frac": gbs(alg_bytes, contract_ms) / HBM_PEAK_GBS, "ms_per_launch": contract_ms,
-                "path": "contract (algo 3, full rewrite), in-step, measured on extra steps after the timed region"}
+    # ms_per_launch = the two kernels' own durations (start -> stop events each launch carries), i.e. what `rocprofv3 --kernel-trace
+    # --stats` reports as their average durations.  The SPAN of an event-carrying call also contains a 7-10 us gap between the
+    # launches that plain launches do not have: in the kernel trace of this very command (profiles/r04/voxelize_contract_trace.json)
+    # the plain launches' second kernel starts within 10 ns of the first one's end (gap 0.0 us) while the armed ones sit 7-10 us
+    # apart — the completion signal + start timestamp of the events themselves.  So span_armed / gap_armed are reported, not priced.
+    def roof_of(m, nbytes, path):
+        ms = m["kernel_sum_us"] * 1e-3
+        return {"achieved": gbs(nbytes, ms), "frac": gbs(nbytes, ms) / HBM_PEAK_GBS, "ms_per_launch": ms, "path": path}
+    if contract is not None:
+        roof = roof_of(contract, alg_bytes, "contract (algo 3, full rewrite), in-step, " +
+                       ("every step of this run" if args.contract_only else "measured on extra steps after the timed region"))
     else:   # --no-full-rewrite: only the timed path was measured; price it with its own bytes
-        roof = {"achieved": gbs(own_bytes, vox_ms), "frac": gbs(own_bytes, vox_ms) / HBM_PEAK_GBS, "ms_per_launch": vox_ms,
-                "path": "resident (algo 4), in-step, extra steps after the timed region, priced with its own algorithmic bytes"}
+        roof = roof_of(resident, own_bytes, "resident (algo 4), in-step, extra steps after the timed region, priced with its own algorithmic bytes")
+    vox_ms = (resident or contract)["kernel_sum_us"] * 1e-3
     res = {
         "metric": "frames/sec (fwd+NMS) PointPillar-KITTI", "value": frames_total / dt, "unit": "frames/s",
         "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": dt / args.steps * 1e3,
@@ -374,9 +471,18 @@ def main():
         "roofline": {"bound": "hbm", "kernel": "lidar_voxelize = vxl_keybin_kernel (bin + zero-fill roles in one launch) + vxl_emit_kernel",
                      "achieved": roof["achieved"], "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": roof["frac"], "path": roof["path"],
                      "ms_per_launch": roof["ms_per_launch"], "alg_bytes_per_launch": alg_bytes if contract_ms is not None else own_bytes,
-                     "timing": "start of the call's first kernel to the end of its last one, from the HIP events the launches themselves "
-                               "carry (hipExtLaunchKernel start / stop events: the dispatch timestamps a kernel trace reports; the gap "
-                               "between the two launches is inside); bracket_ms_per_launch = hipEventRecord before / after the call, "
+                     # the same span split (means over `launches` armed launches): rocprofv3's per-kernel averages of this command
+                     # (profiles/r04/) must agree with first_kernel_us / last_kernel_us, and ms_per_launch = their sum + gap_us
+                     "launches": (contract or resident)["launches"], "kernel_sum_us": (contract or resident)["kernel_sum_us"],
+                     "first_kernel_us": (contract or resident)["first_kernel_us"], "last_kernel_us": (contract or resident)["last_kernel_us"],
+                     "gap_armed_us": (contract or resident)["gap_us"], "span_armed_ms": (contract or resident)["ms"],
+                     "span_armed_p10_p90_ms": [(contract or resident)["p10_ms"], (contract or resident)["p90_ms"]],
+                     "gap_plain_us_in_trace": "0.0 (profiles/r04/voxelize_contract_trace.json: same command under rocprofv3 --kernel-trace)",
+                     "bracket_armed_ms_per_launch": (contract or resident)["bracket_armed_ms"],
+                     "timing": "ms_per_launch = sum of the two kernels' own durations, each from the start / stop HIP events its launch carries "
+                               "(hipExtLaunchKernel: the dispatch timestamps a kernel trace reports), mean over `launches` in-step launches; "
+                               "span_armed_ms = first start to last end of those event-carrying calls (contains gap_armed_us, an artefact of "
+                               "the events: plain launches run back to back in the trace); bracket_ms_per_launch = hipEventRecord before / after the call, "
                                "which adds the event-marker and queue overhead (event_pair_overhead_ms)",
                      "bracket_ms_per_launch": contract_bracket_ms if contract_ms is not None else vox_bracket_ms,
                      "traffic": traffic["full"] if contract_ms is not None else traffic["resident"],
@@ -388,6 +494,8 @@ def main():
                      "timed_path": {"mode": "resident output buffer (algo 4): the padded rows' zeros persist between calls, only the previous "
                                             "call's occupied slots are re-zeroed — same output bits as the contract path (tested)",
                                     "ms_per_launch": vox_ms, "bracket_ms_per_launch": vox_bracket_ms, "own_alg_bytes_per_launch": own_bytes,
+                                    "kernel_sum_us": (resident or contract)["kernel_sum_us"], "gap_armed_us": (resident or contract)["gap_us"],
+                                    "launches": (resident or contract)["launches"],
                                     "achieved_own": gbs(own_bytes, vox_ms), "frac_own": gbs(own_bytes, vox_ms) / HBM_PEAK_GBS,
                                     "equivalent_contract_frac": gbs(alg_bytes, vox_ms) / HBM_PEAK_GBS,
                                     "traffic": traffic["resident"], "traffic_ratio_vs_own": ratio(traffic["resident"], own_bytes),
@@ -418,7 +526,11 @@ def main():
         import bench_extra
         del out, canvas, vox
         try:
-            res["extra"] = bench_extra.pp_kernels(model, pts, offs)
+            res["extra"] = h2d_inclusive(model, frames, args.steps, device, frames_total / world / dt)
+        except Exception as e:
+            res["extra"] = {"h2d_inclusive_error": repr(e)[:200]}
+        try:
+            res["extra"].update(bench_extra.pp_kernels(model, pts, offs))
             res["extra"].update(bench_extra.pp_ring(model))
             model(pts, offs, hoffs)
         except Exception as e:

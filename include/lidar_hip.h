@@ -70,14 +70,17 @@ int lidar_voxelize_hostoff(const float *points, const int *point_offsets, const 
                            int num_features, const float *range6, const float *voxel_size3, const int *grid3, int max_points,
                            int max_voxels, int compact, int algo, float *voxels, int *coords, int *num_points,
                            int *voxel_offsets, void *ws, size_t ws_bytes, void *stream);
-/* Measurement only: a timer = two HIP events carried by the launches themselves (hipExtLaunchKernel's start / stop events):
+/* Measurement only: a timer = four HIP events carried by the launches themselves (hipExtLaunchKernel's start / stop events):
  * the time from the start of the call's first kernel to the end of its last one, as a kernel trace would report it, without the
  * marker / queue overhead of a hipEventRecord bracket around the call.  lidar_voxelize_time_next arms `timer` for the calling
- * thread's next lidar_voxelize(_hostoff) call (LDS-binned path); lidar_timer_elapsed_ms waits for the stop event. */
+ * thread's next lidar_voxelize(_hostoff) call: the LDS-binned path records into it, any other path (or an argument error)
+ * disarms it unrecorded.  lidar_timer_elapsed_ms waits for the stop event (< 0: nothing was recorded);
+ * lidar_timer_parts_ms splits the same span into {first launch, gap between the launches, last launch}. */
 void *lidar_timer_create(void);
 void lidar_timer_destroy(void *timer);
 void lidar_voxelize_time_next(void *timer);
 float lidar_timer_elapsed_ms(void *timer);
+int lidar_timer_parts_ms(void *timer, float *out3);
 /* optional: a device-visible HOST int (pinned + mapped memory) that receives the same error bits, so the caller can poll
  * the flag without a copy or a synchronisation (nullptr unregisters).  Cleared by the caller. */
 int lidar_voxelize_set_error_mirror(void *ws, size_t ws_bytes, int batch, int n_max, int max_voxels, int *host_flag,
@@ -358,6 +361,25 @@ int lidar_bias_act_upsample_nhwc(const float *in, const float *bias, int batch, 
  * LIDAR_ERR_UNSUPPORTED when the library is not loadable or has no kernel for the problem. */
 int lidar_dense_gemm_bias_act(const float *A, long long M, int K, const float *W, int N, const float *bias, int relu,
                               float *D, int ldd, void *ws, size_t ws_bytes, void *stream);
+/* The library offers several kernels per shape and the wrapper keeps the one that timed fastest at the first call.  For N ranks
+ * to run the SAME kernel (the reference's DDP ranks all run cuDNN's deterministic heuristic pick: pcdet/utils/common_utils.py:170-184
+ * launches identical processes), rank 0's picks are exported — 7 ints per shape — and imported by the others before their first
+ * call.  export returns the number of plans (writes at most cap). */
+int lidar_dense_gemm_export_choices(int *out7, int cap);
+int lidar_dense_gemm_import_choices(const int *in7, int n);
+
+/* 3x3 / stride 1 / padding 1 fp32 convolution + folded BatchNorm shift + ReLU on NHWC maps — the LAYER_NUMS stride-1 layers of
+ * every BaseBEVBackbone block (pcdet/models/backbones_2d/base_bev_backbone.py:34-45) — as Winograd F(2x2, 3x3) on the fp32 matrix
+ * cores (csrc/wino_conv.hip): 2.25x fewer MFMA cycles than the direct form, |error| ~ 1e-6 of the output scale.
+ * lidar_wino_pack_weights: w (Cout, Cin, 3, 3) contiguous (BatchNorm scale already folded in) -> `packed`, lidar_wino_packed_floats
+ * (Cin, Cout) floats (0: shape not supported — Cin % 8 == 0 and Cout % 32 == 0 are); once per weight update.
+ * lidar_wino_conv3x3_nhwc: out[b][y][x][out_off + co] = act(conv(in, w)[b][y][x][co] + bias[co]), `in` (B, H, W, Cin), `out`
+ * (B, H, W, out_C) — out_off / out_C as in lidar_bias_act_nhwc (a slice of the concatenated map); bias may be null. */
+size_t lidar_wino_packed_floats(int Cin, int Cout);
+int lidar_wino_supported(int Cin, int Cout);
+int lidar_wino_pack_weights(const float *w, int Cin, int Cout, float *packed, void *stream);
+int lidar_wino_conv3x3_nhwc(const float *in, int B, int H, int W, int Cin, const float *packed, const float *bias, int relu, int Cout,
+                            float *out, int out_C, int out_off, void *stream);
 
 /* ------------------------------------------------------------------ anchor-head post-processing feeding NMS (8f rank 1)
  * head: (n_loc = B*H*W, row_stride) rows of the merged head output [cls | box | dir] as the 1x1 heads emit it

@@ -22,6 +22,7 @@ SIGNATURES = {
     "lidar_timer_destroy": (None, [vp]),
     "lidar_voxelize_time_next": (None, [vp]),
     "lidar_timer_elapsed_ms": (C.c_float, [vp]),
+    "lidar_timer_parts_ms": (i32, [vp, vp]),
     "lidar_voxelize_set_error_mirror": (i32, [vp, sz, i32, i32, i32, vp, vp]),
     "lidar_pillar_vfe": (i32, [vp, vp, vp, i32, vp, i32, i32, vp, vp, vp, i32, vp, vp, i32, i32, i32, vp, vp]),
     "lidar_mean_vfe": (i32, [vp, vp, i32, i32, i32, i32, vp, vp]),
@@ -92,6 +93,12 @@ SIGNATURES = {
     "lidar_bias_act_nhwc": (i32, [vp, vp, C.c_longlong, i32, i32, vp, i32, i32, vp]),
     "lidar_bias_act_upsample_nhwc": (i32, [vp, vp, i32, i32, i32, i32, i32, i32, vp, i32, i32, vp]),
     "lidar_dense_gemm_bias_act": (i32, [vp, C.c_longlong, i32, vp, i32, vp, i32, vp, i32, vp, sz, vp]),
+    "lidar_dense_gemm_export_choices": (i32, [vp, i32]),
+    "lidar_dense_gemm_import_choices": (i32, [vp, i32]),
+    "lidar_wino_packed_floats": (sz, [i32, i32]),
+    "lidar_wino_supported": (i32, [i32, i32]),
+    "lidar_wino_pack_weights": (i32, [vp, i32, i32, vp, vp]),
+    "lidar_wino_conv3x3_nhwc": (i32, [vp, i32, i32, i32, i32, vp, vp, i32, i32, vp, i32, i32, vp]),
     "lidar_anchor_scores": (i32, [vp, C.c_longlong, i32, i32, i32, i32, f32, vp, vp, vp]),
     "lidar_decode_topk": (i32, [vp, i32, C.c_longlong, i32, i32, i32, i32, i32, vp, i32, vp, f32, f32, f32, vp, vp]),
     "lidar_topk_workspace_bytes": (sz, [i32, C.c_longlong]),
@@ -126,6 +133,19 @@ def lib():
             fn.restype = res
             fn.argtypes = args
     return _lib
+
+
+def load_variant(path):
+    """A second, independently loaded build of the library with the same signatures (tests: A/B variants from
+    csrc/build.py:VARIANTS).  The product path never calls this."""
+    if not os.path.exists(path):
+        raise LidarHipError(f"{path} is missing: build it with lidardetection_amd/csrc/build.py (build_variants)")
+    v = C.CDLL(path)
+    for name, (res, args) in SIGNATURES.items():
+        fn = getattr(v, name)
+        fn.restype = res
+        fn.argtypes = args
+    return v
 
 
 def check(status, what):

@@ -10,8 +10,17 @@ from . import _lib
 _TOPK_WS = {}
 
 
-def topk_supported(n, k):
-    return n % 4 == 0 and 0 < k <= 4096 and n < 2 ** 31
+def topk_supported(n, k, valid_min=None):
+    """lidar_topk_desc / lidar_anchor_scores_hist take N % 4 == 0, k <= 4096 and a POSITIVE threshold (the selection key is
+    bits(score) - bits(threshold) + 1); anything else (e.g. SCORE_THRESH 0) goes to torch.topk in the callers."""
+    return n % 4 == 0 and 0 < k <= 4096 and n < 2 ** 31 and (valid_min is None or float(valid_min) > 0.0)
+
+
+def drop_topk_workspace(ws):
+    """forget a cached workspace whose histogram may be half-consumed (an exception between anchor_scores(topk_ws=ws) and
+    topk_desc(hist_ready=True)): the next call gets a freshly initialised one"""
+    for key in [k for k, v in _TOPK_WS.items() if v is ws]:
+        del _TOPK_WS[key]
 
 
 def topk_workspace(batch, n, device):
@@ -32,8 +41,8 @@ def topk_desc(scores, k, valid_min, ws=None, hist_ready=False, score_max=1.0):
     of every frame, ties by ascending index; slots past counts[b] hold (-1, 0).  hist_ready: `ws` was handed to anchor_scores
     (topk_ws=ws) for these very scores."""
     _lib.require_cuda(scores)
-    if scores.dtype != torch.float32 or scores.dim() != 2 or not topk_supported(scores.shape[1], k):
-        raise _lib.LidarHipError("topk_desc: scores must be float32 (B, N) with N % 4 == 0 and k <= 4096")
+    if scores.dtype != torch.float32 or scores.dim() != 2 or not topk_supported(scores.shape[1], k, valid_min):
+        raise _lib.LidarHipError("topk_desc: scores must be float32 (B, N) with N % 4 == 0, k <= 4096 and valid_min > 0")
     B, n = scores.shape
     if ws is None:
         ws, hist_ready = topk_workspace(B, n, scores.device), False

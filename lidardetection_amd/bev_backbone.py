@@ -20,7 +20,7 @@ import torch
 import torch.nn as nn
 import torch.nn.functional as F
 
-from . import _lib, workspace
+from . import _lib, wino, workspace
 
 
 def bias_act_(x, bias, relu=True, out=None, out_offset=0):
@@ -41,6 +41,7 @@ def bias_act_(x, bias, relu=True, out=None, out_offset=0):
 
 _LT_GEMM = [os.environ.get("LIDAR_BEV_LT_GEMM", "1") != "0"]      # the fused stride-1 deblock (csrc/dense_gemm.hip); A/B switch
 _SPLIT = [int(os.environ.get("LIDAR_BEV_SPLIT", "2"))]            # part-batches / streams of FoldedBEVBackbone.merged (1 = off)
+_WINO = [os.environ.get("LIDAR_BEV_WINO", "1") != "0"]            # stride-1 3x3 layers on csrc/wino_conv.hip (0: MIOpen + epilogue pass)
 
 
 def _lt_gemm(a_ptr, M, K, w_kn, bias, relu, d_ptr, ldd, device):
@@ -161,7 +162,14 @@ class FoldedBEVBackbone:
                 conv, bn = mods[i], mods[i + 1]
                 assert isinstance(conv, nn.Conv2d) and isinstance(bn, nn.BatchNorm2d) and isinstance(mods[i + 2], nn.ReLU)
                 w, b = _fold(conv.weight, bn, 0, conv.bias)
-                convs.append((w.contiguous(memory_format=torch.channels_last), b, conv.stride, conv.padding[0] + pad))
+                # stride-1 3x3 layers (LAYER_NUMS per block, base_bev_backbone.py:40-45; SECOND's first block opens with one too):
+                # Winograd F(2x2, 3x3) on the matrix cores with shift + ReLU in the kernel (csrc/wino_conv.hip)
+                packed = None
+                if (_WINO[0] and w.is_cuda and tuple(conv.kernel_size) == (3, 3) and tuple(conv.stride) == (1, 1)
+                        and tuple(conv.dilation) == (1, 1) and conv.groups == 1 and conv.padding[0] + pad == 1
+                        and conv.padding[1] + pad == 1 and wino.supported(w.shape[1], w.shape[0])):
+                    packed = wino.pack_weights(w)
+                convs.append((w.contiguous(memory_format=torch.channels_last), b, conv.stride, conv.padding[0] + pad, packed))
                 i += 3
             up, bn = de[0], de[1]
             if isinstance(up, nn.ConvTranspose2d):
@@ -191,7 +199,10 @@ class FoldedBEVBackbone:
         """-> the concatenated upsampled map (B, sum(up_channels), H, W), channels-last."""
         x, cat, off = canvas, None, 0
         for convs, (kind, uw, ub, ustride) in self.stages:
-            for w, b, stride, pad in convs:
+            for w, b, stride, pad, packed in convs:
+                if packed is not None and _WINO[0] and x.is_contiguous(memory_format=torch.channels_last):
+                    x = wino.conv3x3(x, packed, w.shape[0], b, True)
+                    continue
                 x = F.conv2d(x, w, None, stride, pad)
                 if not x.is_contiguous(memory_format=torch.channels_last):
                     x = x.contiguous(memory_format=torch.channels_last)

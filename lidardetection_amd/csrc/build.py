@@ -47,5 +47,39 @@ def build(force=False, verbose=False):
     return SO
 
 
+# A/B variants of the library, loaded by tests through `_lib.load_variant` (never by the product path): name -> (source, extra flags)
+VARIANTS = {
+    # every bin workgroup of the voxeliser's LDS-binned path behaves as if its shared keys never arrived and takes the
+    # deadline exit (s_slow -> vxl_bin_streaming): the branch an ordinary run reaches only beside a stalled neighbour
+    "vxl_nowait": ("voxelize.hip", ["-DVXL_WAIT_TICKS=0"]),
+}
+
+
+def variant_path(name):
+    return os.path.join(HERE, f"liblidar_hip_{name}.so")
+
+
+def build_variants(force=False, verbose=False):
+    build(force=False, verbose=verbose)
+    outs = []
+    for name, (src, extra) in VARIANTS.items():
+        so = variant_path(name)
+        s = os.path.join(HERE, src)
+        deps = [s] + glob.glob(os.path.join(HERE, "*.h")) + [os.path.abspath(__file__), SO]
+        if not force and os.path.exists(so) and all(os.path.getmtime(so) >= os.path.getmtime(d) for d in deps):
+            outs.append(so)
+            continue
+        o = os.path.join(HERE, f"{src[:-4]}.{name}.o")
+        cmd = [HIPCC, *FLAGS, *extra, "-c", s, "-o", o]
+        if verbose:
+            print(" ".join(cmd))
+        subprocess.check_call(cmd)
+        objs = [x[:-4] + ".o" for x in sources() if os.path.basename(x) != src] + [o]
+        subprocess.check_call([HIPCC, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", so, *objs])
+        outs.append(so)
+    return outs
+
+
 if __name__ == "__main__":
     print(build(force="--force" in sys.argv, verbose=True))
+    print(build_variants(force="--force" in sys.argv, verbose=True))

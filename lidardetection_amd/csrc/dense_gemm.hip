@@ -52,6 +52,8 @@ LtApi *lt_api() {
 
 struct LtPlan {
     long long M;
+    int device;                        // plans and handles belong to ONE device: a process that drives two GPUs must not share them
+    int pick;                          // index of the kept candidate in the library's heuristic list (-1: none)
     int K, N, ldd, relu, has_bias;
     size_t ws_bytes;
     hipblasLtMatmulDesc_t desc;
@@ -62,8 +64,11 @@ struct LtPlan {
 };
 std::mutex g_mu;
 std::vector<LtPlan> g_plans;           // a handful of shapes per process, kept for its lifetime
-std::vector<std::pair<void *, hipblasLtHandle_t>> g_handles;   // one library handle per stream: a handle's internal buffers are not
-                                                                // meant for two streams at once (the split backbone runs two)
+struct LtHandle { int device; void *stream; hipblasLtHandle_t h; };
+std::vector<LtHandle> g_handles;       // one library handle per (device, stream): a handle's internal buffers are not meant for two
+                                       // streams at once (the split backbone runs two), and the null stream exists on every device
+struct LtChoice { long long M; int K, N, ldd, relu, has_bias, pick; };
+std::vector<LtChoice> g_imported;      // candidate picks handed over by another process (lidar_dense_gemm_import_choices)
 }  // namespace
 
 // D (M x N, row-major, row pitch ldd floats) = act(A (M x K, row-major, dense) @ W (K x N, row-major, dense) + bias (N)).
@@ -74,18 +79,21 @@ LIDAR_EXPORT int lidar_dense_gemm_bias_act(const float *A, long long M, int K, c
     LtApi *api = lt_api();
     if (!api->ok) return LIDAR_ERR_UNSUPPORTED;
     std::lock_guard<std::mutex> lock(g_mu);
+    int device = 0;
+    if (hipGetDevice(&device) != hipSuccess) return LIDAR_ERR_LAUNCH;
     hipblasLtHandle_t g_handle = nullptr;
     for (auto &hs : g_handles)
-        if (hs.first == stream) g_handle = hs.second;
+        if (hs.device == device && hs.stream == stream) g_handle = hs.h;
     if (!g_handle) {
         if (api->create(&g_handle) != HIPBLAS_STATUS_SUCCESS) return LIDAR_ERR_UNSUPPORTED;
-        g_handles.emplace_back(stream, g_handle);
+        g_handles.push_back(LtHandle{device, stream, g_handle});
     }
     LtPlan *plan = nullptr;
     for (auto &q : g_plans)
-        if (q.M == M && q.K == K && q.N == N && q.ldd == ldd && q.relu == (relu != 0) && q.has_bias == (bias != nullptr) && q.ws_bytes == ws_bytes) plan = &q;
+        if (q.device == device && q.M == M && q.K == K && q.N == N && q.ldd == ldd && q.relu == (relu != 0) && q.has_bias == (bias != nullptr) && q.ws_bytes == ws_bytes) plan = &q;
     if (!plan) {
         LtPlan q{};
+        q.device = device; q.pick = -1;
         q.M = M; q.K = K; q.N = N; q.ldd = ldd; q.relu = relu != 0; q.has_bias = bias != nullptr; q.ws_bytes = ws_bytes; q.usable = false;
         bool ok = api->desc_create(&q.desc, HIPBLAS_COMPUTE_32F, HIP_R_32F) == HIPBLAS_STATUS_SUCCESS;
         const hipblasOperation_t opn = HIPBLAS_OP_N;
@@ -119,7 +127,16 @@ LIDAR_EXPORT int lidar_dense_gemm_bias_act(const float *A, long long M, int K, c
             static const bool autotune = !(getenv("LIDAR_LT_AUTOTUNE") && atoi(getenv("LIDAR_LT_AUTOTUNE")) == 0);
             hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;      // (a capturing stream must not be synchronised: first pick)
             (void)hipStreamIsCapturing((hipStream_t)stream, &cap);
-            if (best >= 0 && autotune && found > 1 && cap == hipStreamCaptureStatusNone) {
+            // a pick imported from another rank (same library, same GPU model: the heuristic list is the same) wins over timing here,
+            // so that N ranks run the SAME kernel instead of N independent timing decisions
+            int imported = -1;
+            for (auto &c : g_imported)
+                if (c.M == M && c.K == K && c.N == N && c.ldd == ldd && c.relu == (relu != 0) && c.has_bias == (bias != nullptr)) imported = c.pick;
+            if (imported >= 0 && imported < found && res[imported].state == HIPBLAS_STATUS_SUCCESS && res[imported].workspaceSize <= max_ws)
+                best = imported;
+            else
+                imported = -1;
+            if (best >= 0 && imported < 0 && autotune && found > 1 && cap == hipStreamCaptureStatusNone) {
                 hipStream_t s = (hipStream_t)stream;
                 hipEvent_t e0, e1;
                 const float one = 1.f, zero = 0.f;
@@ -143,6 +160,7 @@ LIDAR_EXPORT int lidar_dense_gemm_bias_act(const float *A, long long M, int K, c
                 }
             }
             if (best >= 0) {
+                q.pick = best;
                 q.algo = res[best].algo;
                 q.algo_ws = res[best].workspaceSize;
                 q.usable = true;
@@ -158,4 +176,31 @@ LIDAR_EXPORT int lidar_dense_gemm_bias_act(const float *A, long long M, int K, c
     const hipblasStatus_t st = api->matmul(g_handle, plan->desc, &alpha, W, plan->la, A, plan->lb, &beta, D, plan->ld, D, plan->ld,
                                            &plan->algo, ws, plan->algo_ws, (hipStream_t)stream);
     return st == HIPBLAS_STATUS_SUCCESS ? LIDAR_OK : LIDAR_ERR_LAUNCH;
+}
+
+// Candidate picks of this process's plans, 7 ints each {M (low 31 bits), M >> 31, K, N, ldd, relu | has_bias << 1, pick}: -> number
+// of plans (also when cap is smaller; only min(n, cap) are written).  A launcher hands rank 0's list to the other ranks
+// (lidar_dense_gemm_import_choices BEFORE their first call of a shape) so that every rank runs the same library kernel.
+LIDAR_EXPORT int lidar_dense_gemm_export_choices(int *out7, int cap) {
+    std::lock_guard<std::mutex> lock(g_mu);
+    int n = 0;
+    for (auto &q : g_plans) {
+        if (!q.usable) continue;
+        if (out7 && n < cap) {
+            int *o = out7 + 7 * n;
+            o[0] = (int)(q.M & 0x7FFFFFFF); o[1] = (int)(q.M >> 31); o[2] = q.K; o[3] = q.N; o[4] = q.ldd;
+            o[5] = q.relu | (q.has_bias << 1); o[6] = q.pick;
+        }
+        ++n;
+    }
+    return n;
+}
+LIDAR_EXPORT int lidar_dense_gemm_import_choices(const int *in7, int n) {
+    if (!in7 || n < 0) return LIDAR_ERR_ARG;
+    std::lock_guard<std::mutex> lock(g_mu);
+    for (int i = 0; i < n; ++i) {
+        const int *o = in7 + 7 * i;
+        g_imported.push_back(LtChoice{((long long)o[1] << 31) | (long long)o[0], o[2], o[3], o[4], o[5] & 1, (o[5] >> 1) & 1, o[6]});
+    }
+    return LIDAR_OK;
 }

@@ -459,7 +459,9 @@ __global__ __launch_bounds__(256) void vx_rows_kernel(const float *__restrict__ 
 #define VXL_MAX_ITEMS 32    // n_max <= 32 * 1024 (a point index fits 15 bits)
 #define VXL_A_KEYS 1280     // keys per wave and round in phase A1: 20 per lane, five 16-byte sc1 loads in flight on one address register
 #define VXL_FILL_F4_PER_WG (1024 * 4)      // 64 KiB of zeros per fill chunk
+#ifndef VXL_WAIT_TICKS                     // (-DVXL_WAIT_TICKS=0: the test build whose every bin workgroup takes the deadline exit)
 #define VXL_WAIT_TICKS 20000               // 200 us of the 100 MHz wall clock: how long a wave re-reads a key that has not arrived
+#endif
 #define VX_NOKEY 0xFFFFFFFFu               // a shared key that has not been published (never a valid key: vx_key2)
 
 // floor(fl(d / vs)) — the reference's expression — without paying for the IEEE division when it
@@ -872,8 +874,9 @@ __global__ __launch_bounds__(1024, 8) void vxl_keybin_kernel(const float *__rest
                 for (int r = 0; r < 5; ++r)
 #pragma unroll
                     for (int c = 0; c < 4; ++c) miss |= (uint32_t)(kq[r][c] == VX_NOKEY) << (r * 4 + c);
-                if (__ballot((miss & live) != 0) == 0ull) break;       // wave-uniform
-                if (wall_clock64() > deadline) {                       // the frame's other workgroups are not (all) running beside
+                constexpr bool expired_at_once = (VXL_WAIT_TICKS) <= 0;   // test build (build.py: liblidar_hip_vxl_nowait.so)
+                if (!expired_at_once && __ballot((miss & live) != 0) == 0ull) break;       // wave-uniform
+                if (expired_at_once || wall_clock64() > deadline) {    // the frame's other workgroups are not (all) running beside
                     s_slow = 1;                                        // this one: the workgroup redoes its bin from the points
                     live = 0;                                          // themselves (streaming variant) after the barrier
                     break;
@@ -1179,7 +1182,9 @@ static int vxl_env_int(const char *name, int dflt) {
     return e ? atoi(e) : dflt;
 }
 
-struct VxTimer { hipEvent_t a, b; };
+// a = start of the first launch, a2 = its end, b0 = start of the last launch, b = its end; `recorded` only once a call has
+// really carried the events (a call that takes another path leaves the timer untouched and disarms it)
+struct VxTimer { hipEvent_t a, a2, b0, b; int recorded; };
 static thread_local VxTimer *g_next_timer = nullptr;
 
 // bin + fill launch, then emit: 2 launches
@@ -1207,7 +1212,8 @@ static void vxl_run_fused(const float *points, const int *point_offsets, const V
     // hipEventRecord bracket around the call adds (4.7-5.5 us, more when other streams are alive in the process)
     VxTimer *tm = g_next_timer;
     g_next_timer = nullptr;
-    hipEvent_t ev_a = tm ? tm->a : nullptr, ev_b = tm ? tm->b : nullptr;
+    hipEvent_t ev_a = tm ? tm->a : nullptr, ev_a2 = tm ? tm->a2 : nullptr, ev_b0 = tm ? tm->b0 : nullptr, ev_b = tm ? tm->b : nullptr;
+    if (tm) tm->recorded = 1;
     const dim3 g1(nbinwg + nfillwg), blk(1024);
     const dim3 ge(ntiles, p.batch);
     if (!tm) {                           // the ordinary path: plain launches (the event-carrying form costs ~5 us of queue time per launch)
@@ -1219,10 +1225,10 @@ static void vxl_run_fused(const float *points, const int *point_offsets, const V
         return;
     }
     if (emit_only) {}
-    else if (c4) hipExtLaunchKernelGGL(vxl_keybin_kernel<true>, g1, blk, 0, s, ev_a, nullptr, 0, points, point_offsets, p, w, G, nbinwg, nfillwg, voxels, total_f4, tf, help16, resident, (const int *)num_points);
-    else hipExtLaunchKernelGGL(vxl_keybin_kernel<false>, g1, blk, 0, s, ev_a, nullptr, 0, points, point_offsets, p, w, G, nbinwg, nfillwg, voxels, total_f4, tf, help16, resident, (const int *)num_points);
-    if (c4) hipExtLaunchKernelGGL(vxl_emit_kernel<true>, ge, blk, 0, s, nullptr, ev_b, 0, points, point_offsets, p, w, G, voxels, coords, num_points, voxel_offsets, resident);
-    else hipExtLaunchKernelGGL(vxl_emit_kernel<false>, ge, blk, 0, s, nullptr, ev_b, 0, points, point_offsets, p, w, G, voxels, coords, num_points, voxel_offsets, resident);
+    else if (c4) hipExtLaunchKernelGGL(vxl_keybin_kernel<true>, g1, blk, 0, s, ev_a, ev_a2, 0, points, point_offsets, p, w, G, nbinwg, nfillwg, voxels, total_f4, tf, help16, resident, (const int *)num_points);
+    else hipExtLaunchKernelGGL(vxl_keybin_kernel<false>, g1, blk, 0, s, ev_a, ev_a2, 0, points, point_offsets, p, w, G, nbinwg, nfillwg, voxels, total_f4, tf, help16, resident, (const int *)num_points);
+    if (c4) hipExtLaunchKernelGGL(vxl_emit_kernel<true>, ge, blk, 0, s, ev_b0, ev_b, 0, points, point_offsets, p, w, G, voxels, coords, num_points, voxel_offsets, resident);
+    else hipExtLaunchKernelGGL(vxl_emit_kernel<false>, ge, blk, 0, s, ev_b0, ev_b, 0, points, point_offsets, p, w, G, voxels, coords, num_points, voxel_offsets, resident);
 }
 
 // ------------------------------------------------------------------ C ABI
@@ -1288,6 +1294,10 @@ LIDAR_EXPORT int lidar_voxelize_hostoff(const float *points, const int *point_of
                                         const int *grid3, int max_points, int max_voxels, int compact, int algo, float *voxels,
                                         int *coords, int *num_points, int *voxel_offsets, void *ws, size_t ws_bytes,
                                         void *stream) {
+    // a timer armed with lidar_voxelize_time_next belongs to THIS call whatever path it takes: only the LDS-binned launches
+    // carry it, every other exit (argument error, global-hash path) disarms it so that no later call records into a stale handle
+    VxTimer *armed = g_next_timer;
+    g_next_timer = nullptr;
     if (!points || !point_offsets || !voxels || !coords || !num_points || !voxel_offsets || !ws) return LIDAR_ERR_ARG;
     if (batch <= 0 || num_features < 3 || max_points <= 0 || max_voxels <= 0 || n_max < 0) return LIDAR_ERR_ARG;
     if ((double)grid3[0] * grid3[1] * grid3[2] >= 4294967295.0) return LIDAR_ERR_ARG;
@@ -1330,6 +1340,7 @@ LIDAR_EXPORT int lidar_voxelize_hostoff(const float *points, const int *point_of
     if (algo == 0) algo = lds_ok ? 3 : 2;
     if (algo == 3 || algo == 4) {
         const bool unaligned = ((reinterpret_cast<uintptr_t>(voxels) & 15) != 0);      // the resident clear wants 16-B rows
+        g_next_timer = armed;
         vxl_run_fused(points, point_offsets, p, w, c4, voxels, coords, num_points, voxel_offsets, s,
                       (algo == 4 && compact && !unaligned) ? 1 : 0);
         return lidar_check_launch("lidar_voxelize(lds)");
@@ -1354,25 +1365,42 @@ LIDAR_EXPORT int lidar_voxelize_hostoff(const float *points, const int *point_of
 }
 
 // ------------------------------------------------------------------ launch timer (measurement only)
+LIDAR_EXPORT void lidar_timer_destroy(void *timer);
 LIDAR_EXPORT void *lidar_timer_create(void) {
-    VxTimer *t = new VxTimer{nullptr, nullptr};
-    if (hipEventCreate(&t->a) != hipSuccess || hipEventCreate(&t->b) != hipSuccess) { delete t; return nullptr; }
+    VxTimer *t = new VxTimer{nullptr, nullptr, nullptr, nullptr, 0};
+    if (hipEventCreate(&t->a) != hipSuccess || hipEventCreate(&t->a2) != hipSuccess || hipEventCreate(&t->b0) != hipSuccess ||
+        hipEventCreate(&t->b) != hipSuccess) {
+        lidar_timer_destroy(t);
+        return nullptr;
+    }
     return t;
 }
 LIDAR_EXPORT void lidar_timer_destroy(void *timer) {
     VxTimer *t = (VxTimer *)timer;
     if (!t) return;
-    (void)hipEventDestroy(t->a);
-    (void)hipEventDestroy(t->b);
+    if (g_next_timer == t) g_next_timer = nullptr;
+    if (t->a) (void)hipEventDestroy(t->a);
+    if (t->a2) (void)hipEventDestroy(t->a2);
+    if (t->b0) (void)hipEventDestroy(t->b0);
+    if (t->b) (void)hipEventDestroy(t->b);
     delete t;
 }
-// the calling thread's NEXT lidar_voxelize / lidar_voxelize_hostoff call (LDS-binned path) records its first launch's start and its
-// last launch's end into `timer`
+// the calling thread's NEXT lidar_voxelize / lidar_voxelize_hostoff call records, if it takes the LDS-binned path, its first
+// launch's start / end and its last launch's start / end into `timer`; on any other path the call disarms the timer unrecorded
 LIDAR_EXPORT void lidar_voxelize_time_next(void *timer) { g_next_timer = (VxTimer *)timer; }
-// waits for the stop event; milliseconds from the start of the first launch to the end of the last one (< 0: not recorded)
+// waits for the stop event; milliseconds from the start of the first launch to the end of the last one (< 0: nothing recorded)
 LIDAR_EXPORT float lidar_timer_elapsed_ms(void *timer) {
     VxTimer *t = (VxTimer *)timer;
     float ms = -1.f;
-    if (!t || hipEventSynchronize(t->b) != hipSuccess || hipEventElapsedTime(&ms, t->a, t->b) != hipSuccess) return -1.f;
+    if (!t || !t->recorded || hipEventSynchronize(t->b) != hipSuccess || hipEventElapsedTime(&ms, t->a, t->b) != hipSuccess) return -1.f;
     return ms;
+}
+// the same span split: out3 = {first launch, gap between the launches, last launch} in milliseconds (what a kernel trace of the
+// call shows as the two durations and the idle time between them); 0 on success, LIDAR_ERR_ARG when nothing was recorded
+LIDAR_EXPORT int lidar_timer_parts_ms(void *timer, float *out3) {
+    VxTimer *t = (VxTimer *)timer;
+    if (!t || !out3 || !t->recorded || hipEventSynchronize(t->b) != hipSuccess) return LIDAR_ERR_ARG;
+    if (hipEventElapsedTime(&out3[0], t->a, t->a2) != hipSuccess || hipEventElapsedTime(&out3[1], t->a2, t->b0) != hipSuccess ||
+        hipEventElapsedTime(&out3[2], t->b0, t->b) != hipSuccess) return LIDAR_ERR_LAUNCH;
+    return LIDAR_OK;
 }

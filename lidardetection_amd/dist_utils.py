@@ -51,3 +51,24 @@ def barrier(dist=None, cuda=False):
         dist.barrier()
     if cuda:
         torch.cuda.synchronize()
+
+
+def export_gemm_choices():
+    """rank 0's library-GEMM candidate picks (csrc/dense_gemm.hip) as a flat list of ints (7 per shape) for a broadcast"""
+    import ctypes
+    from . import _lib
+    L = _lib.lib()
+    n = L.lidar_dense_gemm_export_choices(None, 0)
+    buf = (ctypes.c_int * (7 * max(n, 1)))()
+    n = min(n, L.lidar_dense_gemm_export_choices(buf, max(n, 1)))
+    return [int(v) for v in buf[:7 * n]]
+
+
+def import_gemm_choices(flat):
+    """the other ranks, before their first call of those shapes: run the kernels rank 0 kept instead of timing their own"""
+    import ctypes
+    from . import _lib
+    if not flat:
+        return
+    buf = (ctypes.c_int * len(flat))(*flat)
+    _lib.check(_lib.lib().lidar_dense_gemm_import_choices(buf, len(flat) // 7), "lidar_dense_gemm_import_choices")

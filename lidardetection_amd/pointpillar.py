@@ -196,7 +196,7 @@ class PointPillarKITTI(nn.Module):
     def select_topk(self, masked, k):
         """(B, N) masked scores (-1 below SCORE_THRESH) -> the k best per frame, sorted descending: (scores (B, k), anchor indices
         (B, k)).  The HIP selection (csrc/topk.hip) breaks ties by ascending anchor index; torch.topk where it does not apply."""
-        if masked.is_cuda and anchor_post.topk_supported(masked.shape[1], k):
+        if masked.is_cuda and anchor_post.topk_supported(masked.shape[1], k, self.score_thresh):
             return anchor_post.topk_desc(masked, k, self.score_thresh)[:2]
         return torch.topk(masked, k, dim=1)
 
@@ -204,10 +204,14 @@ class PointPillarKITTI(nn.Module):
         a = self.num_anchor_per_loc
         n = head.shape[1] * head.shape[2] * a if head.dim() == 4 else head.shape[1] * a
         k = min(self.nms_pre, n)
-        if anchor_post.topk_supported(n, k):   # scores + histogram, collect, finalize: 3 launches, ties by ascending anchor index
+        if anchor_post.topk_supported(n, k, self.score_thresh):   # scores + histogram, collect, finalize: 3 launches, ties by ascending anchor index
             ws = anchor_post.topk_workspace(head.shape[0], n, head.device)
-            masked, labels_all = anchor_post.anchor_scores(head, a, self.num_class, self.score_thresh, cls_off=0, topk_ws=ws)
-            top_scores, top_idx, counts = anchor_post.topk_desc(masked, k, self.score_thresh, ws, hist_ready=True)
+            try:
+                masked, labels_all = anchor_post.anchor_scores(head, a, self.num_class, self.score_thresh, cls_off=0, topk_ws=ws)
+                top_scores, top_idx, counts = anchor_post.topk_desc(masked, k, self.score_thresh, ws, hist_ready=True)
+            except BaseException:
+                anchor_post.drop_topk_workspace(ws)       # its histogram may be filled and not consumed
+                raise
         else:
             masked, labels_all = anchor_post.anchor_scores(head, a, self.num_class, self.score_thresh, cls_off=0)
             top_scores, top_idx = torch.topk(masked, k, dim=1)        # sorted descending == nms_gpu's sort

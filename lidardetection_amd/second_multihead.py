@@ -224,7 +224,7 @@ class SECONDMultiHeadNuScenes(nn.Module):
             lab += list(labels)
             c0 += c_h
             off += n_h
-        if anchor_post.topk_supported(n_max, k):                             # csrc/topk.hip: exact, ties by ascending anchor index; slots
+        if anchor_post.topk_supported(n_max, k, self.score_thresh):                             # csrc/topk.hip: exact, ties by ascending anchor index; slots
             scores, idx, _ = anchor_post.topk_desc(masked.view(B * n_cols, n_max), k, self.score_thresh)   # past the valid ones hold (-1, 0)
             scores, idx = scores.view(B, n_cols, k), idx.view(B, n_cols, k)
         else:

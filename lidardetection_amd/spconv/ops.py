@@ -60,16 +60,22 @@ class GridPool:
         self.grids.clear()
 
     def _evict_for(self, nbytes):
-        """least-recently-used grids that hold no rows make room for a new one (another batch size or resolution: the last
-        partial eval batch, a bs-1 demo after bs-16): the pool never grows past MAX_TOTAL_BYTES.  Rare: waits for the device."""
+        """make room for a new grid of `nbytes` (another batch size or resolution: the last partial eval batch, a bs-1 demo after
+        bs-16): least-recently-used grids go first, row-holding ones included — after every forward each level's grid still holds
+        its rows (wipes are lazy), so "empty grids only" would evict nothing.  A dropped grid needs no wipe (its memory is released;
+        a level that needs one again gets a freshly initialised grid and scatters its rows again).  -> False when even an empty pool
+        cannot take it within MAX_TOTAL_BYTES: the level then uses the hash builder.  Rare: waits for the device."""
         total = sum(e[0].numel() * 4 for e in self.grids.values())
         if total + nbytes <= self.MAX_TOTAL_BYTES:
-            return
+            return True
+        if nbytes > self.MAX_TOTAL_BYTES:
+            return False
         torch.cuda.synchronize()                 # a grid may still be in use on any stream
-        for key in sorted((k for k, e in self.grids.items() if e[2] == 0), key=lambda k: self.grids[k][6]):
+        for key in sorted(self.grids, key=lambda k: self.grids[k][6]):
             total -= self.grids.pop(key)[0].numel() * 4
             if total + nbytes <= self.MAX_TOTAL_BYTES:
                 break
+        return total + nbytes <= self.MAX_TOTAL_BYTES
 
     def _entry(self, device, batch, shape):
         key = (str(device), int(batch), *[int(v) for v in shape])
@@ -81,7 +87,8 @@ class GridPool:
             cells = int(batch) * int(shape[0]) * int(shape[1]) * int(shape[2])
             if not self.ENABLED or cells * 4 > self.MAX_BYTES_PER_GRID or cells <= 0:
                 return None
-            self._evict_for(cells * 4)
+            if not self._evict_for(cells * 4):
+                return None
             grid = torch.empty(cells, dtype=torch.int32, device=device)
             _lib.check(_lib.lib().lidar_spconv_grid_init(_lib.ptr(grid), cells, _lib.stream()), "lidar_spconv_grid_init")
             ent = self.grids[key] = [grid, None, 0, None, None, int(batch), self.counter]

@@ -100,7 +100,14 @@ class BatchVoxelizer:
         if host_offsets is not None:
             if len(host_offsets) != batch + 1:
                 raise _lib.LidarHipError("host_offsets must hold batch + 1 entries")
-            hoff = (ctypes.c_int * (batch + 1))(*[int(v) for v in host_offsets])
+            hv = [int(v) for v in host_offsets]
+            # the LDS-binned launches read the points through THESE offsets (kernel arguments), not the device array: a stale
+            # or foreign list would walk past `points`.  Everything needed to refuse it is on the host — no synchronisation.
+            if hv[0] < 0 or hv[-1] > points.shape[0] or any(b < a for a, b in zip(hv, hv[1:])):
+                raise _lib.LidarHipError(f"host_offsets must be non-decreasing within [0, {points.shape[0]}] (got {hv[0]}..{hv[-1]})")
+            if batch and max(b - a for a, b in zip(hv, hv[1:])) > n_max:
+                raise _lib.LidarHipError(f"host_offsets hold a frame longer than n_max = {n_max}")
+            hoff = (ctypes.c_int * (batch + 1))(*hv)
         if timer is not None:
             L.lidar_voxelize_time_next(timer)
         _lib.check(L.lidar_voxelize_hostoff(_lib.ptr(points), _lib.ptr(point_offsets), hoff, batch, n_max, self.C, self._range_h,

@@ -1,0 +1,45 @@
+"""Host side of csrc/wino_conv.hip: the stride-1 3x3 convolutions of the dense BEV backbone (pcdet/models/backbones_2d/
+base_bev_backbone.py:34-45) as Winograd F(2x2, 3x3) on the fp32 matrix cores, shift + ReLU in the kernel's epilogue."""
+import torch
+
+from . import _lib
+
+
+def supported(cin, cout):
+    return bool(_lib.lib().lidar_wino_supported(int(cin), int(cout)))
+
+
+def pack_weights(w):
+    """w (Cout, Cin, 3, 3) fp32 (BatchNorm scale folded in) -> the packed transformed filters the kernel reads (16 Cin Cout floats)"""
+    _lib.require_cuda(w.contiguous())
+    if w.dim() != 4 or tuple(w.shape[2:]) != (3, 3) or w.dtype != torch.float32 or not supported(w.shape[1], w.shape[0]):
+        raise _lib.LidarHipError(f"wino.pack_weights: expected a float32 (Cout % 32 == 0, Cin % 8 == 0, 3, 3) weight, got {tuple(w.shape)}")
+    wc = w.detach().contiguous()                      # plain (Cout, Cin, 3, 3) order whatever the memory format of `w`
+    if wc.stride() != (wc.shape[1] * 9, 9, 3, 1):
+        wc = wc.clone(memory_format=torch.contiguous_format)
+    L = _lib.lib()
+    packed = torch.empty(L.lidar_wino_packed_floats(w.shape[1], w.shape[0]), dtype=torch.float32, device=w.device)
+    _lib.check(L.lidar_wino_pack_weights(_lib.ptr(wc), w.shape[1], w.shape[0], _lib.ptr(packed), _lib.stream()), "lidar_wino_pack_weights")
+    return packed
+
+
+def conv3x3(x, packed, cout, bias=None, relu=True, out=None, out_offset=0):
+    """x (B, Cin, H, W) channels-last fp32 -> act(conv3x3(x, w, padding=1) + bias) as a channels-last (B, cout, H, W) tensor, or
+    into channels [out_offset, out_offset + cout) of the channels-last `out` (B, C_out, H, W)."""
+    _lib.require_cuda(packed, bias)
+    if not (x.is_cuda and x.dim() == 4 and x.dtype == torch.float32 and x.is_contiguous(memory_format=torch.channels_last)):
+        raise _lib.LidarHipError("wino.conv3x3: expected a channels-last float32 CUDA tensor")
+    B, cin, H, W = x.shape
+    L = _lib.lib()
+    if packed.numel() != L.lidar_wino_packed_floats(cin, cout) or packed.numel() == 0:
+        raise _lib.LidarHipError("wino.conv3x3: packed filters do not match (Cin, Cout)")
+    if bias is not None and bias.numel() != cout:
+        raise _lib.LidarHipError("wino.conv3x3: bias must hold Cout values")
+    if out is None:
+        out, out_offset = torch.empty((B, cout, H, W), dtype=torch.float32, device=x.device, memory_format=torch.channels_last), 0
+    elif not (out.is_cuda and out.dtype == torch.float32 and out.is_contiguous(memory_format=torch.channels_last)
+              and out.shape[0] == B and tuple(out.shape[2:]) == (H, W) and 0 <= out_offset and out_offset + cout <= out.shape[1]):
+        raise _lib.LidarHipError("wino.conv3x3: output must be channels-last (B, C_out, H, W) with room for the slice")
+    _lib.check(L.lidar_wino_conv3x3_nhwc(_lib.ptr(x), B, H, W, cin, _lib.ptr(packed), _lib.ptr(bias), int(bool(relu)), int(cout),
+                                         _lib.ptr(out), out.shape[1], int(out_offset), _lib.stream()), "lidar_wino_conv3x3_nhwc")
+    return out

@@ -78,3 +78,28 @@ def test_bench_refuses_a_world_size_mismatch():
     r = _run_bench(["--gpus", "4", "--dry-run"], env={"WORLD_SIZE": "1", "RANK": "0", "LOCAL_RANK": "0"})
     assert r.returncode != 0 and "WORLD_SIZE=1" in r.stderr
     assert not [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+
+
+def test_bench_train_ddp_mode_two_ranks_dry_run():
+    """`bench.py --gpus 2 --mode train-ddp` (BASELINE configs[4]'s DDP leg; reference: tools/train.py:141-142 wraps the model in
+    DistributedDataParallel, process group from pcdet/utils/common_utils.py:170-184): two ranks through the launcher, the DDP
+    reducer, the no_sync re-timing, the stand-alone all-reduce and the single JSON line — on CPU / gloo with the stand-in model."""
+    import json
+    r = _run_bench(["--gpus", "2", "--mode", "train-ddp", "--steps", "3", "--warmup", "1", "--dry-run"])
+    assert r.returncode == 0, r.stderr
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1
+    rec = json.loads(lines[0])
+    assert rec["n_gpus"] == 2 and rec["steps"] == 3 and rec["dry_run"] is True and rec["scaling"] == "weak"
+    assert rec["config"]["batch_per_gpu"] == 4 and rec["config"]["parallelism"].startswith("ddp2")
+    ar = rec["allreduce"]
+    assert ar["gradient_bytes"] > 0 and ar["alone_ms"] > 0 and ar["step_ms_no_sync"] > 0
+    assert abs(rec["value"] - 4 * 2 * 3 / (rec["ms_per_step"] * 3e-3)) < 1e-6 * rec["value"]       # whole-job samples / s
+
+
+def test_gemm_choice_export_import_round_trip():
+    """N > 1: rank 0's library-GEMM picks travel to the other ranks as a flat int list (csrc/dense_gemm.hip export / import);
+    on a box without a GPU there are no plans yet: empty export, import of a foreign list accepted (it only seeds later plans)"""
+    assert dist_utils.export_gemm_choices() == []
+    dist_utils.import_gemm_choices([857088 & 0x7FFFFFFF, 0, 64, 128, 384, 3, 2])
+    dist_utils.import_gemm_choices([])

@@ -215,3 +215,41 @@ def test_second_kitti_bs16_timed_path_over_successive_batches(dev):
         for k in keys:
             n_rows = total if k != "voxel_offsets" else ref[k].numel()
             assert torch.equal(m._vox_out[k][:n_rows], ref[k][:n_rows]), f"device-offset entry: {k}"
+
+
+def test_pinned_feeder_batches_voxelise_bit_exactly(dev):
+    """raw clouds staged in pinned memory and copied on a side stream while the previous batch is processed
+    (lidardetection_amd/feeder.py; the reference: dataset.py:153-185 collate + models/__init__.py:16-22 synchronous .cuda()).
+    Six successive batches of different sizes through TWO staging slots in bench.py's order (submit k+1, then get + voxelise k,
+    with a long kernel in between so that copies and compute really overlap): every fed batch voxelises to the oracle's bits in
+    the resident buffer, the host offsets it carries are the device offsets, and misuse is refused."""
+    from lidardetection_amd import _lib
+    from lidardetection_amd.feeder import PinnedPointFeeder
+    from lidardetection_amd.voxelizer import BatchVoxelizer
+    P, maxv = 32, 16000
+    bt = _batches(synth.PP_RANGE)
+    seq = [bt["uniform"][:5], bt["short"][:8], bt["ring"][:3], bt["short"][8:], bt["uniform"][5:9], [np.zeros((0, 4), np.float32)] * 2]
+    feeder = PinnedPointFeeder(8 * 20000, 4, max_batch=8, device=dev, depth=2)
+    vz = BatchVoxelizer(synth.PP_VOXEL, synth.PP_RANGE, P, maxv, 4)
+    outs = {}
+    busy = torch.empty(64 << 20, device=dev)
+    feeder.submit(seq[0])
+    for k, frames in enumerate(seq):
+        if k + 1 < len(seq):
+            feeder.submit(seq[k + 1])                    # overlaps with this batch's kernels
+        fb = feeder.get()
+        assert fb.batch == len(frames) and fb.host_offsets == [int(v) for v in np.concatenate([[0], np.cumsum([len(f) for f in frames])])]
+        assert fb.offsets.cpu().tolist() == fb.host_offsets
+        out = outs.setdefault(fb.batch, vz.alloc_outputs(fb.batch, dev))
+        pts = fb.points if fb.points.shape[0] else torch.zeros((1, 4), device=dev)
+        vox = vz(pts, fb.offsets, max(fb.n_max, 1), out=out, resident=False, host_offsets=fb.host_offsets)
+        for _ in range(20):
+            busy.mul_(1.0001)                            # keeps the compute stream busy while the next copy is in flight
+        _check_voxels(vox, frames, synth.PP_VOXEL, synth.PP_RANGE, P, maxv, f"fed batch {k}")
+    with pytest.raises(_lib.LidarHipError):
+        feeder.get()                                     # nothing submitted
+    feeder.submit(seq[0]); feeder.submit(seq[1])
+    with pytest.raises(_lib.LidarHipError):
+        feeder.submit(seq[2])                            # both slots un-fetched
+    with pytest.raises(_lib.LidarHipError):
+        PinnedPointFeeder(100, 4, max_batch=2, device=dev).submit(seq[0])      # does not fit

@@ -118,6 +118,65 @@ def test_voxelize_zero_padded_clouds_on_the_hot_path(dev):
     assert vz.error_flag(len(frames), max(sizes), dev) == 0
 
 
+def test_voxelize_deadline_fallback_every_bin_workgroup(dev, monkeypatch):
+    """csrc/voxelize.hip phase A1: a wave whose shared keys have not arrived by its deadline sets s_slow and the workgroup rebuilds
+    its bin from the points themselves (vxl_bin_streaming).  An ordinary run never gets there, so the same source is built a second
+    time with -DVXL_WAIT_TICKS=0 (csrc/build.py VARIANTS["vxl_nowait"]): EVERY bin workgroup of that library takes the deadline
+    exit.  Same contract: bit-exact against the sequential oracle (data_processor.py:48-80 semantics), error flag 0 — on the
+    PointPillar / SECOND / NuScenes shapes, a > 20 480-point frame (two key rounds), the zero-padded batch, through both entries
+    (device offsets and host offsets) and in resident mode."""
+    from lidardetection_amd import _lib
+    from lidardetection_amd.csrc import build as hip_build
+    variant = _lib.load_variant(hip_build.variant_path("vxl_nowait"))
+    _lib.lib()
+    monkeypatch.setattr(_lib, "_lib", variant)
+    big = np.concatenate([synth.cloud_uniform(1003), synth.cloud_uniform(1004, n=9000)], 0)          # 29 000 points: two rounds
+    cases = [([synth.cloud_ring(2000), synth.cloud_uniform(1000), np.zeros((0, 4), np.float32), synth.cloud_uniform(1001, n=333)],
+              synth.PP_VOXEL, synth.PP_RANGE, 32, 16000, 4),
+             ([big, synth.cloud_ring(2001)[:7777]], synth.PP_VOXEL, synth.PP_RANGE, 32, 16000, 4),
+             ([synth.cloud_ring(2000), synth.cloud_uniform(1000, pc_range=synth.SEC_RANGE)], synth.SEC_VOXEL, synth.SEC_RANGE, 5, 16000, 4),
+             ([synth.cloud_nus(4000), synth.cloud_nus(4001)[:12345]], synth.NUS_VOXEL, synth.NUS_RANGE, 10, 60000, 5),
+             ([_zero_padded(synth.cloud_ring(2000)[:9000], 11000), _zero_padded(synth.cloud_uniform(1000, n=12000), 8000),
+               synth.cloud_uniform(1001)], synth.PP_VOXEL, synth.PP_RANGE, 32, 16000, 4)]
+    for frames, vs, rng, P, maxv, C in cases:
+        exp = [c_oracle.voxelize(f, vs, rng, P, maxv) for f in frames]
+        ev, ec, en = pp_oracle.collate(exp)
+        _check_one_algo(frames, vs, rng, P, maxv, C, dev, 2, 3, exp, ev, ec, en)
+        sizes = [len(f) for f in frames]
+        hoffs = [int(v) for v in np.concatenate([[0], np.cumsum(sizes)])]
+        pts = torch.from_numpy(np.concatenate(frames)).to(dev)
+        offs = torch.tensor(hoffs, dtype=torch.int32, device=dev)
+        vz = BatchVoxelizer(vs, rng, P, maxv, C)
+        out = vz.alloc_outputs(len(frames), dev)
+        out["voxels"].fill_(float("nan"))
+        for k in range(3):                              # resident mode + host offsets: first call full fill, then slot clears
+            o = vz(pts, offs, max(sizes), out=out, resident=True, host_offsets=hoffs if k else None)
+            total = int(o["voxel_offsets"][-1].item())
+            assert total == len(ev)
+            assert np.array_equal(o["voxels"][:total].cpu().numpy().view(np.uint32), ev.view(np.uint32))
+            assert np.array_equal(o["voxel_coords"][:total].cpu().numpy(), ec.astype(np.int32))
+            assert np.array_equal(o["voxel_num_points"][:total].cpu().numpy(), en)
+            assert not o["voxels"][total:].any()
+        assert vz.error_flag(len(frames), max(sizes), dev) == 0
+        vz.poll_error()
+
+
+def test_voxelize_refuses_bad_host_offsets(dev):
+    """the LDS-binned launches read the points through the HOST offsets (kernel arguments); a stale list — another
+    batch's, or one that ends beyond the point buffer — must be refused on the host before any launch."""
+    from lidardetection_amd import _lib
+    frames = [synth.cloud_uniform(1000, n=5000), synth.cloud_uniform(1001, n=4000)]
+    pts = torch.from_numpy(np.concatenate(frames)).to(dev)
+    offs = torch.tensor([0, 5000, 9000], dtype=torch.int32, device=dev)
+    vz = BatchVoxelizer(synth.PP_VOXEL, synth.PP_RANGE, 32, 16000, 4)
+    good = vz(pts, offs, 5000, host_offsets=[0, 5000, 9000])
+    for bad in ([0, 5000, 9001], [0, 6000, 5000], [-1, 5000, 9000], [0, 5000], [0, 1, 9000], [0, 8000, 9000]):
+        with pytest.raises(_lib.LidarHipError):
+            vz(pts, offs, 5000, host_offsets=bad)
+    again = vz(pts, offs, 5000, host_offsets=np.array([0, 5000, 9000]))
+    assert torch.equal(good["voxels"][:int(good["voxel_offsets"][-1])], again["voxels"][:int(again["voxel_offsets"][-1])])
+
+
 def _cells_of_one_bin(n_cells, G, nx=432, ny=496):
     """pillar centres of `n_cells` distinct PointPillar cells whose keys all fall into hash bin 0 of G (csrc/voxelize.hip)"""
     cell = np.arange(nx * ny, dtype=np.uint64)          # vxl_bin_of24: top log2(G) bits of a 24-bit multiplicative hash of the
@@ -475,7 +534,7 @@ def test_topk_desc_exact_deterministic_with_ties(dev, case):
     (the radix-select path), with fewer valid scores than k, with none, and for k < 4096; torch.topk agrees wherever scores are
     distinct."""
     from lidardetection_amd import anchor_post
-    r = np.random.default_rng(hash(case) % 1000)
+    r = np.random.default_rng(__import__("zlib").crc32(case.encode()) % 1000)   # fixed per case: hash() changes with PYTHONHASHSEED
     B, n, k, thr = 3, 321408, 4096, 0.1
     s = r.uniform(0.0, 1.0, (B, n)).astype(np.float32)
     if case == "quantised":
@@ -664,3 +723,42 @@ def test_voxelize_resident_output_equals_fresh_output(dev, shape):
     out["voxels"][5000:].fill_(float("nan"))              # (those rows are "unspecified" after a non-resident call)
     run_and_check(["dense"] * 3, out)
     assert vz.error_flag(B, n_max, dev) == 0
+
+
+@pytest.mark.parametrize("limit_offset", [0.0, 0.5])
+def test_direction_bin_fixup_known_answers(dev, limit_offset):
+    """generate_predicted_boxes' direction fix-up (pcdet/models/dense_heads/anchor_head_template.py:253-266 with
+    common_utils.limit_period :52-55): heading = limit_period(rg - DIR_OFFSET, DIR_LIMIT_OFFSET, period) + DIR_OFFSET + period * bin,
+    period = 2 pi / NUM_DIR_BINS.  No reference fixture can exist for it (the golden decode has NUM_DIR_BINS = 0), so the expected
+    headings are worked out BY HAND in closed form: with DIR_LIMIT_OFFSET = 0 the residue lies in [0, pi) — a heading 0.3 below
+    DIR_OFFSET wraps to pi - 0.3 above it; with 0.5 it lies in [-pi/2, pi/2) — the wrap sits at +-pi/2.  Two anchors per location,
+    two direction bins (KITTI configs: DIR_OFFSET 0.78539, NUM_DIR_BINS 2), each case with bin 0 and bin 1 winning."""
+    from lidardetection_amd import anchor_post
+    pi, off = np.pi, 0.78539
+    # (rg - DIR_OFFSET, residue for DIR_LIMIT_OFFSET 0, residue for DIR_LIMIT_OFFSET 0.5)
+    cases = [(0.3, 0.3, 0.3), (-0.3, pi - 0.3, -0.3), (pi + 0.5, 0.5, 0.5), (-pi - 0.5, pi - 0.5, -0.5), (0.0, 0.0, 0.0),
+             (pi / 2 - 1e-3, pi / 2 - 1e-3, pi / 2 - 1e-3), (pi / 2 + 1e-3, pi / 2 + 1e-3, -pi / 2 + 1e-3),
+             (-pi / 2 - 1e-3, pi / 2 - 1e-3, pi / 2 - 1e-3), (-pi / 2 + 1e-3, pi / 2 + 1e-3, -pi / 2 + 1e-3),
+             (2 * pi + 0.25, 0.25, 0.25), (3.0, 3.0, 3.0 - pi), (-3.0, pi - 3.0, pi - 3.0), (7.5, 7.5 - 2 * pi, 7.5 - 2 * pi)]
+    A, nb = 2, 2
+    n_loc = len(cases)
+    head = np.zeros((1, n_loc, A * 7 + A * nb), np.float32)
+    anchors = np.zeros((n_loc * A, 7), np.float32)
+    anchors[:, 3:6] = [3.9, 1.6, 1.56]
+    want = np.zeros((n_loc * A,), np.float64)
+    for i, (val, r0, r5) in enumerate(cases):
+        for a in range(A):
+            ra = np.float32(0.0 if a == 0 else 1.57)                     # the two anchor rotations of the KITTI configs
+            anchors[i * A + a, 6] = ra
+            head[0, i, a * 7 + 6] = np.float32(np.float32(off) + np.float32(val)) - ra     # encoded angle: rg = t + ra = off + val
+            lab = (i + a) % 2
+            head[0, i, A * 7 + a * nb + lab] = 1.0                       # that bin's logit wins
+            want[i * A + a] = (r0 if limit_offset == 0.0 else r5) + off + pi * lab
+    idx = torch.arange(n_loc * A, device=dev).view(1, -1)
+    boxes = anchor_post.decode_topk(torch.from_numpy(head).to(dev), idx, torch.from_numpy(anchors).to(dev), A, box_off=0, dir_off=A * 7,
+                                    num_dir_bins=nb, dir_offset=off, dir_limit_offset=limit_offset)
+    got = boxes[0, :, 6].cpu().numpy().astype(np.float64)
+    # fp32 evaluation of a closed form: a few ulp of values up to ~10 (the exact-zero case (0.0, ...) sits on a floor() boundary
+    # and is placed so that fp32 rounding cannot cross it: rg - DIR_OFFSET == 0 exactly)
+    np.testing.assert_allclose(got, want, rtol=0, atol=4e-6)
+    assert np.array_equal(boxes[0, :, 3:6].cpu().numpy(), anchors[:, 3:6])      # exp(0) * size: untouched by the fix-up

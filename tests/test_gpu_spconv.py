@@ -576,3 +576,45 @@ def test_grid_pool_budget_evicts_least_recently_used_grids(dev):
     finally:
         ops.GridPool.MAX_TOTAL_BYTES = keep
         ops.GRIDS.reset()
+
+
+def test_grid_pool_budget_holds_when_every_grid_still_holds_rows(dev):
+    """after a forward every level's grid still holds its rows (wipes are lazy), so "evict empty grids only" evicted
+    nothing and the pool grew past its budget.  Two batch sizes through the same levels WITHOUT wipe_all in between: the pool stays
+    within MAX_TOTAL_BYTES, a grid that cannot fit at all sends its level to the hash builder, and every table is unchanged."""
+    from lidardetection_amd.spconv import ops
+    keep = ops.GridPool.MAX_TOTAL_BYTES
+    ops.GRIDS.reset()
+    shape, big = [9, 14, 16], [41, 60, 52]
+    nbytes = lambda b, s: b * s[0] * s[1] * s[2] * 4
+    ops.GridPool.MAX_TOTAL_BYTES = nbytes(4, shape) + nbytes(4, [5, 7, 8]) + 64        # one bs-4 forward's two levels, nothing more
+    try:
+        ref = {}
+        for B in (4, 2, 4, 1):
+            c = torch.from_numpy(_sites(40 + B, B, shape, 60 * B)).to(dev)
+            d = {}
+            got = (ops.subm_rulebook(c, shape, [3, 3, 3], B, d), *ops.conv_rulebook(c, B, shape, [3, 3, 3], [2, 2, 2], [1, 1, 1], d))
+            assert ops.GRIDS.holds_rows()                                              # nothing wiped: the r03 failure case
+            assert sum(e[0].numel() * 4 for e in ops.GRIDS.grids.values()) <= ops.GridPool.MAX_TOTAL_BYTES, B
+            ops.GridPool.ENABLED = False
+            try:
+                d = {}
+                want = (ops.subm_rulebook(c, shape, [3, 3, 3], B, d), *ops.conv_rulebook(c, B, shape, [3, 3, 3], [2, 2, 2], [1, 1, 1], d))
+            finally:
+                ops.GridPool.ENABLED = True
+            for a, b in zip(got, want):
+                assert torch.equal(a, b), B
+            ref[B] = got
+        # a level whose grid alone exceeds the whole budget: no grid, hash builder, same table
+        c = torch.from_numpy(_sites(77, 2, big, 500)).to(dev)
+        assert ops.GRIDS._entry(dev, 2, big) is None
+        a = ops.subm_rulebook(c, big, [3, 3, 3], 2, {})
+        ops.GridPool.ENABLED = False
+        try:
+            assert torch.equal(a, ops.subm_rulebook(c, big, [3, 3, 3], 2, {}))
+        finally:
+            ops.GridPool.ENABLED = True
+        assert sum(e[0].numel() * 4 for e in ops.GRIDS.grids.values()) <= ops.GridPool.MAX_TOTAL_BYTES
+    finally:
+        ops.GridPool.MAX_TOTAL_BYTES = keep
+        ops.GRIDS.reset()

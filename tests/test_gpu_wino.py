@@ -1,0 +1,87 @@
+"""csrc/wino_conv.hip — the stride-1 3x3 convolutions of BaseBEVBackbone (pcdet/models/backbones_2d/base_bev_backbone.py:34-45:
+Conv2d(3x3, padding 1, bias=False) + BatchNorm2d + ReLU) as Winograd F(2x2, 3x3) on the fp32 matrix cores.
+Oracle: the direct convolution evaluated in float64 (torch CPU), which is what the reference's cuDNN fp32 convolution
+approximates; tolerance 1e-4 of the output scale (north_star), written at each assert; measured error ~1e-6.
+The reference-golden test of the whole folded backbone (tests/test_gpu_pointpillar_path.py::test_bev_backbone_and_box_decode_...)
+runs through the same kernel once FoldedBEVBackbone routes its eligible layers here."""
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+from lidardetection_amd import _lib, wino
+
+pytestmark = pytest.mark.gpu
+
+
+def _ref(x, w, bias, relu):
+    y = F.conv2d(x.double().cpu(), w.double().cpu(), None if bias is None else bias.double().cpu(), 1, 1)
+    return torch.relu(y) if relu else y
+
+
+@pytest.mark.parametrize("B,cin,cout,H,W", [
+    (2, 64, 64, 20, 36),       # 2 x 2 waves, partial blocks in both directions
+    (1, 64, 64, 16, 16),       # exactly one workgroup
+    (3, 128, 128, 14, 22),     # 1 x 4 waves
+    (2, 256, 256, 9, 11),      # two channel groups per spatial block, odd sizes (bounds in the last tile row / column)
+    (1, 8, 32, 7, 5),          # smallest supported channel counts: 4 x 1 waves, two chunks
+    (2, 64, 128, 6, 40),       # Cin != Cout
+    (1, 128, 64, 33, 17),
+])
+def test_wino_conv3x3_vs_float64_direct_convolution(dev, B, cin, cout, H, W):
+    g = torch.Generator(device="cpu").manual_seed(1000 * cin + cout + H)
+    x = torch.randn(B, cin, H, W, generator=g)
+    x[:, :, 0, :] += 2.0                                    # make the borders matter (zero padding must really be zero)
+    x[:, :, :, -1] -= 3.0
+    w = torch.randn(cout, cin, 3, 3, generator=g) / np.sqrt(9 * cin)
+    bias = torch.randn(cout, generator=g)
+    xd = x.to(dev).contiguous(memory_format=torch.channels_last)
+    packed = wino.pack_weights(w.to(dev))
+    for relu, b in ((True, bias), (False, None), (False, bias)):
+        want = _ref(x, w, b, relu)
+        got = wino.conv3x3(xd, packed, cout, None if b is None else b.to(dev), relu)
+        assert got.shape == want.shape and got.is_contiguous(memory_format=torch.channels_last)
+        scale = max(1.0, float(want.abs().max()))
+        err = float((got.double().cpu() - want).abs().max())
+        assert err <= 1e-4 * scale, (err, scale)            # north_star tolerance; typically 2e-6
+    # channels-last weights (what FoldedBEVBackbone holds) pack to the same filters
+    assert torch.equal(wino.pack_weights(w.to(dev).contiguous(memory_format=torch.channels_last)), packed)
+
+
+def test_wino_conv3x3_writes_its_channel_slice_only(dev):
+    """out_off / out_C: the layer's channels inside a wider NHWC map (base_bev_backbone.py:103 concat), neighbours untouched"""
+    g = torch.Generator(device="cpu").manual_seed(5)
+    x = torch.randn(2, 64, 12, 20, generator=g)
+    w = torch.randn(64, 64, 3, 3, generator=g) / 24.0
+    bias = torch.randn(64, generator=g)
+    out = torch.full((2, 160, 12, 20), 7.0, device=dev).contiguous(memory_format=torch.channels_last)
+    wino.conv3x3(x.to(dev).contiguous(memory_format=torch.channels_last), wino.pack_weights(w.to(dev)), 64, bias.to(dev), True, out=out, out_offset=32)
+    want = _ref(x, w, bias, True)
+    assert float((out[:, 32:96].double().cpu() - want).abs().max()) <= 1e-4 * max(1.0, float(want.abs().max()))
+    assert bool((out[:, :32] == 7.0).all()) and bool((out[:, 96:] == 7.0).all())
+
+
+def test_wino_conv3x3_is_deterministic_and_matches_miopen(dev):
+    """run-to-run bit-identical (fixed summation order, no atomics — the library's split-K kernels are not), and within 1e-4 of
+    the stock fp32 convolution on a backbone-sized map (PointPillar block 2: 128 channels, 124 x 108)"""
+    g = torch.Generator(device="cpu").manual_seed(9)
+    x = torch.randn(4, 128, 124, 108, generator=g).to(dev).contiguous(memory_format=torch.channels_last)
+    w = (torch.randn(128, 128, 3, 3, generator=g) / np.sqrt(9 * 128)).to(dev)
+    bias = torch.randn(128, generator=g).to(dev)
+    packed = wino.pack_weights(w)
+    a = wino.conv3x3(x, packed, 128, bias, True)
+    b = wino.conv3x3(x, packed, 128, bias, True)
+    assert torch.equal(a, b)
+    ref = torch.relu(F.conv2d(x, w.contiguous(memory_format=torch.channels_last), bias, 1, 1))
+    assert float((a - ref).abs().max()) <= 1e-4 * max(1.0, float(ref.abs().max()))
+
+
+def test_wino_boundary_rejects_unsupported_shapes(dev):
+    assert not wino.supported(4, 32) and not wino.supported(64, 48) and wino.supported(8, 32)
+    with pytest.raises(_lib.LidarHipError):
+        wino.pack_weights(torch.zeros(48, 64, 3, 3, device=dev))
+    x = torch.zeros(1, 64, 8, 8, device=dev).contiguous(memory_format=torch.channels_last)
+    with pytest.raises(_lib.LidarHipError):
+        wino.conv3x3(x, torch.zeros(16, device=dev), 64)
+    with pytest.raises(_lib.LidarHipError):
+        wino.conv3x3(torch.zeros(1, 64, 8, 8, device=dev), wino.pack_weights(torch.zeros(64, 64, 3, 3, device=dev)), 64)   # NCHW strides
