@@ -328,6 +328,15 @@ int lidar_spconv_sorted_gemm_supported(int K, int Cin, int Cout);
 int lidar_spconv_implicit_gemm_sorted(const float *in_features, const int *nbr, const int *row_mask, const int *order,
                                       int n_out, int K, int Cin, int Cout, const float *weight, const float *bias,
                                       const float *residual, int relu, float *out_features, void *stream);
+/* The same GEMM reading the weights in PACKED form: lidar_spconv_pack_weights lays the folded (K, Cin, Cout) weights out in the
+ * order the MFMA lanes consume them (once per weight update; lidar_spconv_packed_floats floats, 0 = shape not supported:
+ * Cin in {16, 32, 64, 128}, Cout % 4 == 0, K <= 32), so that a stage goes global -> LDS by LDS-DMA and the B operands of four
+ * MFMA steps are one 128-bit LDS read.  Same products in the same order: bit-identical to lidar_spconv_implicit_gemm_sorted. */
+size_t lidar_spconv_packed_floats(int K, int Cin, int Cout);
+int lidar_spconv_pack_weights(const float *weight, int K, int Cin, int Cout, float *packed, void *stream);
+int lidar_spconv_implicit_gemm_sorted_packed(const float *in_features, const int *nbr, const int *row_mask, const int *order,
+                                             int n_out, int K, int Cin, int Cout, const float *packed, const float *bias,
+                                             const float *residual, int relu, float *out_features, void *stream);
 /* weight gradient: grad_weight (K, Cin, Cout) += sum_j in[nbr[j][k]]^T (x) grad_out[j]; zero-filled by the caller */
 int lidar_spconv_wgrad(const float *in_features, const float *grad_out, const int *nbr, int n_out, int K, int Cin, int Cout,
                        float *grad_weight, void *stream);

@@ -83,6 +83,9 @@ SIGNATURES = {
     "lidar_spconv_mask_group": (i32, [vp, i32, i32, vp, vp, vp, sz, vp]),
     "lidar_spconv_sorted_gemm_supported": (i32, [i32, i32, i32]),
     "lidar_spconv_implicit_gemm_sorted": (i32, [vp, vp, vp, vp, i32, i32, i32, i32, vp, vp, vp, i32, vp, vp]),
+    "lidar_spconv_packed_floats": (sz, [i32, i32, i32]),
+    "lidar_spconv_pack_weights": (i32, [vp, i32, i32, i32, vp, vp]),
+    "lidar_spconv_implicit_gemm_sorted_packed": (i32, [vp, vp, vp, vp, i32, i32, i32, i32, vp, vp, vp, i32, vp, vp]),
     "lidar_spconv_wgrad": (i32, [vp, vp, vp, i32, i32, i32, i32, vp, vp]),
     "lidar_spconv_wgrad_mfma_supported": (i32, [i32, i32, i32]),
     "lidar_spconv_wgrad_workspace_bytes": (sz, [i32, i32, i32, i32]),

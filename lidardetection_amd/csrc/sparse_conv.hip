@@ -764,6 +764,182 @@ __global__ __launch_bounds__(256) void sc_implicit_gemm_rega_kernel(const float 
     }
 }
 
+// Packed-weight variant of the register-A kernel (r04; same shapes, same channel ownership, same summation order: results are
+// bit-identical to the register-A kernel's).  What changes is how W[k] reaches the matrix cores.  The register-A kernel fetched
+// W[k+1] into registers (wr[NW]), stored it to LDS behind the MFMAs (store_w) and read it back ONE FLOAT PER MFMA (64 ds_read_b32
+// per 64->64 stage, each with its own wait).  Here the folded weights are packed ONCE PER WEIGHT UPDATE (lidar_spconv_pack_weights)
+// in exactly the order the lanes consume them —
+//     P[k][h][u][q][lane = ak * 32 + ar][j] = W[k][h * Cin + ak * HALF + 4 u + j][32 q + ar]      (float4 over j; 0 past Cout)
+// — so that (a) a stage is a straight copy and goes global -> LDS by LDS-DMA (global_load_lds_dwordx4: no registers, no store
+// phase; NG * NT wave-instructions of 1 KB per stage), and (b) a lane reads the B operands of FOUR consecutive MFMA steps with
+// one conflict-free ds_read_b128 (lane-linear image).  One barrier per stage as before (it also drains the DMA: vmcnt(0)).
+template <int NT, int C4, int SL = 1>
+__global__ __launch_bounds__(256) void sc_implicit_gemm_pk_kernel(const float *__restrict__ in, const int *__restrict__ nbr, int n_out,
+                                                                  int K, int Cout, const float *__restrict__ Wp,
+                                                                  const float *__restrict__ bias, const float *__restrict__ residual,
+                                                                  int relu, float *__restrict__ out,
+                                                                  const int *__restrict__ row_mask, const int *__restrict__ out_row) {
+    constexpr int Cin = C4 * 4, HALF = Cin / 2, CinT = Cin * SL;
+    constexpr int NG = HALF / 4;                          // float4 gathers per lane per stage = groups of four MFMA steps
+    constexpr int NI = NG * NT;                           // 1 KB pieces (DMA wave-instructions) per stage
+    constexpr int NIW = (NI + 3) / 4;                     // ... per wave
+    extern __shared__ float4 s_w4[];                      // W stage buffers: [2][NI][64 lanes] float4
+    const int t = threadIdx.x, l = t & 63, wv = __builtin_amdgcn_readfirstlane(t >> 6);
+    const int row0 = blockIdx.x * IG_ROWS + wv * 32;
+    const int ar = l & 31, ak = l >> 5;
+    const int myrow = row0 + ar;
+    const int trow = (out_row && myrow < n_out) ? out_row[myrow] : myrow;
+    f32x16 acc[NT];
+#pragma unroll
+    for (int q = 0; q < NT; ++q)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[q][r] = 0.f;
+    __shared__ unsigned s_wmask[4];
+    unsigned wave_mask = 0xffffffffu, wg_mask = 0xffffffffu;
+    if (row_mask) {
+        unsigned m = (myrow < n_out) ? (unsigned)row_mask[trow] : 0u;
+#pragma unroll
+        for (int d = 1; d < 64; d <<= 1) m |= (unsigned)__shfl_xor((int)m, d, 64);
+        wave_mask = m;
+        if (l == 0) s_wmask[wv] = m;
+        __syncthreads();
+        wg_mask = s_wmask[0] | s_wmask[1] | s_wmask[2] | s_wmask[3];
+    }
+    auto next_k = [&](int k) {
+        if (!row_mask) return k + 1;
+        const unsigned rest = (k + 1 < 32) ? (wg_mask >> (k + 1)) : 0u;
+        return rest ? k + 1 + __builtin_ctz(rest) : K;
+    };
+    auto load_src = [&](int k) { return (myrow < n_out && k < K) ? nbr[(size_t)trow * K + k] : -1; };
+    auto wave_uses = [&](int k, int src) { return row_mask ? ((wave_mask >> k) & 1u) != 0u : __ballot(src >= 0) != 0ull; };
+    float4 ga[NG], gn[NG];
+    auto dma_w = [&](int k, int h, int buf) {             // stage (k, h) -> buffer buf: piece i = wv + 4 e by wave wv
+        const float4 *srcp = reinterpret_cast<const float4 *>(Wp) + ((size_t)(k * SL + h) * NI) * 64 + l;
+#pragma unroll
+        for (int e = 0; e < NIW; ++e) {
+            const int i = wv + 4 * e;
+            if (i < NI)
+                __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(srcp + (size_t)i * 64),
+                                                 (__attribute__((address_space(3))) void *)(s_w4 + ((size_t)buf * NI + i) * 64), 16, 0, 0);
+        }
+    };
+    auto fetch_a = [&](float4 (&g)[NG], int h, int src, bool any) {
+        const float4 *rowp = reinterpret_cast<const float4 *>(in + (size_t)max(src, 0) * CinT + h * Cin + ak * HALF);
+#pragma unroll
+        for (int u = 0; u < NG; ++u) {
+            g[u] = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (any && src >= 0) g[u] = rowp[u];
+        }
+    };
+    int k = next_k(-1), h = 0, buf = 0;
+    if (k >= K) k = K;
+    int src_cur = load_src(k), src_ahead = -1;
+    bool any = false;
+    if (k < K) {
+        any = wave_uses(k, src_cur);
+        dma_w(k, 0, 0);
+        fetch_a(ga, 0, src_cur, any);
+        src_ahead = load_src(next_k(k));
+    }
+    for (; k < K;) {
+        int kn = k, hn = h + 1;                           // the stage after this one
+        if (hn == SL) { kn = next_k(k); hn = 0; }
+        __syncthreads();                                  // this stage's W has landed for every wave; the other buffer's readers are done
+        int src_next = src_cur;
+        bool any_next = false;
+        if (kn < K) {                                     // in flight while the MFMAs below run
+            if (kn != k) {
+                src_next = src_ahead;
+                src_ahead = load_src(next_k(kn));
+            }
+            any_next = wave_uses(kn, src_next);
+            dma_w(kn, hn, buf ^ 1);
+            fetch_a(gn, hn, src_next, any_next);
+        }
+        if (any) {
+            const float4 *Wb = s_w4 + (size_t)buf * NI * 64 + l;
+#pragma unroll
+            for (int u = 0; u < NG; ++u) {
+                const float av[4] = {ga[u].x, ga[u].y, ga[u].z, ga[u].w};
+                float4 bq[NT];
+#pragma unroll
+                for (int q = 0; q < NT; ++q) bq[q] = Wb[(u * NT + q) * 64];
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+#pragma unroll
+                    for (int q = 0; q < NT; ++q) {
+                        const float bv4[4] = {bq[q].x, bq[q].y, bq[q].z, bq[q].w};
+                        acc[q] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[j], bv4[j], acc[q], 0, 0, 0);
+                    }
+                }
+            }
+        }
+        if (kn < K) {
+#pragma unroll
+            for (int u = 0; u < NG; ++u) ga[u] = gn[u];
+        }
+        src_cur = src_next;
+        any = any_next;
+        k = kn;
+        h = hn;
+        buf ^= 1;
+    }
+    const int last = n_out - 1;
+#pragma unroll
+    for (int hh = 0; hh < 2; ++hh) {
+        int orow[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            const int r = hh * 8 + j;
+            const int row = min(row0 + (r & 3) + 8 * (r >> 2) + 4 * (l >> 5), last);
+            orow[j] = out_row ? out_row[row] : row;
+        }
+#pragma unroll
+        for (int q = 0; q < NT; ++q) {
+            const int col = q * 32 + (l & 31);
+            const int cc = min(col, Cout - 1);
+            const float bv = bias ? bias[cc] : 0.f;
+            float res[8];
+#pragma unroll
+            for (int j = 0; j < 8; ++j) res[j] = 0.f;
+            if (residual) {
+#pragma unroll
+                for (int j = 0; j < 8; ++j) res[j] = residual[(size_t)orow[j] * Cout + cc];
+            }
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                const int r = hh * 8 + j;
+                const int row = row0 + (r & 3) + 8 * (r >> 2) + 4 * (l >> 5);
+                if (row < n_out && col < Cout) {
+                    const float v = acc[q][r] + bv + res[j];
+                    out[(size_t)orow[j] * Cout + col] = relu ? fmaxf(v, 0.f) : v;
+                }
+            }
+        }
+    }
+}
+
+// W (K, CinT, Cout) -> the packed order above; one thread per float4
+__global__ __launch_bounds__(256) void sc_pack_weights_kernel(const float *__restrict__ W, int K, int CinT, int Cout, int Cin, int NT,
+                                                              float4 *__restrict__ P, long long total) {
+    const long long e = (long long)blockIdx.x * 256 + threadIdx.x;
+    if (e >= total) return;
+    const int HALF = Cin / 2, NG = HALF / 4, SL = CinT / Cin;
+    long long r = e;
+    const int lane = (int)(r & 63); r >>= 6;
+    const int q = (int)(r % NT); r /= NT;
+    const int u = (int)(r % NG); r /= NG;
+    const int h = (int)(r % SL);
+    const int k = (int)(r / SL);
+    const int ar = lane & 31, ak = lane >> 5, col = q * 32 + ar;
+    float v[4] = {0.f, 0.f, 0.f, 0.f};
+    if (col < Cout) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) v[j] = W[((size_t)k * CinT + h * Cin + ak * HALF + 4 * u + j) * Cout + col];
+    }
+    P[e] = make_float4(v[0], v[1], v[2], v[3]);
+}
+
 // Wave-private variant of the register-A kernel (r03 experiment, LIDAR_SPCONV_WAVE_KERNEL=1; needs 4 waves x Cin x CW floats <= 64 KB
 // of LDS, i.e. two workgroups per CU).  MEASURED SLOWER than the register-A kernel (64->64: 418-424 vs 382-384 us, SECOND stack
 // 2.18 vs 2.01 ms): the per-offset barrier is NOT what holds the matrix pipe at 49 %.  The register-A kernel shares each W[k] stage among the four waves of a workgroup: one barrier per
@@ -1010,9 +1186,14 @@ __global__ __launch_bounds__(256) void sc_input_layer_gemm_kernel(const float *_
 // indice_conv forward / dgrad (with the transposed table and W^T) — spconv.functional indice_conv (Appendix A.3) —
 // with the inference epilogue of the reference's conv/BatchNorm1d/ReLU triplets (spconv_backbone.py:20-26) and of
 // SparseBasicBlock (spconv_backbone.py:49-63): out = act(gemm + bias + residual).
+static int sc_pk_stage_cin(int Cin) { return Cin == 128 ? 64 : Cin; }
+static bool sc_pk_supported(int K, int Cin, int Cout) {
+    return K > 0 && K <= 32 && (Cin == 16 || Cin == 32 || Cin == 64 || Cin == 128) && Cout > 0 && Cout <= IG_MAX_C && (Cout & 3) == 0;
+}
+
 static int sc_gemm_launch(const float *in_features, const int *nbr, int n_out, int K, int Cin, int Cout, const float *weight,
                           const float *bias, const float *residual, int relu, float *out_features, const int *row_mask,
-                          const int *out_row, void *stream) {
+                          const int *out_row, void *stream, const float *packed = nullptr) {
     if (n_out < 0 || K <= 0 || Cin <= 0 || Cout <= 0 || Cin > IG_MAX_C || Cout > IG_MAX_C) return LIDAR_ERR_ARG;
     if (n_out == 0) return LIDAR_OK;
     if (!in_features || !nbr || !weight || !out_features) return LIDAR_ERR_ARG;
@@ -1033,6 +1214,16 @@ static int sc_gemm_launch(const float *in_features, const int *nbr, int n_out, i
                           else hipLaunchKernelGGL((sc_implicit_gemm_rega_kernel<NT, C4, 2>), grid, dim3(256), lds_rega, s, in_features, nbr, n_out, K, Cout, weight, bias, residual, relu, out_features, row_mask, out_row); } while (0)
     const bool pipe = (Cout & 3) == 0 && (Cin == 16 || Cin == 32 || Cin == 64 || Cin == 128);
     if ((row_mask || out_row) && (!pipe || K > 32 || !row_mask || !out_row)) return LIDAR_ERR_ARG;
+    if (packed && !sc_pk_supported(K, Cin, Cout)) return LIDAR_ERR_ARG;
+    if (packed) {                                         // packed weights: LDS-DMA staging + 128-bit operand reads
+        const size_t lds_pk = (size_t)2 * cin_stage * nt * 32 * sizeof(float);
+#define IGK(NT, C4, SLV) hipLaunchKernelGGL((sc_implicit_gemm_pk_kernel<NT, C4, SLV>), grid, dim3(256), lds_pk, s, in_features, nbr, n_out, K, Cout, packed, bias, residual, relu, out_features, row_mask, out_row)
+#define IGK_NT(C4, SLV) switch (nt) { case 1: IGK(1, C4, SLV); break; case 2: IGK(2, C4, SLV); break; case 3: IGK(3, C4, SLV); break; default: IGK(4, C4, SLV); break; }
+        if (Cin == 16) { IGK_NT(4, 1) } else if (Cin == 32) { IGK_NT(8, 1) } else if (Cin == 64) { IGK_NT(16, 1) } else { IGK_NT(16, 2) }
+#undef IGK_NT
+#undef IGK
+        return lidar_check_launch("lidar_spconv_implicit_gemm(packed)");
+    }
     if (pipe) {
         const int c4 = Cin / 4;
 #define IGP_NT(C4) switch (nt) { case 1: IGP(1, C4); break; case 2: IGP(2, C4); break; case 3: IGP(3, C4); break; default: IGP(4, C4); break; }
@@ -1320,6 +1511,33 @@ LIDAR_EXPORT int lidar_spconv_implicit_gemm_sorted(const float *in_features, con
     if (!lidar_spconv_sorted_gemm_supported(K, Cin, Cout) || (n_out > 0 && (!row_mask || !out_row))) return LIDAR_ERR_ARG;
     return sc_gemm_launch(in_features, nbr, n_out, K, Cin, Cout, weight, bias, residual, relu, out_features, row_mask,
                           out_row, stream);
+}
+
+// Packed weights for the mask-ordered GEMM (sc_implicit_gemm_pk_kernel): floats needed for (K, Cin, Cout), 0 = shape not supported
+LIDAR_EXPORT size_t lidar_spconv_packed_floats(int K, int Cin, int Cout) {
+    if (!sc_pk_supported(K, Cin, Cout)) return 0;
+    return (size_t)K * Cin * divup(Cout, 32) * 32;
+}
+
+// weight (K, Cin, Cout) row-major (BatchNorm scale folded in) -> packed; once per weight update
+LIDAR_EXPORT int lidar_spconv_pack_weights(const float *weight, int K, int Cin, int Cout, float *packed, void *stream) {
+    if (!weight || !packed || !sc_pk_supported(K, Cin, Cout) || (reinterpret_cast<uintptr_t>(packed) & 15)) return LIDAR_ERR_ARG;
+    const long long total = (long long)lidar_spconv_packed_floats(K, Cin, Cout) / 4;
+    hipLaunchKernelGGL(sc_pack_weights_kernel, dim3(divup(total, 256)), dim3(256), 0, (hipStream_t)stream, weight, K, Cin, Cout,
+                       sc_pk_stage_cin(Cin), divup(Cout, 32), reinterpret_cast<float4 *>(packed), total);
+    return lidar_check_launch("lidar_spconv_pack_weights");
+}
+
+// lidar_spconv_implicit_gemm_sorted with the weights in packed form (same results, bit for bit)
+LIDAR_EXPORT int lidar_spconv_implicit_gemm_sorted_packed(const float *in_features, const int *nbr, const int *row_mask,
+                                                          const int *out_row, int n_out, int K, int Cin, int Cout,
+                                                          const float *packed, const float *bias, const float *residual, int relu,
+                                                          float *out_features, void *stream) {
+    if (!lidar_spconv_sorted_gemm_supported(K, Cin, Cout) || !sc_pk_supported(K, Cin, Cout) || (n_out > 0 && (!row_mask || !out_row)) ||
+        !packed || (reinterpret_cast<uintptr_t>(packed) & 15))
+        return LIDAR_ERR_ARG;
+    return sc_gemm_launch(in_features, nbr, n_out, K, Cin, Cout, packed, bias, residual, relu, out_features, row_mask, out_row, stream,
+                          packed);
 }
 
 LIDAR_EXPORT int lidar_spconv_implicit_gemm(const float *in_features, const int *nbr, int n_out, int K, int Cin, int Cout,

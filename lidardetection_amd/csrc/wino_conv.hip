@@ -13,30 +13,50 @@
 //   B^T = [1 0 -1 0; 0 1 1 0; 0 -1 1 0; 0 1 0 -1]   G = [1 0 0; .5 .5 .5; .5 -.5 .5; 0 0 1]   A^T = [1 1 1 0; 0 1 -1 -1]
 //
 // For each of the 16 transform positions xi the sum over cin is a plain GEMM  M_xi[tile, cout] = V_xi[tile, cin] @ U_xi[cin, cout].
-// A WAVE owns 32 tiles (4 x 8 tiles = 8 x 16 output pixels) x 32 output channels x all 16 positions: 16 accumulator tiles of
-// v_mfma_f32_32x32x2_f32 = 256 accumulator registers — one wave per SIMD, 512 registers each.  In the accumulator layout the 16
-// positions of one (tile, cout) sit in the SAME lane at the same register index of the 16 tiles, so the output transform is
-// lane-local arithmetic: no shuffles, no LDS.
-//   A operand: lane (i = lane & 31, h = lane >> 5) supplies tile i, input channel 4c + 2h + s of chunk c, K-step s — it reads the
-//              16 raw pixels of its patch (two channels each, ds_read_b64) from the workgroup's LDS image of the input region and
-//              transforms them in registers (32 packed adds per chunk).
-//   B operand: the transformed filters are packed ON THE HOST SIDE (lidar_wino_pack_weights, once per weight update) in exactly
-//              the order the lanes consume them — [chunk][cout / 32][xi][lane][s] — so a wave's load is one contiguous 512 B.
-//   LDS image of the input region ((8 MW + 2) x 18 pixels x 4 channels per chunk): filled by LDS-DMA (global_load_lds_dwordx4,
-//              one pixel per lane, zero padding by pointing out-of-image lanes at a zero word), three buffers in a ring, ONE
-//              workgroup barrier per chunk: chunk c + 2 is in flight and chunk c + 1 is being read while chunk c is multiplied.
-// Workgroup = 4 waves = MW x NW (rows of tiles x groups of 32 output channels): 2 x 2 for 64 output channels, 1 x 4 from 128.
+// A WAVE owns 32 tiles (4 x 8 tiles = 8 x 16 output pixels; "tall": 8 x 4) x 32 output channels x all 16 positions: 16 accumulator
+// tiles of v_mfma_f32_32x32x2_f32 = 256 accumulator registers — one wave per SIMD, 512 registers each.  In the accumulator layout
+// the 16 positions of one (tile, cout) sit in the SAME lane at the same register index of the 16 tiles, so the output transform is
+// lane-local arithmetic.  Workgroup = 4 waves = MW x NW (tile blocks x groups of 32 output channels): 2 x 2 for 64 output channels,
+// 1 x 4 from 128.  Channels are consumed in chunks of 4 (two MFMA K-steps, 32 MFMAs = 2 048 matrix-pipe cycles per wave).
+//   A operand: lane (i = lane & 31, h = lane >> 5) supplies tile i, input channel 4c + 2h + s of chunk c, K-step s.  The input
+//              transform of a tile block is computed ONCE per workgroup: the NW waves that share a block each take 4 / NW of the four
+//              transform rows (raw pixels from the LDS image of the region, 8 reads + 8 adds + 4 writes per row) and leave V in LDS
+//              in A-operand lane order; every wave then reads its 16 operands as 8-byte lane-linear loads.
+//   B operand: the transformed filters are packed once per weight update (lidar_wino_pack_weights) in exactly the order the lanes
+//              consume them — [chunk][cout / 32][xi / 2][lane][xi & 1][s] — a wave's load is one contiguous 1 KB (dwordx4 per lane).
+//   LDS image of the input region ((2 TY MW + 2) x (2 TX + 2) pixels x 4 channels per chunk): filled by LDS-DMA
+//              (global_load_lds_dwordx4, one pixel per lane; zero padding = out-of-image lanes read a zero word).
+// Pipeline (r04 v3), per chunk c: MFMAs(c) | A operands of c + 1 read from V | transform of c + 2 | DMA of c + 3, ONE barrier per
+// chunk, two-buffer rings for the raw images and for V.  One wave per SIMD has nobody to hide behind, so (measured with the
+// -DWINO_PROBE ablations, tools/wino_probe.py):
+//   * the issue order inside a chunk is written out MFMA by MFMA with scheduling fences (the compiler's own order, or
+//     sched_group_barrier hints, cost 7-12 %): a vector-memory instruction costs 30-60 issue cycles here, so the 8 filter loads go one
+//     per MFMA gap; the transform's reads, arithmetic and writes follow; the second half of a chunk is bare MFMAs, so the barrier's
+//     wait finds everything complete;
+//   * the kernel is PERSISTENT and the pipeline never drains: a workgroup walks its list of tile blocks and the DMA / transform /
+//     operand reads of the next block's first chunks run under the last chunks of the current one (the per-block prologue — two
+//     dependent DMA round trips and two barriers — was 6-12 % of a block); a block's first MFMAs take a zero C operand instead of
+//     cleared accumulators;
+//   * the 2 x 2 output tiles go through a per-wave LDS staging tile and leave as 16-byte stores of 4 channels (v1: one 4-byte
+//     store per value, 23 % of the 64-channel layer).
 #include "common.h"
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef float f32x2 __attribute__((ext_vector_type(2)));
 
-#define WINO_RW 18                       // region width in pixels: 8 tiles x 2 + 2 halo
+#ifndef WINO_PROBE                       // timing probes (tools/wino_probe.py; WRONG results): bit 0 no input DMA in the loop, bit 1 no
+#define WINO_PROBE 0                     // filter loads in the loop, bit 2 no patch reads / transform in the loop, bit 3 no epilogue,
+#endif                                   // bit 4 no barrier in the loop
+#ifndef WINO_PERSIST                     // A/B: 0 = one tile block per workgroup launch slot (the pipeline drains at every block)
+#define WINO_PERSIST 1
+#endif
 
 __device__ float4 g_wino_zero = {0.f, 0.f, 0.f, 0.f};      // what an out-of-image pixel reads (zero padding)
 
 // ------------------------------------------------------------------ filter transform + packing
-// w: (Cout, Cin, 3, 3) contiguous.  upk[(((c * NB + nb) * 16 + xi) * 64 + lane) * 2 + s] = U_xi[cin = 4c + 2 (lane >> 5) + s][cout = 32 nb + (lane & 31)]
+// w: (Cout, Cin, 3, 3) contiguous.
+// upk[((((c * NB + nb) * 8 + xi / 2) * 64 + lane) * 2 + (xi & 1)) * 2 + s] = U_xi[cin = 4c + 2 (lane >> 5) + s][cout = 32 nb + (lane & 31)]
 __global__ __launch_bounds__(256) void wino_pack_kernel(const float *__restrict__ w, int Cin, int Cout, float *__restrict__ upk) {
     const int idx = blockIdx.x * 256 + threadIdx.x;
     if (idx >= Cin * Cout) return;
@@ -56,8 +76,10 @@ __global__ __launch_bounds__(256) void wino_pack_kernel(const float *__restrict_
     for (int y = 0; y < 4; ++y) {
         const float u[4] = {t[y][0], 0.5f * (t[y][0] + t[y][1] + t[y][2]), 0.5f * (t[y][0] - t[y][1] + t[y][2]), t[y][2]};
 #pragma unroll
-        for (int x = 0; x < 4; ++x)
-            upk[((((size_t)c * NB + nb) * 16 + (y * 4 + x)) * 64 + (h * 32 + j)) * 2 + s] = u[x];
+        for (int x = 0; x < 4; ++x) {
+            const int xi = y * 4 + x;
+            upk[(((((size_t)c * NB + nb) * 8 + (xi >> 1)) * 64 + (h * 32 + j)) * 2 + (xi & 1)) * 2 + s] = u[x];
+        }
     }
 }
 
@@ -71,168 +93,297 @@ struct WinoArgs {
     int blocks_y, blocks_x, n_groups, n_blocks;       // grid decomposition (n_blocks = B * blocks_y * blocks_x * n_groups)
 };
 
-template <int NW>
+#define WINO_STG_PITCH 36                 // floats per staged output pixel (32 channels + 4: 16-byte aligned rows, spread over banks)
+
+// LDS bytes of wino_f23_kernel<NW, TALL>: raw ring [2][RP] float4 + V ring [2][MW][16][64] float2 + output staging [4][128][pitch]
+static constexpr int wino_rp(int NW, bool TALL) {
+    return ((((TALL ? 16 : 8) * (4 / NW) + 2) * ((TALL ? 8 : 16) + 2) + 63) / 64) * 64;
+}
+static constexpr size_t wino_lds_bytes(int NW, bool TALL) {
+    return (size_t)2 * wino_rp(NW, TALL) * 16 + (size_t)2 * (4 / NW) * 16 * 64 * 8 + (size_t)4 * 128 * WINO_STG_PITCH * 4;
+}
+
+template <int NW, bool TALL>
 __global__ __launch_bounds__(256) void wino_f23_kernel(const WinoArgs a) {
     constexpr int MW = 4 / NW;
-    constexpr int RH = 8 * MW + 2;                       // region rows
-    constexpr int RP = ((RH * WINO_RW + 63) / 64) * 64;  // region pixels, padded to whole DMA wave-instructions
-    constexpr int NQ = RP / 64;                          // DMA wave-instructions per chunk and workgroup
-    constexpr int QW = (NQ + 3) / 4;                     // ... per wave
-    __shared__ float4 s_a[3][RP];                        // ring of region images: [pixel slot][4 channels of the chunk]
-
-    // XCD-aware block order: the hardware deals consecutive workgroup ids round-robin over the 8 XCDs; blocks that share input
-    // (the channel groups of one spatial block, horizontally adjacent blocks: halo) should share an L2, so consecutive LOGICAL
-    // blocks are given to the same XCD
-    const int nb8 = (a.n_blocks + 7) >> 3;
-    int blk = (int)(blockIdx.x & 7) * nb8 + (int)(blockIdx.x >> 3);
-    if (blk >= a.n_blocks) return;
-    const int ng = blk % a.n_groups;
-    blk /= a.n_groups;
-    const int bx = blk % a.blocks_x;
-    blk /= a.blocks_x;
-    const int by = blk % a.blocks_y;
-    const int b = blk / a.blocks_y;
+    constexpr int TYW = TALL ? 8 : 4, TXW = TALL ? 4 : 8;   // tiles per wave: rows, columns
+    constexpr int RW = 2 * TXW + 2;                       // region width (pixels)
+    constexpr int RH = 2 * TYW * MW + 2;                  // region height
+    constexpr int RP = wino_rp(NW, TALL);                 // region pixels, padded to whole DMA wave-instructions
+    constexpr int NQ = RP / 64;                           // DMA wave-instructions per chunk and workgroup
+    constexpr int QW = (NQ + 3) / 4;                      // ... per wave
+    constexpr int RPW = 4 / NW;                           // transform rows per wave
+    extern __shared__ float4 s_mem4[];
+    float4 *s_raw = s_mem4;                                                   // [2][RP]: [pixel slot][4 channels of the chunk]
+    f32x2 *s_v = reinterpret_cast<f32x2 *>(s_mem4 + 2 * RP);                  // [2][MW][16][64]: V in A-operand lane order
+    float *s_stg = reinterpret_cast<float *>(s_v + 2 * MW * 16 * 64);         // [4 waves][128 pixels][WINO_STG_PITCH]
 
     const int t = threadIdx.x, l = t & 63, wv = __builtin_amdgcn_readfirstlane(t >> 6);     // (wave-uniform, and known to be)
     const int mw = wv / NW, nw = wv % NW;
     const int i = l & 31, h = l >> 5;
-    const int ty = i >> 3, tx = i & 7;
+    const int ty = TALL ? (i >> 2) : (i >> 3), tx = TALL ? (i & 3) : (i & 7);
     const int H = a.H, W = a.W, Cin = a.Cin;
-    const int R0 = 8 * MW * by - 1, C0 = 16 * bx - 1;    // image coordinates of region pixel (0, 0)
+    const int NB = a.Cout >> 5;
+    const size_t bstride = (size_t)NB * 8 * 64;          // float4 per chunk
 
-    // ---- this lane's DMA sources: region slots p = q * 64 + l for q = wv, wv + 4, ...
-    const float *src[QW];
-    bool src_ok[QW];
+    // ---- the list of tile blocks of this workgroup.  XCD-aware: the hardware deals consecutive workgroup ids round-robin over
+    // the 8 XCDs; blocks that share input (the channel groups of one spatial block, horizontally adjacent blocks: halo) should
+    // share an L2, so XCD x owns the LOGICAL blocks [x * nb8, (x + 1) * nb8) and its workgroups stride through them
+    const int nb8 = (a.n_blocks + 7) >> 3;
+    const int xcd = (int)(blockIdx.x & 7), slot = (int)(blockIdx.x >> 3), nslots = (int)(gridDim.x >> 3);
+    const int blk_end = min((xcd + 1) * nb8, a.n_blocks);
+    int blk = xcd * nb8 + slot;
+    if (blk >= blk_end) return;
+
+    struct Tile {
+        const float *src[QW];            // this lane's DMA sources (region slots q * 64 + l for q = wv, wv + 4, ...), chunk 0
+        bool ok[QW];                     // ... inside the image (else: the zero word, never advanced)
+        const f32x4 *b;                  // this lane's packed filters, chunk 0
+        int bidx, by, bx, nb;
+    };
+    auto make_tile = [&](int blk_) {
+        Tile tl;
+        const int ng = blk_ % a.n_groups;
+        blk_ /= a.n_groups;
+        tl.bx = blk_ % a.blocks_x;
+        blk_ /= a.blocks_x;
+        tl.by = blk_ % a.blocks_y;
+        tl.bidx = blk_ / a.blocks_y;
+        tl.nb = ng * NW + nw;
+        tl.b = reinterpret_cast<const f32x4 *>(a.upk) + ((size_t)tl.nb * 8) * 64 + l;
+        const int R0 = 2 * TYW * MW * tl.by - 1, C0 = 2 * TXW * tl.bx - 1;      // image coordinates of region pixel (0, 0)
 #pragma unroll
-    for (int k = 0; k < QW; ++k) {
-        const int q = wv + 4 * k;
-        const int p = q * 64 + l;
-        const int ry = p / WINO_RW, rx = p - ry * WINO_RW;
-        const int gy = R0 + ry, gx = C0 + rx;
-        src_ok[k] = (q < NQ) && (p < RH * WINO_RW) && gy >= 0 && gy < H && gx >= 0 && gx < W;
-        src[k] = src_ok[k] ? a.in + (((size_t)b * H + gy) * W + gx) * Cin : (const float *)&g_wino_zero;
-    }
-    auto dma = [&](int c, int buf) {
+        for (int k = 0; k < QW; ++k) {
+            const int q = wv + 4 * k;
+            const int p = q * 64 + l;
+            const int ry = p / RW, rx = p - ry * RW;
+            const int gy = R0 + ry, gx = C0 + rx;
+            tl.ok[k] = (q < NQ) && (p < RH * RW) && gy >= 0 && gy < H && gx >= 0 && gx < W;
+            tl.src[k] = tl.ok[k] ? a.in + (((size_t)tl.bidx * H + gy) * W + gx) * Cin : (const float *)&g_wino_zero;
+        }
+        return tl;
+    };
+    auto dma = [&](const Tile &tl, int c, int buf) {
 #pragma unroll
         for (int k = 0; k < QW; ++k) {
             const int q = wv + 4 * k;
             if (q < NQ) {                                 // wave-uniform
-                const float *g = src_ok[k] ? src[k] + 4 * c : src[k];
+                const float *g = tl.ok[k] ? tl.src[k] + 4 * c : tl.src[k];
                 __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)g,
-                                                 (__attribute__((address_space(3))) void *)(&s_a[buf][q * 64]), 16, 0, 0);
+                                                 (__attribute__((address_space(3))) void *)(s_raw + buf * RP + q * 64), 16, 0, 0);
             }
         }
     };
-    // ---- B operand: 16 x float2 per chunk, contiguous per wave
-    const int NB = a.Cout >> 5, nb = ng * NW + nw;
-    const f32x2 *bsrc = reinterpret_cast<const f32x2 *>(a.upk) + ((size_t)nb * 16) * 64 + l;
-    const size_t bstride = (size_t)NB * 16 * 64;         // float2 per chunk
-    auto load_b = [&](int c, f32x2 (&bb)[16]) {
-        const f32x2 *p = bsrc + (size_t)c * bstride;
+    // ---- input transform, this wave's share: rows xy = nw * RPW + rr of V = B^T d B for the tile block mw, lane = (tile i, channel
+    // pair h) as in the A operand.  Row xy of B^T d is d[ra] + sg * d[rb] (sg = +-1: the fma is exact)
+    const int slot0 = (2 * TYW * mw + 2 * ty) * RW + 2 * tx;
+    int txy[RPW], tra[RPW], trb[RPW];
+    float tsg[RPW];
 #pragma unroll
-        for (int xi = 0; xi < 16; ++xi) bb[xi] = p[xi * 64];
+    for (int rr = 0; rr < RPW; ++rr) {
+        const int xy = nw * RPW + rr;                     // wave-uniform
+        txy[rr] = xy;
+        tra[rr] = xy == 0 ? 0 : (xy == 2 ? 2 : 1);
+        trb[rr] = xy < 2 ? 2 : (xy == 2 ? 1 : 3);
+        tsg[rr] = xy == 1 ? 1.f : -1.f;
+    }
+    auto transform = [&](int rbuf, int vbuf) {
+        const f32x2 *base = reinterpret_cast<const f32x2 *>(s_raw + rbuf * RP + slot0) + h;
+        f32x2 *vdst = s_v + ((size_t)(vbuf * MW + mw) * 16) * 64 + l;
+#pragma unroll
+        for (int rr = 0; rr < RPW; ++rr) {
+            f32x2 tr[4];
+#pragma unroll
+            for (int x = 0; x < 4; ++x) {
+                const f32x2 da = base[(tra[rr] * RW + x) * 2], db = base[(trb[rr] * RW + x) * 2];
+                tr[x][0] = __builtin_fmaf(tsg[rr], db[0], da[0]);
+                tr[x][1] = __builtin_fmaf(tsg[rr], db[1], da[1]);
+            }
+            vdst[(txy[rr] * 4 + 0) * 64] = tr[0] - tr[2];
+            vdst[(txy[rr] * 4 + 1) * 64] = tr[1] + tr[2];
+            vdst[(txy[rr] * 4 + 2) * 64] = tr[2] - tr[1];
+            vdst[(txy[rr] * 4 + 3) * 64] = tr[1] - tr[3];
+        }
     };
-    // ---- A operand: raw patch from the LDS image, transformed in registers (B^T d B, two channels packed per register pair)
-    const int slot0 = (8 * mw + 2 * ty) * WINO_RW + 2 * tx;
-    auto load_v = [&](int buf, f32x2 (&v)[16]) {
-        const f32x2 *base = reinterpret_cast<const f32x2 *>(&s_a[buf][slot0]) + h;
-        f32x2 d[4][4];
+    auto load_v = [&](int vbuf, f32x2 (&v)[16]) {
+        const f32x2 *vsrc = s_v + ((size_t)(vbuf * MW + mw) * 16) * 64 + l;
 #pragma unroll
-        for (int y = 0; y < 4; ++y)
+        for (int xi = 0; xi < 16; ++xi) v[xi] = vsrc[xi * 64];
+    };
+    auto load_b = [&](const Tile &tl, int c, f32x4 (&bb)[8]) {
+        const f32x4 *p = tl.b + (size_t)c * bstride;
 #pragma unroll
-            for (int x = 0; x < 4; ++x) d[y][x] = base[(y * WINO_RW + x) * 2];
-#pragma unroll
-        for (int x = 0; x < 4; ++x) {                    // columns: B^T d
-            const f32x2 t0 = d[0][x] - d[2][x], t1 = d[1][x] + d[2][x], t2 = d[2][x] - d[1][x], t3 = d[1][x] - d[3][x];
-            d[0][x] = t0; d[1][x] = t1; d[2][x] = t2; d[3][x] = t3;
-        }
-#pragma unroll
-        for (int y = 0; y < 4; ++y) {                    // rows: (.) B
-            v[y * 4 + 0] = d[y][0] - d[y][2];
-            v[y * 4 + 1] = d[y][1] + d[y][2];
-            v[y * 4 + 2] = d[y][2] - d[y][1];
-            v[y * 4 + 3] = d[y][1] - d[y][3];
-        }
+        for (int e = 0; e < 8; ++e) bb[e] = p[e * 64];
     };
 
     f32x16 acc[16];
-#pragma unroll
-    for (int xi = 0; xi < 16; ++xi)
-#pragma unroll
-        for (int r = 0; r < 16; ++r) acc[xi][r] = 0.f;
-
-    // ---- main loop.  Chunk c multiplies (vc, bc) while (vn, bn) of chunk c + 1 are fetched / transformed and the DMA of chunk
-    // c + 2 is in flight; two chunks per iteration so that the register sets swap roles without copies.  One basic block per
-    // chunk (clamped instead of conditional loads), with the issue order pinned: the LDS reads of the next patch behind the first
-    // MFMAs, its transform (32 packed adds) and the next filter loads spread under the rest — an MFMA occupies the matrix pipe for
-    // 64 cycles, the wave issues two or three other instructions in that time.
     const int NC = Cin >> 2;
-    f32x2 b0[16], b1[16], v0[16], v1[16];
-    dma(0, 0);
-    dma(1, 1);
-    load_b(0, b0);
-    __syncthreads();                                      // (drains the DMA: vmcnt(0) + barrier)
-    load_v(0, v0);
-    int ring = 2;                                         // buffer that receives chunk c + 2; chunk c + 1 sits in (ring + 2) % 3
-#define WINO_CHUNK(c, VC, BC, VN, BN)                                                                                              \
-    {                                                                                                                              \
-        if ((c) > 0) __syncthreads();      /* image c + 1 has landed for every wave; image c - 1 is no longer read */             \
-        if ((c) + 2 < NC) dma((c) + 2, ring);                                                                                      \
-        const int nxt = ring == 0 ? 2 : ring - 1;                                                                                  \
-        ring = ring == 2 ? 0 : ring + 1;                                                                                           \
-        load_b(min((c) + 1, NC - 1), BN);                                                                                          \
-        _Pragma("unroll") for (int xi = 0; xi < 16; ++xi) acc[xi] = __builtin_amdgcn_mfma_f32_32x32x2f32(VC[xi][0], BC[xi][0], acc[xi], 0, 0, 0); \
-        load_v(nxt, VN);                                                                                                           \
-        _Pragma("unroll") for (int xi = 0; xi < 16; ++xi) acc[xi] = __builtin_amdgcn_mfma_f32_32x32x2f32(VC[xi][1], BC[xi][1], acc[xi], 0, 0, 0); \
-        _Pragma("unroll") for (int k = 0; k < 8; ++k) {                                                                            \
-            __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);     /* MFMA */                                                     \
-            __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);     /* DS read */                                                  \
-            __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);     /* VMEM read */                                                \
-        }                                                                                                                          \
-        _Pragma("unroll") for (int k = 0; k < 8; ++k) {                                                                            \
-            __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);                                                                     \
-            __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);                                                                     \
-            __builtin_amdgcn_sched_group_barrier(0x002, 2, 0);     /* VALU */                                                     \
-        }                                                                                                                          \
-        _Pragma("unroll") for (int k = 0; k < 16; ++k) {                                                                           \
-            __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);                                                                     \
-            __builtin_amdgcn_sched_group_barrier(0x002, 2, 0);                                                                     \
-        }                                                                                                                          \
-    }
-    for (int c = 0; c < NC; c += 2) {
-        WINO_CHUNK(c, v0, b0, v1, b1)
-        WINO_CHUNK(c + 1, v1, b1, v0, b0)
-    }
-#undef WINO_CHUNK
+    f32x4 b0[8], b1[8];
+    f32x2 v0[16], v1[16];
+    Tile cur = make_tile(blk), nxt = cur;
 
-    // ---- epilogue: Y = A^T M A per (tile, cout), + shift, ReLU, store.  acc[xi][r]: tile row 8 (r / 4) + 4 h + (r % 4), cout l & 31
-    const int ch = 32 * nb + i;
-    const float bv = a.bias ? a.bias[ch] : 0.f;
-    const bool relu = a.relu != 0;
-    float *obase = a.out + (size_t)b * H * W * a.out_C + a.out_off + ch;
-    const int tile_y0 = (4 * MW * by + 4 * mw), tile_x0 = 8 * bx;
-#pragma unroll
-    for (int r = 0; r < 16; ++r) {
-        const int it = 8 * (r >> 2) + 4 * h + (r & 3);
-        const int oy = 2 * (tile_y0 + (it >> 3)), ox = 2 * (tile_x0 + (it & 7));
-        float tt[2][4];
-#pragma unroll
-        for (int x = 0; x < 4; ++x) {
-            tt[0][x] = acc[0 + x][r] + acc[4 + x][r] + acc[8 + x][r];
-            tt[1][x] = acc[4 + x][r] - acc[8 + x][r] - acc[12 + x][r];
+    // ---- pipeline fill (first block only): raw(0..2), V(0), V(1), the A operands and filters of chunk 0
+    dma(cur, 0, 0);
+    dma(cur, 1, 1);
+    load_b(cur, 0, b0);
+    __syncthreads();                                      // raw(0), raw(1) landed (vmcnt(0) + barrier)
+    transform(0, 0);
+    __syncthreads();                                      // V(0) visible; raw[0] free
+    if (2 < NC) dma(cur, 2, 0);
+    transform(1, 1);
+    load_v(0, v0);
+    __syncthreads();                                      // V(1) visible, raw(2) landed; raw[1] free
+#if WINO_PROBE
+    load_b(cur, 0, b1);
+    load_v(1, v1);
+#endif
+
+    // chunk c (parity P = c & 1, NC even): DMA raw(c + 3) -> raw[!P]; A operands of c + 1 from V[!P]; transform raw(c + 2) in raw[P]
+    // -> V[P]; filters of c + 1.  Past the end of the block, "c + k" means chunk c + k - NC of the NEXT block (same parities).
+    // FIRST: the block's first chunk — its K-step 0 starts the accumulators from a zero C operand.
+#define WINO_CHUNK(c, P, FIRST, VC, BC, VN, BN)                                                                                    \
+    {                                                                                                                              \
+        if (!(WINO_PROBE & 16)) {                                                                                                  \
+            if ((c) > 0) __syncthreads();                                                                                          \
+            else if (!first_block) {       /* block boundary: everything this barrier orders is LDS traffic or was drained before  \
+                                              the epilogue; do NOT wait for the epilogue's stores here (vmcnt untouched) */       \
+                __builtin_amdgcn_s_waitcnt(0xC07F);        /* lgkmcnt(0) */                                                        \
+                __builtin_amdgcn_s_barrier();                                                                                      \
+            }                                                                                                                      \
+        }                                                                                                                          \
+        if (!(WINO_PROBE & 1)) {                                                                                                   \
+            if ((c) + 3 < NC) dma(cur, (c) + 3, 1 - (P));                                                                          \
+            else if (has_next) dma(nxt, (c) + 3 - NC, 1 - (P));                                                                    \
+        }                                                                                                                          \
+        const f32x4 *bp_ = ((c) + 1 < NC) ? cur.b + (size_t)((c) + 1) * bstride : (has_next ? nxt.b : cur.b);                      \
+        const f32x2 *rb_ = reinterpret_cast<const f32x2 *>(s_raw + (P) * RP + slot0) + h;                                          \
+        const f32x2 *vs_ = s_v + ((size_t)((1 - (P)) * MW + mw) * 16) * 64 + l;                                                    \
+        f32x2 *vd_ = s_v + ((size_t)((P) * MW + mw) * 16) * 64 + l;                                                                \
+        f32x2 da_[RPW][4], db_[RPW][4], tr_[RPW][4];                                                                               \
+        __builtin_amdgcn_sched_barrier(0);                                                                                         \
+        _Pragma("unroll") for (int k = 0; k < 32; ++k) {                                                                           \
+            const float bop_ = BC[(k & 15) >> 1][((k & 1) << 1) + (k >> 4)];                                                       \
+            if (FIRST && k < 16) {                                                                                                 \
+                f32x16 z_;                                                                                                         \
+                _Pragma("unroll") for (int r_ = 0; r_ < 16; ++r_) z_[r_] = 0.f;                                                    \
+                acc[k & 15] = __builtin_amdgcn_mfma_f32_32x32x2f32(VC[k & 15][k >> 4], bop_, z_, 0, 0, 0);                         \
+            } else {                                                                                                               \
+                acc[k & 15] = __builtin_amdgcn_mfma_f32_32x32x2f32(VC[k & 15][k >> 4], bop_, acc[k & 15], 0, 0, 0);                \
+            }                                                                                                                      \
+            if (k < 8 && !(WINO_PROBE & 2)) BN[k] = bp_[k * 64];                                                                   \
+            if (k < 4 && !(WINO_PROBE & 4)) {                                                                                      \
+                _Pragma("unroll") for (int rr = 0; rr < RPW; ++rr) {                                                               \
+                    da_[rr][k] = rb_[(tra[rr] * RW + k) * 2];                                                                      \
+                    db_[rr][k] = rb_[(trb[rr] * RW + k) * 2];                                                                      \
+                }                                                                                                                  \
+            }                                                                                                                      \
+            if (k >= 4 && k < 8 && !(WINO_PROBE & 4)) {                                                                            \
+                _Pragma("unroll") for (int rr = 0; rr < RPW; ++rr) {                                                               \
+                    tr_[rr][k - 4][0] = __builtin_fmaf(tsg[rr], db_[rr][k - 4][0], da_[rr][k - 4][0]);                             \
+                    tr_[rr][k - 4][1] = __builtin_fmaf(tsg[rr], db_[rr][k - 4][1], da_[rr][k - 4][1]);                             \
+                }                                                                                                                  \
+            }                                                                                                                      \
+            if (k >= 8 && k < 8 + RPW && !(WINO_PROBE & 4)) {                                                                      \
+                const int rr = k - 8;                                                                                              \
+                vd_[(txy[rr] * 4 + 0) * 64] = tr_[rr][0] - tr_[rr][2];                                                             \
+                vd_[(txy[rr] * 4 + 1) * 64] = tr_[rr][1] + tr_[rr][2];                                                             \
+                vd_[(txy[rr] * 4 + 2) * 64] = tr_[rr][2] - tr_[rr][1];                                                             \
+                vd_[(txy[rr] * 4 + 3) * 64] = tr_[rr][1] - tr_[rr][3];                                                             \
+            }                                                                                                                      \
+            if (k >= 12 && k < 20 && !(WINO_PROBE & 4)) { VN[2 * (k - 12)] = vs_[(2 * (k - 12)) * 64]; VN[2 * (k - 12) + 1] = vs_[(2 * (k - 12) + 1) * 64]; } \
+            __builtin_amdgcn_sched_barrier(0);                                                                                     \
+        }                                                                                                                          \
+    }
+
+    bool first_block = true;
+    for (;;) {
+        const int blk_next = blk + nslots;
+        const bool has_next = WINO_PERSIST && blk_next < blk_end;
+        if (has_next) nxt = make_tile(blk_next);
+        WINO_CHUNK(0, 0, true, v0, b0, v1, b1)
+        WINO_CHUNK(1, 1, false, v1, b1, v0, b0)
+        for (int c = 2; c < NC; c += 2) {
+            WINO_CHUNK(c, 0, false, v0, b0, v1, b1)
+            WINO_CHUNK(c + 1, 1, false, v1, b1, v0, b0)
         }
+#if WINO_PROBE & 8
+        {
+            float sum = 0.f;
 #pragma unroll
-        for (int yy = 0; yy < 2; ++yy) {
-            float y0 = tt[yy][0] + tt[yy][1] + tt[yy][2] + bv;
-            float y1 = tt[yy][1] - tt[yy][2] - tt[yy][3] + bv;
-            if (relu) { y0 = fmaxf(y0, 0.f); y1 = fmaxf(y1, 0.f); }
-            if (oy + yy < H) {
-                float *o = obase + ((size_t)(oy + yy) * W + ox) * a.out_C;
-                if (ox < W) o[0] = y0;
-                if (ox + 1 < W) o[a.out_C] = y1;
+            for (int xi = 0; xi < 16; ++xi)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) sum += acc[xi][r];
+            if (sum == 12345.678f) a.out[0] = sum;
+        }
+#else
+        // ---- epilogue: Y = A^T M A per (tile, cout), + shift, ReLU -> this wave's LDS staging tile [pixel = tile * 4 + (y, x)][32
+        // channels] -> 16-byte stores (8 lanes = the 128 contiguous bytes of one pixel's 32 channels).
+        // acc[xi][r]: tile 8 (r / 4) + 4 h + (r % 4) of the wave, channel l & 31
+        {
+            // the DMAs / filter loads issued during the last chunk (the next block's) are drained HERE, before the stores below are
+            // issued, so that the next block's first barrier need not wait on the vector-memory counter (= on these stores)
+            __builtin_amdgcn_s_waitcnt(0x0F70);            // vmcnt(0)
+            int lo = l;                                    // opaque copy: keeps the per-lane store addresses from being hoisted out
+            asm volatile("" : "+v"(lo));                   // of the block loop (they were spilled across the main loop: 70-100 VGPRs)
+            const int ch0 = 32 * cur.nb;
+            const float bv = a.bias ? a.bias[ch0 + i] : 0.f;
+            const bool relu = a.relu != 0;
+            float *stg = s_stg + (size_t)wv * 128 * WINO_STG_PITCH;
+            // xi-major: the compiler moves an accumulator tile to VGPRs as a whole (16 registers) the moment one element feeds a
+            // VALU op, so walking r-major (all 16 tiles live per row) pulled all 256 accumulators into VGPRs at once and spilled the
+            // next block's operands.  Here one tile is live at a time and adds straight into the 4 x 16 output values:
+            // y[2 i + j][r] = sum_xi At[i][xi >> 2] At[j][xi & 3] acc[xi][r], At = [1 1 1 0; 0 1 -1 -1] (36 adds per (tile, cout))
+            float yv[4][16];
+#pragma unroll
+            for (int p = 0; p < 4; ++p)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) yv[p][r] = bv;
+#pragma unroll
+            for (int xi = 0; xi < 16; ++xi) {
+                float m[16];                               // element-wise AGPR reads (an "a"-constrained asm operand stays in its AGPR;
+#pragma unroll                                             //  a plain acc[xi][r] use copies the whole tile, see above)
+                for (int r = 0; r < 16; ++r) asm volatile("v_accvgpr_read_b32 %0, %1" : "=v"(m[r]) : "a"(acc[xi][r]));
+                const int cy[2] = {(xi >> 2) < 3 ? 1 : 0, (xi >> 2) == 0 ? 0 : ((xi >> 2) == 1 ? 1 : -1)};
+                const int cx[2] = {(xi & 3) < 3 ? 1 : 0, (xi & 3) == 0 ? 0 : ((xi & 3) == 1 ? 1 : -1)};
+#pragma unroll
+                for (int p = 0; p < 4; ++p) {
+                    const int coef = cy[p >> 1] * cx[p & 1];
+                    if (coef == 1) {
+#pragma unroll
+                        for (int r = 0; r < 16; ++r) yv[p][r] += m[r];
+                    } else if (coef == -1) {
+#pragma unroll
+                        for (int r = 0; r < 16; ++r) yv[p][r] -= m[r];
+                    }
+                }
+                __builtin_amdgcn_sched_barrier(0);
+            }
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int it = 8 * (r >> 2) + 4 * h + (r & 3);
+#pragma unroll
+                for (int p = 0; p < 4; ++p) stg[(it * 4 + p) * WINO_STG_PITCH + i] = relu ? fmaxf(yv[p][r], 0.f) : yv[p][r];
+            }
+            // (only this wave reads its staging tile back: its own LDS operations are ordered, no barrier)
+            float *obase = a.out + (size_t)cur.bidx * H * W * a.out_C + a.out_off + ch0 + 4 * (lo & 7);
+            const int tile_y0 = TYW * (MW * cur.by + mw), tile_x0 = TXW * cur.bx;
+#pragma unroll
+            for (int k = 0; k < 16; ++k) {
+                const int pix = k * 8 + (lo >> 3);        // staged pixel: tile pix >> 2, position pix & 3
+                const int it = pix >> 2, py = (pix >> 1) & 1, px = pix & 1;
+                const int oy = 2 * (tile_y0 + (TALL ? (it >> 2) : (it >> 3))) + py, ox = 2 * (tile_x0 + (TALL ? (it & 3) : (it & 7))) + px;
+                const float4 v = *reinterpret_cast<const float4 *>(stg + pix * WINO_STG_PITCH + 4 * (lo & 7));
+                if (oy < H && ox < W) *reinterpret_cast<float4 *>(obase + ((size_t)oy * W + ox) * a.out_C) = v;
+                if ((k & 3) == 3) __builtin_amdgcn_sched_barrier(0);      // four stores in flight at a time: all 16 at once spill
             }
         }
+#endif
+        if (!has_next) break;
+        cur = nxt;
+        blk = blk_next;
+        first_block = false;
     }
+#undef WINO_CHUNK
 }
 
 // ------------------------------------------------------------------ C ABI
@@ -250,27 +401,57 @@ LIDAR_EXPORT int lidar_wino_pack_weights(const float *w, int Cin, int Cout, floa
     return lidar_check_launch("lidar_wino_pack_weights");
 }
 
+static int wino_cu_count() {
+    static int cus = 0;
+    if (cus == 0) {
+        int dev = 0, n = 0;
+        if (hipGetDevice(&dev) == hipSuccess && hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && n > 0) cus = n;
+        else cus = 256;
+    }
+    return cus;
+}
+
 // out[b][y][x][out_off + co] = act(sum_{ky,kx,ci} in[b][y+ky-1][x+kx-1][ci] * w[co][ci][ky][kx] + bias[co])   (zero padding)
 LIDAR_EXPORT int lidar_wino_conv3x3_nhwc(const float *in, int B, int H, int W, int Cin, const float *packed, const float *bias, int relu,
                                          int Cout, float *out, int out_C, int out_off, void *stream) {
     if (!in || !packed || !out || B <= 0 || H <= 0 || W <= 0 || !lidar_wino_supported(Cin, Cout) || out_off < 0 || out_off + Cout > out_C)
         return LIDAR_ERR_ARG;
-    if ((reinterpret_cast<uintptr_t>(in) & 15) || (reinterpret_cast<uintptr_t>(packed) & 7)) return LIDAR_ERR_ARG;
+    if ((reinterpret_cast<uintptr_t>(in) & 15) || (reinterpret_cast<uintptr_t>(packed) & 15)) return LIDAR_ERR_ARG;
+    if ((reinterpret_cast<uintptr_t>(out) & 15) || (out_C & 3) || (out_off & 3)) return LIDAR_ERR_ARG;       // 16-byte output stores
     WinoArgs a;
     a.in = in; a.upk = packed; a.bias = bias; a.out = out;
     a.B = B; a.H = H; a.W = W; a.Cin = Cin; a.Cout = Cout; a.out_C = out_C; a.out_off = out_off; a.relu = relu;
     const int NW = (Cout % 128 == 0) ? 4 : (Cout % 64 == 0) ? 2 : 1, MW = 4 / NW;
     const int tiles_y = (H + 1) / 2, tiles_x = (W + 1) / 2;
-    a.blocks_y = divup(tiles_y, 4 * MW);
-    a.blocks_x = divup(tiles_x, 8);
+    // wave tile 4 x 8 tiles (wide) or 8 x 4 (tall): whichever covers the map with fewer tile blocks (62 x 54: 28 instead of 32)
+    const long long wide = (long long)divup(tiles_y, 4 * MW) * divup(tiles_x, 8), tall = (long long)divup(tiles_y, 8 * MW) * divup(tiles_x, 4);
+    const bool use_tall = tall < wide;
+    a.blocks_y = divup(tiles_y, (use_tall ? 8 : 4) * MW);
+    a.blocks_x = divup(tiles_x, use_tall ? 4 : 8);
     a.n_groups = Cout / (32 * NW);
     const long long nblk = (long long)B * a.blocks_y * a.blocks_x * a.n_groups;
     if (nblk > 0x7ffffff0ll) return LIDAR_ERR_ARG;
     a.n_blocks = (int)nblk;
-    const dim3 grid((unsigned)(((nblk + 7) / 8) * 8)), blk(256);
+    // persistent: one workgroup per CU (512 registers per wave: nothing else fits), each walks its XCD's share of the blocks
+    long long want = ((nblk + 7) / 8) * 8;
+#if WINO_PERSIST
+    const long long cap = ((long long)wino_cu_count() / 8) * 8;
+    if (cap >= 8 && want > cap) want = cap;
+#endif
+    const dim3 grid((unsigned)want), blk(256);
     hipStream_t s = (hipStream_t)stream;
-    if (NW == 4) hipLaunchKernelGGL(wino_f23_kernel<4>, grid, blk, 0, s, a);
-    else if (NW == 2) hipLaunchKernelGGL(wino_f23_kernel<2>, grid, blk, 0, s, a);
-    else hipLaunchKernelGGL(wino_f23_kernel<1>, grid, blk, 0, s, a);
+#define WINO_LAUNCH(NWV, TALLV) do {                                                                                               \
+        static bool attr_set = false;                                                                                             \
+        if (!attr_set) {                                                                                                          \
+            (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&wino_f23_kernel<NWV, TALLV>), hipFuncAttributeMaxDynamicSharedMemorySize, \
+                                      (int)wino_lds_bytes(NWV, TALLV));                                                            \
+            attr_set = true;                                                                                                      \
+        }                                                                                                                         \
+        hipLaunchKernelGGL((wino_f23_kernel<NWV, TALLV>), grid, blk, wino_lds_bytes(NWV, TALLV), s, a);                           \
+    } while (0)
+    if (NW == 4) { if (use_tall) WINO_LAUNCH(4, true); else WINO_LAUNCH(4, false); }
+    else if (NW == 2) { if (use_tall) WINO_LAUNCH(2, true); else WINO_LAUNCH(2, false); }
+    else { if (use_tall) WINO_LAUNCH(1, true); else WINO_LAUNCH(1, false); }
+#undef WINO_LAUNCH
     return lidar_check_launch("lidar_wino_conv3x3_nhwc");
 }

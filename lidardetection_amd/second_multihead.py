@@ -20,8 +20,8 @@ import torch
 import torch.nn as nn
 import torch.nn.functional as F
 
-from . import anchor_post, pillar_ops, synth
-from .bev_backbone import FoldedBEVBackbone, bias_act_, collect_params, params_key
+from . import anchor_post, pillar_ops, synth, wino
+from .bev_backbone import _WINO, FoldedBEVBackbone, bias_act_, collect_params, params_key
 from .bev_backbone import _fold as fold_bn
 from .ext import iou3d_nms_cuda
 from .pcdet.models.backbones_3d import spconv_backbone
@@ -181,15 +181,24 @@ class SECONDMultiHeadNuScenes(nn.Module):
                         b1.append(b)
                         second.append(br[3])
                 cl = lambda t: t.contiguous(memory_format=torch.channels_last)
-                cache = (key, cl(ws), bs, cl(torch.cat(w1, 0)), torch.cat(b1, 0).contiguous(), second)
+                w1c = torch.cat(w1, 0)
+                # both merged 3x3 layers are stride 1 / padding 1: Winograd F(2x2, 3x3) with shift + ReLU in the kernel (csrc/wino_conv.hip)
+                pk = None
+                if _WINO[0] and ws.is_cuda and wino.supported(ws.shape[1], ws.shape[0]) and wino.supported(w1c.shape[1], w1c.shape[0]):
+                    pk = (wino.pack_weights(ws), wino.pack_weights(w1c))
+                cache = (key, cl(ws), bs.contiguous(), cl(w1c), torch.cat(b1, 0).contiguous(), second, pk)
             self.__dict__["_heads_folded"] = cache
         return cache[1:]
 
     def heads(self, spatial_2d):
         """same outputs as heads_reference_layout(): shared conv and all first-layer branch convolutions merged and folded"""
-        ws, bs, w1, b1, second = self._folded_heads()
-        x = bias_act_(F.conv2d(spatial_2d, ws, None, padding=1), bs, True)
-        y = bias_act_(F.conv2d(x, w1, None, padding=1), b1, True)
+        ws, bs, w1, b1, second, pk = self._folded_heads()
+        if pk is not None and _WINO[0] and spatial_2d.is_contiguous(memory_format=torch.channels_last):
+            x = wino.conv3x3(spatial_2d, pk[0], ws.shape[0], bs, True)
+            y = wino.conv3x3(x, pk[1], w1.shape[0], b1, True)
+        else:
+            x = bias_act_(F.conv2d(spatial_2d, ws, None, padding=1), bs, True)
+            y = bias_act_(F.conv2d(x, w1, None, padding=1), b1, True)
         mid = w1.shape[0] // len(second)
         z = [conv(y[:, g * mid:(g + 1) * mid]) for g, conv in enumerate(second)]
         B, _, H, W = y.shape

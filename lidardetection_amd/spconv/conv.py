@@ -178,9 +178,16 @@ class SparseConvolution(SparseModule):
                     shift = bn.bias.detach() - bn.running_mean * scale
                     w = w * scale.view(1, 1, -1)
                     b = shift if b is None else b * scale + shift
-                cache = (key, w.contiguous(), None if b is None else b.contiguous())
+                w = w.contiguous()
+                packed = ops.pack_gemm_weights(w) if (w.is_cuda and ops.sorted_gemm_supported(w.shape[0], self.in_channels, self.out_channels)) else None
+                cache = (key, w, None if b is None else b.contiguous(), packed)
             self._fold_cache = cache
         return cache[1], cache[2]
+
+    def _folded_packed(self):
+        """the packed form of the last _folded() weights (None: no packed kernel for this shape)"""
+        cache = getattr(self, "_fold_cache", None)
+        return None if cache is None else cache[3]
 
     def forward_fused(self, input, bn=None, relu=False, residual=None):
         """act(bn(conv(input)) + residual) with eval-mode BatchNorm1d folded into the weights; no autograd graph.
@@ -201,7 +208,8 @@ class SparseConvolution(SparseModule):
             if ops.sorted_gemm_supported(w.shape[0], self.in_channels, self.out_channels):
                 # mask order of the table's rows, shared through indice_key
                 st = ops.cached_mask_order(datas, "order_t" if self.inverse else "order", fwd_table)
-            f = ops.indice_conv_fused(feats, fwd_table, w, b, None if residual is None else residual.contiguous(), relu, st)
+            f = ops.indice_conv_fused(feats, fwd_table, w, b, None if residual is None else residual.contiguous(), relu, st,
+                                      self._folded_packed() if st is not None else None)
         out = SparseConvTensor(f, out_indices, out_shape, input.batch_size)
         out.indice_dict, out.grid = input.indice_dict, input.grid
         return out

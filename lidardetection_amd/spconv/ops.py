@@ -454,9 +454,27 @@ def mask_order(nbr, stream=None):
     return masks, order
 
 
-def indice_conv_fused(feats, nbr, weight_kcc, bias, residual=None, relu=False, order=None):
+PACKED_GEMM = [__import__("os").environ.get("LIDAR_SPCONV_PACKED", "1") != "0"]      # A/B switch: packed-weight GEMM kernel
+
+
+def pack_gemm_weights(weight_kcc):
+    """(K, Cin, Cout) folded weights -> the lane-ordered packed form lidar_spconv_implicit_gemm_sorted_packed reads, or None when
+    the shape has no packed kernel (csrc/sparse_conv.hip sc_implicit_gemm_pk_kernel)"""
+    K, Cin, Cout = weight_kcc.shape
+    L = _lib.lib()
+    n = L.lidar_spconv_packed_floats(K, Cin, Cout)
+    if n == 0 or not weight_kcc.is_cuda or not PACKED_GEMM[0]:
+        return None
+    w = weight_kcc.contiguous()
+    packed = torch.empty(n, dtype=torch.float32, device=w.device)
+    _lib.check(L.lidar_spconv_pack_weights(_lib.ptr(w), K, Cin, Cout, _lib.ptr(packed), _lib.stream()), "lidar_spconv_pack_weights")
+    return packed
+
+
+def indice_conv_fused(feats, nbr, weight_kcc, bias, residual=None, relu=False, order=None, packed=None):
     """Inference-only: act(sum_k feats[nbr[:, k]] @ weight_kcc[k] + bias + residual) in one launch (no autograd).
-    order = mask_order(nbr) visits the rows in mask order (bit-identical result, far fewer padding MFMA tiles)."""
+    order = mask_order(nbr) visits the rows in mask order (bit-identical result, far fewer padding MFMA tiles).
+    packed = pack_gemm_weights(weight_kcc): the mask-ordered GEMM then runs its packed-weight kernel (bit-identical again)."""
     K, Cin, Cout = weight_kcc.shape
     n_out = nbr.shape[0]
     _lib.require_cuda(feats, weight_kcc, nbr, bias, residual)
@@ -465,6 +483,13 @@ def indice_conv_fused(feats, nbr, weight_kcc, bias, residual=None, relu=False, o
         return out
     if residual is not None and tuple(residual.shape) != (n_out, Cout):
         raise _lib.LidarHipError("indice_conv_fused: residual must be (n_out, Cout)")
+    if order is not None and packed is not None and PACKED_GEMM[0]:
+        masks, perm = order
+        _lib.check(_lib.lib().lidar_spconv_implicit_gemm_sorted_packed(_lib.ptr(feats), _lib.ptr(nbr), _lib.ptr(masks), _lib.ptr(perm),
+                                                                       n_out, K, Cin, Cout, _lib.ptr(packed), _lib.ptr(bias),
+                                                                       _lib.ptr(residual), int(bool(relu)), _lib.ptr(out), _lib.stream()),
+                   "lidar_spconv_implicit_gemm_sorted_packed")
+        return out
     if order is not None:
         masks, perm = order
         _lib.check(_lib.lib().lidar_spconv_implicit_gemm_sorted(_lib.ptr(feats), _lib.ptr(nbr), _lib.ptr(masks), _lib.ptr(perm),

@@ -27,6 +27,9 @@ def _ref(x, w, bias, relu):
     (1, 8, 32, 7, 5),          # smallest supported channel counts: 4 x 1 waves, two chunks
     (2, 64, 128, 6, 40),       # Cin != Cout
     (1, 128, 64, 33, 17),
+    (1, 64, 128, 62, 54),      # tall wave tiles (8 x 4 tiles) are chosen: 28 workgroups instead of 32 (PointPillar block 3 geometry)
+    (1, 64, 64, 32, 8),        # tall, 2 x 2 waves
+    (1, 8, 32, 64, 8),         # tall, 4 x 1 waves
 ])
 def test_wino_conv3x3_vs_float64_direct_convolution(dev, B, cin, cout, H, W):
     g = torch.Generator(device="cpu").manual_seed(1000 * cin + cout + H)

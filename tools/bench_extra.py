@@ -72,7 +72,8 @@ def second_kitti(dev, B=16):
                     w = c.weight.reshape(-1, c.in_channels, c.out_channels).contiguous()
                     f = x.features.contiguous()
                     st = ops.mask_order(nbr) if ops.sorted_gemm_supported(w.shape[0], c.in_channels, c.out_channels) else None
-                    t, _ = _events(lambda: ops.indice_conv_fused(f, nbr, w, None, None, True, st), n=5, warm=2)
+                    pk = ops.pack_gemm_weights(w) if st is not None else None       # what forward_fused runs (csrc/sparse_conv.hip pk kernel)
+                    t, _ = _events(lambda: ops.indice_conv_fused(f, nbr, w, None, None, True, st, pk), n=5, warm=2)
                     tot_ms += t
                     tot_fl += 2.0 * float((nbr >= 0).sum()) * c.in_channels * c.out_channels
                     x = y

@@ -34,7 +34,7 @@ def eff32(nbr):
 
 with torch.no_grad():
     x = spconv.SparseConvTensor(bd["voxel_features"], bd["voxel_coords"].int(), m.sparse_shape, B)
-    tot = [0.0, 0.0, 0.0, 0.0]
+    tot = [0.0, 0.0, 0.0, 0.0, 0.0]
     def walk(mod, x):
         for c in mod._modules.values():
             if isinstance(c, spconv.SparseSequential):
@@ -53,8 +53,12 @@ with torch.no_grad():
                     t_new = timeit(lambda: ops.indice_conv_fused(f, nbr, w, None, None, True, st))
                     line += f" | mask-sorted {t_new:7.1f} us {fl / t_new / 1e6:6.1f} TF (row eff {eff32(nbr[st[1].long()]):.2f}; sort {t_sort:6.1f} us)"
                     tot[1] += t_new; tot[3] += t_sort
+                    pk = ops.pack_gemm_weights(w)
+                    t_pk = timeit(lambda: ops.indice_conv_fused(f, nbr, w, None, None, True, st, pk)) if pk is not None else t_new
+                    line += f" | packed {t_pk:7.1f} us {fl / t_pk / 1e6:6.1f} TF"
+                    tot[4] += t_pk
                 else:
-                    tot[1] += t_old
+                    tot[1] += t_old; tot[4] += t_old
                 print(line, flush=True)
                 x = y
             else:
@@ -64,3 +68,4 @@ with torch.no_grad():
         x = walk(getattr(m, name), x)
     print(f"total table-order {tot[0] / 1e3:.3f} ms ({tot[2] / tot[0] / 1e6:.1f} TF)  mask-sorted {tot[1] / 1e3:.3f} ms "
           f"({tot[2] / tot[1] / 1e6:.1f} TF = {tot[2] / tot[1] / 1e6 / 157.3 * 100:.1f}% of fp32 MFMA peak); sorts (every table, incl. reused) {tot[3] / 1e3:.3f} ms")
+    print(f"packed-weight kernel {tot[4] / 1e3:.3f} ms ({tot[2] / tot[4] / 1e6:.1f} TF = {tot[2] / tot[4] / 1e6 / 157.3 * 100:.1f}% of fp32 MFMA peak)")

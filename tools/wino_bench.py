@@ -33,6 +33,9 @@ for B, C, H, W in shapes:
     packed = wino.pack_weights(w)
     with torch.no_grad():
         t_w = ev(lambda: wino.conv3x3(x, packed, C, bias, True))
+        if os.environ.get("WINO_BENCH_ONLY"):
+            print(f"B{B} C{C} {H}x{W}: wino {t_w:.3f} ms, MFMA {2.0 * 9 * C * C * B * H * W / 1e9 * 16 / 36 / t_w / 157.3:.3f} of peak |", flush=True)
+            continue
         t_m = ev(lambda: bias_act_(F.conv2d(x, wl, None, 1, 1), bias))
         t_c = ev(lambda: F.conv2d(x, wl, None, 1, 1))
         err = float((wino.conv3x3(x, packed, C, bias, True) - bias_act_(F.conv2d(x, wl, None, 1, 1), bias)).abs().max())
