@@ -127,6 +127,15 @@ int lidar_mean_vfe(const float *voxels, const void *num_points, int num_voxels, 
 int lidar_pillar_scatter_update(const float *pillar_features, const void *coords, int coords_are_float, int num_voxels,
                                 const int *num_voxels_dev, int channels, int batch, int nx, int ny, float *canvas,
                                 int *prev_cells, int *prev_count, void *stream);
+/* The backbone's first convolution straight from the pillars (PointPillarScatter pointpillar_scatter.py:14-37 + the first
+ * ZeroPad2d / Conv2d / BatchNorm / ReLU of BaseBEVBackbone, base_bev_backbone.py:34-45, fused): the k x k / stride / pad
+ * convolution's neighbour table over ALL output pixels in NHWC map order, nbr[(b * OH + oy) * OW + ox][ky * k + kx] = pillar row
+ * at input cell (oy * stride - pad + ky, ox * stride - pad + kx) or -1.  lidar_spconv_implicit_gemm_sorted over this table with
+ * weight (k * k, Cin, Cout), the folded shift as bias and ReLU writes the layer's dense NHWC output (rows without taps get
+ * act(bias)); the > 90 %-zero canvas is never built.  ws: lidar_pillar_conv_table_workspace_bytes (inverse cell -> pillar map). */
+size_t lidar_pillar_conv_table_workspace_bytes(int batch, int nx, int ny);
+int lidar_pillar_conv_table(const void *coords, int coords_are_float, int num_voxels, const int *num_voxels_dev, int batch, int nx,
+                            int ny, int k, int stride, int pad, int *nbr, void *ws, size_t ws_bytes, void *stream);
 size_t lidar_pillar_scatter_workspace_bytes(int batch, int nx, int ny);
 int lidar_pillar_scatter(const float *pillar_features, const void *coords, int coords_are_float, int num_voxels,
                          const int *num_voxels_dev, int channels, int batch, int nx, int ny, int channels_last,

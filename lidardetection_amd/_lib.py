@@ -29,6 +29,8 @@ SIGNATURES = {
     "lidar_pillar_scatter_workspace_bytes": (sz, [i32, i32, i32]),
     "lidar_pillar_scatter": (i32, [vp, vp, i32, i32, vp, i32, i32, i32, i32, i32, vp, vp, sz, vp]),
     "lidar_pillar_scatter_update": (i32, [vp, vp, i32, i32, vp, i32, i32, i32, i32, vp, vp, vp, vp]),
+    "lidar_pillar_conv_table_workspace_bytes": (sz, [i32, i32, i32]),
+    "lidar_pillar_conv_table": (i32, [vp, i32, i32, vp, i32, i32, i32, i32, i32, i32, vp, vp, sz, vp]),
     "lidar_iou_workspace_bytes": (sz, [i32, i32]),
     "lidar_boxes_pairwise_bev": (i32, [vp, i32, vp, i32, i32, vp, vp, sz, vp]),
     "lidar_nms_workspace_bytes": (sz, [i32, i32]),

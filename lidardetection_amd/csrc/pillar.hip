@@ -466,6 +466,56 @@ LIDAR_EXPORT int lidar_pillar_scatter(const float *pillar_features, const void *
     return lidar_check_launch("lidar_pillar_scatter");
 }
 
+// ------------------------------------------------------------------ the backbone's FIRST convolution straight from the pillars
+// PointPillarScatter writes a canvas that is > 90 % zeros and the backbone's first layer (base_bev_backbone.py:34-39: ZeroPad2d(1) +
+// Conv2d(3x3, stride s) + BatchNorm + ReLU) then multiplies all of them: 63 GFLOP for PointPillar-KITTI at bs 16, of which the
+// 16 000 pillars per frame reach 2.25 output pixels each: 4.7 GFLOP.  This builds, from the pillar coordinates alone, the
+// neighbour table of that convolution over ALL output pixels in map order — nbr[(b * OH + oy) * OW + ox][ky * k + kx] = the
+// pillar row at input cell (oy * stride - pad + ky, ox * stride - pad + kx) or -1 — so that the sparse implicit GEMM
+// (csrc/sparse_conv.hip, rows grouped by their tap mask) can write the layer's DENSE NHWC output directly: rows with taps get
+// the convolution, rows without get act(bias), every output element written exactly once.  The canvas is never built.
+// ws: (batch * ny * nx) ints (inverse cell -> pillar map, rebuilt every call).
+__global__ __launch_bounds__(256) void pillar_conv_table_kernel(const int *__restrict__ map, int B, int ny, int nx, int OH, int OW, int k,
+                                                                int stride, int pad, int *__restrict__ nbr) {
+    const long long i = (long long)blockIdx.x * 256 + threadIdx.x;           // one thread per (output pixel, tap): coalesced table writes
+    const int K = k * k;
+    const long long total = (long long)B * OH * OW * K;
+    if (i >= total) return;
+    const int tap = (int)(i % K);
+    long long o = i / K;
+    const int ox = (int)(o % OW);
+    o /= OW;
+    const int oy = (int)(o % OH);
+    const int b = (int)(o / OH);
+    const int iy = oy * stride - pad + tap / k, ix = ox * stride - pad + tap % k;
+    nbr[i] = (iy >= 0 && iy < ny && ix >= 0 && ix < nx) ? map[((size_t)b * ny + iy) * nx + ix] : -1;
+}
+
+LIDAR_EXPORT size_t lidar_pillar_conv_table_workspace_bytes(int batch, int nx, int ny) {
+    return align_up((size_t)batch * nx * ny * 4, 256);
+}
+
+LIDAR_EXPORT int lidar_pillar_conv_table(const void *coords, int coords_are_float, int num_voxels, const int *num_voxels_dev, int batch,
+                                         int nx, int ny, int k, int stride, int pad, int *nbr, void *ws, size_t ws_bytes, void *stream) {
+    if (!coords || !nbr || !ws || batch <= 0 || nx <= 0 || ny <= 0 || num_voxels < 0 || k <= 0 || k > 5 || stride <= 0 || pad < 0)
+        return LIDAR_ERR_ARG;
+    if (ws_bytes < lidar_pillar_conv_table_workspace_bytes(batch, nx, ny)) return LIDAR_ERR_WORKSPACE;
+    const int OH = (ny + 2 * pad - k) / stride + 1, OW = (nx + 2 * pad - k) / stride + 1;
+    if (OH <= 0 || OW <= 0) return LIDAR_ERR_ARG;
+    const long long cells = (long long)batch * nx * ny, total = (long long)batch * OH * OW * k * k;
+    if (cells > 0x7fffffffll || total > 0x7fffffffll * 256ll) return LIDAR_ERR_ARG;
+    hipStream_t s = (hipStream_t)stream;
+    int *map = (int *)ws;
+    int fb = divup(cells, 256 * 4);
+    if (fb > 2048) fb = 2048;
+    hipLaunchKernelGGL(scatter_fill_kernel, dim3(fb), dim3(256), 0, s, map, cells);
+    if (num_voxels > 0)
+        hipLaunchKernelGGL(scatter_index_kernel, dim3(divup(num_voxels, 256)), dim3(256), 0, s, coords, coords_are_float, num_voxels,
+                           num_voxels_dev, batch, nx, ny, ny, map);
+    hipLaunchKernelGGL(pillar_conv_table_kernel, dim3((unsigned)divup(total, 256)), dim3(256), 0, s, map, batch, ny, nx, OH, OW, k, stride, pad, nbr);
+    return lidar_check_launch("lidar_pillar_conv_table");
+}
+
 // Resident canvas: a BEV canvas is > 90 % zeros, and a step's pillars touch a few per cent of its cells.  Instead of rewriting
 // the whole canvas every call (877 MB for PointPillar-KITTI at bs 16), the caller keeps ONE channels-last canvas in HBM; a
 // call clears the cells the previous call wrote (their ids are remembered) and writes the new pillars: ~2 x V x CH x 4 bytes.

@@ -83,3 +83,33 @@ class ResidentCanvas:
                                                           _lib.ptr(self.prev_cells), _lib.ptr(self.prev_count), _lib.stream()),
                    "lidar_pillar_scatter_update")
         return self.canvas
+
+
+def pillar_conv_table(coords, batch_size, nx, ny, k, stride, pad, num_voxels_dev=None):
+    """Neighbour table of the k x k / stride / pad convolution that follows PointPillarScatter, over all output pixels in NHWC map
+    order: (B * OH * OW, k * k) int32 pillar rows or -1 (csrc/pillar.hip lidar_pillar_conv_table).  -> (nbr, OH, OW)"""
+    _lib.require_cuda(coords)
+    if coords.dtype not in (torch.int32, torch.float32) or coords.dim() != 2 or coords.shape[1] != 4:
+        raise _lib.LidarHipError("pillar_conv_table: coords must be (V, 4) [b, z, y, x] int32 or float32")
+    OH, OW = (ny + 2 * pad - k) // stride + 1, (nx + 2 * pad - k) // stride + 1
+    L = _lib.lib()
+    nbr = torch.empty((batch_size * OH * OW, k * k), dtype=torch.int32, device=coords.device)
+    wsb = L.lidar_pillar_conv_table_workspace_bytes(batch_size, nx, ny)
+    ws = workspace.get("pillar_conv_table", wsb, coords.device)
+    _lib.check(L.lidar_pillar_conv_table(_lib.ptr(coords), int(coords.dtype == torch.float32), coords.shape[0], _lib.ptr(num_voxels_dev),
+                                         batch_size, nx, ny, int(k), int(stride), int(pad), _lib.ptr(nbr), _lib.ptr(ws), wsb, _lib.stream()),
+               "lidar_pillar_conv_table")
+    return nbr, OH, OW
+
+
+class PillarMap:
+    """What PointPillarScatter's output IS before anybody materialises it: the PFN rows, their coordinates and the count (on the
+    device).  A consumer that can work from the pillars (FoldedBEVBackbone's sparse first layer) never builds the > 90 %-zero
+    canvas; dense() gives the ordinary channels-last canvas (through the owner's ResidentCanvas) to everybody else."""
+
+    def __init__(self, features, coords, num_voxels_dev, batch_size, nx, ny, dense_fn):
+        self.features, self.coords, self.num_voxels_dev = features, coords, num_voxels_dev
+        self.B, self.nx, self.ny, self._dense_fn = batch_size, nx, ny, dense_fn
+
+    def dense(self):
+        return self._dense_fn(self.features, self.coords, self.num_voxels_dev)

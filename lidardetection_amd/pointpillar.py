@@ -147,15 +147,20 @@ class PointPillarKITTI(nn.Module):
         feat = pillar_ops.pillar_vfe(vox["voxels"], vox["voxel_num_points"], vox["voxel_coords"], w, s, t,
                                      self.voxel_size, self.pc_range, num_voxels_dev=total)
         if self.channels_last:      # resident canvas: clear last step's cells, write this step's (130 MB instead of 877 MB)
-            if self._canvas is None:
-                self._canvas = pillar_ops.ResidentCanvas(self.B, feat.shape[1], self.ny, self.nx, vox["voxels"].shape[0], feat.device)
-            return self._canvas.update(feat, vox["voxel_coords"], num_voxels_dev=total)
+            def dense(f, c, n):
+                if self._canvas is None:
+                    self._canvas = pillar_ops.ResidentCanvas(self.B, f.shape[1], self.ny, self.nx, vox["voxels"].shape[0], f.device)
+                return self._canvas.update(f, c, num_voxels_dev=n)
+            if self.fold_bn and self._bev_folded().sparse_first_ok():
+                # the folded backbone runs its first layer from the pillars themselves: no canvas at all (bev_backbone.py)
+                return pillar_ops.PillarMap(feat, vox["voxel_coords"], total, self.B, self.nx, self.ny, dense)
+            return dense(feat, vox["voxel_coords"], total)
         return pillar_ops.pillar_scatter(feat, vox["voxel_coords"], self.B, self.nx, self.ny, num_voxels_dev=total)
 
     def backbone_head(self, canvas):
         if self.fold_bn:
             return (self._bev_folded().merged(canvas),)  # (B, H, W, 18 + 42 + 12): consumed in place by post_process
-        return self.backbone_head_stock(canvas)
+        return self.backbone_head_stock(canvas if torch.is_tensor(canvas) else canvas.dense())
 
     def split_heads(self, head):
         """merged head (B, H, W, C) -> cls (B, N, 3), box (B, N, 7), dir (B, N, 2) as the reference's view() calls give"""

@@ -454,7 +454,10 @@ def mask_order(nbr, stream=None):
     return masks, order
 
 
-PACKED_GEMM = [__import__("os").environ.get("LIDAR_SPCONV_PACKED", "1") != "0"]      # A/B switch: packed-weight GEMM kernel
+# A/B switch for the packed-weight GEMM kernel (LDS-DMA staging + 128-bit operand reads).  Default OFF: measured 8 % SLOWER than the
+# register-A kernel on the SECOND stack (2.18 vs 2.01 ms, profiles/r04/spconv_gemm_layers.log) — W staging is not what holds that
+# kernel back; kept for the bit-identity test and as the record of the experiment.
+PACKED_GEMM = [__import__("os").environ.get("LIDAR_SPCONV_PACKED", "0") != "0"]
 
 
 def pack_gemm_weights(weight_kcc):

@@ -126,9 +126,21 @@ def test_pointpillar_kitti_bs16_timed_path_over_successive_batches(dev):
         hoffs = np.concatenate([[0], np.cumsum([len(f) for f in frames])]).tolist()   # as bench.py: the offsets on the host too
         with torch.no_grad():                                            # bench.py's timed loop, stage by stage
             vox = m.voxelize(pts, offs, hoffs)
-            canvas = m.vfe_scatter(vox)
-            (head,) = m.backbone_head(canvas)
+            pmap = m.vfe_scatter(vox)                                    # a PillarMap: the folded backbone starts from the pillars
+            (head,) = m.backbone_head(pmap)
             out = m.post_process(head)
+            assert not torch.is_tensor(pmap) and m._bev_folded().sparse_first_ok()
+            canvas = pmap.dense()                                        # the canvas everybody else would get (resident buffer)
+            # the sparse first layer (neighbour table over all output pixels + mask-ordered implicit GEMM, csrc/pillar.hip) against
+            # the stock convolution of that canvas: ZeroPad2d(1) + Conv2d(3x3, stride 2) + folded BatchNorm + ReLU
+            bev = m._bev_folded()
+            x1 = bev.first_layer_from_pillars(pmap)
+            w0, b0, st0, pad0, _ = bev.stages[0][0][0]
+            ref1 = torch.relu(torch.nn.functional.conv2d(canvas, w0, b0, st0, pad0))
+            assert x1.shape == ref1.shape and x1.is_contiguous(memory_format=torch.channels_last)
+            e1 = float((x1 - ref1).abs().max())
+            assert e1 <= 1e-4 * max(1.0, float(ref1.abs().max())), (tag, e1)
+            del ref1, x1
         ev, ec, en = _check_voxels(vox, frames, synth.PP_VOXEL, synth.PP_RANGE, 32, 16000, tag)
         total = len(ev)
         # PFN rows: the canvas holds them; recompute the kernel's rows with the model's own arguments (same kernel, same bits)

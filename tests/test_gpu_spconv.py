@@ -227,11 +227,17 @@ def test_mask_sorted_gemm_is_bit_identical(dev, cin, cout, n_out, p_valid):
     assert torch.equal(got, base)
     np.testing.assert_allclose(got.cpu().double().numpy(), ref.numpy(), rtol=0, atol=1e-4)
     # r04: the packed-weight kernel (LDS-DMA staging, 128-bit operand reads) sums the same products in the same order
-    packed = ops.pack_gemm_weights(w_d)
-    assert packed is not None and packed.numel() == K * cin * ((cout + 31) // 32) * 32
-    for rr, bb, relu in ((r_d, b_d, True), (None, None, False), (None, b_d, True)):
-        assert torch.equal(ops.indice_conv_fused(f_d, nbr_d, w_d, bb, rr, relu, st, packed), ops.indice_conv_fused(f_d, nbr_d, w_d, bb, rr, relu, st))
-    assert ops.pack_gemm_weights(torch.zeros(K, 4, 16, device=dev)) is None
+    keep = ops.PACKED_GEMM[0]
+    ops.PACKED_GEMM[0] = True                                             # (default off: measured slower; the kernel stays under test)
+    try:
+        packed = ops.pack_gemm_weights(w_d)
+        assert packed is not None and packed.numel() == K * cin * ((cout + 31) // 32) * 32
+        for rr, bb, relu in ((r_d, b_d, True), (None, None, False), (None, b_d, True)):
+            want = ops.indice_conv_fused(f_d, nbr_d, w_d, bb, rr, relu, st)
+            assert torch.equal(ops.indice_conv_fused(f_d, nbr_d, w_d, bb, rr, relu, st, packed), want)
+        assert ops.pack_gemm_weights(torch.zeros(K, 4, 16, device=dev)) is None
+    finally:
+        ops.PACKED_GEMM[0] = keep
     assert not ops.sorted_gemm_supported(125, 16, 16) and not ops.sorted_gemm_supported(K, 4, 16)
 
 

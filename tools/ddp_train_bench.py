@@ -164,8 +164,13 @@ def run(args, rank, local, world):
 
     for _ in range(max(args.warmup, 1)):
         step()
+    # A / B / A / B, the faster of each pair: on one GPU the two are the same work and first-run effects would otherwise show up
+    # as a (negative) "all-reduce" time
     dt, loss = timed(args.steps)
     dt_ns, _ = timed(args.steps, no_sync=True)
+    dt2, loss = timed(args.steps)
+    dt_ns2, _ = timed(args.steps, no_sync=True)
+    dt, dt_ns = min(dt, dt2), min(dt_ns, dt_ns2)
     # one all-reduce of the gradient volume by itself (what the buckets move per step)
     flat = torch.zeros(grad_bytes // 4, dtype=torch.float32, device=device)
     for _ in range(2):
