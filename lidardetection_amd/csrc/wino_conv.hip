@@ -40,6 +40,7 @@
 //   * the 2 x 2 output tiles go through a per-wave LDS staging tile and leave as 16-byte stores of 4 channels (v1: one 4-byte
 //     store per value, 23 % of the 64-channel layer).
 #include "common.h"
+#include <stdlib.h>
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef float f32x4 __attribute__((ext_vector_type(4)));
@@ -386,6 +387,271 @@ __global__ __launch_bounds__(256) void wino_f23_kernel(const WinoArgs a) {
 #undef WINO_CHUNK
 }
 
+// ------------------------------------------------------------------ v4: two waves per SIMD, the 16 positions split between a wave pair
+// The kernel above runs ONE wave per SIMD (256 accumulator registers), so every instruction that is not an MFMA — a filter load
+// (30-60 issue cycles each), a wait, the barrier — idles the matrix pipe (ablations: 0.53-0.58 of the fp32 MFMA peak against 0.62-0.68
+// with all of them removed).  Here a (tile block, channel group) is shared by TWO waves that sit on the same SIMD: wave ph = 0 owns
+// transform rows xi_y in {0, 1} (positions 0..7), wave ph = 1 rows {2, 3} — 128 accumulator registers each, 256 registers per wave,
+// two waves per SIMD — and each wave's stalls are covered by its partner's MFMAs.  Workgroup = 8 waves: wave w -> (mw, nw) = w & 3
+// split as above, ph = w >> 2 (waves w and w + 4 share SIMD w & 3).  Everything else is the v3 pipeline: same LDS images, same
+// packed filters (a wave reads the four 16-byte pieces of its half), one barrier per chunk, persistent over tile blocks.
+// The output transform is linear in the positions: each wave forms the partial 2 x 2 outputs of its half, the pair meets in an LDS
+// staging tile (two rounds of 16 tiles), and each wave finishes (adds the partner's partials, shift, ReLU) and stores half the pixels.
+static constexpr size_t wino2_lds_bytes(int NW, bool TALL) {
+    return (size_t)2 * wino_rp(NW, TALL) * 16 + (size_t)2 * (4 / NW) * 16 * 64 * 8 + (size_t)4 * 2 * 64 * 32 * 4;
+}
+
+template <int NW, bool TALL>
+__global__ __launch_bounds__(512) void wino_f23x2_kernel(const WinoArgs a) {
+    constexpr int MW = 4 / NW;
+    constexpr int TYW = TALL ? 8 : 4, TXW = TALL ? 4 : 8;
+    constexpr int RW = 2 * TXW + 2;
+    constexpr int RH = 2 * TYW * MW + 2;
+    constexpr int RP = wino_rp(NW, TALL);
+    constexpr int NQ = RP / 64;                           // DMA wave-instructions per chunk and workgroup
+    constexpr int QW = (NQ + 7) / 8;                      // ... per wave (8 waves)
+    extern __shared__ float4 s_mem4[];
+    float4 *s_raw = s_mem4;                                                   // [2][RP]
+    f32x2 *s_v = reinterpret_cast<f32x2 *>(s_mem4 + 2 * RP);                  // [2][MW][16][64]
+    float *s_stg = reinterpret_cast<float *>(s_v + 2 * MW * 16 * 64);         // [4 pairs][2 halves][64 pixels][32 channels]
+
+    const int t = threadIdx.x, l = t & 63, wv = __builtin_amdgcn_readfirstlane(t >> 6);
+    const int pr = wv & 3, ph = wv >> 2;                  // wave pair (= SIMD), position half
+    const int mw = pr / NW, nw = pr % NW;
+    const int i = l & 31, h = l >> 5;
+    const int ty = TALL ? (i >> 2) : (i >> 3), tx = TALL ? (i & 3) : (i & 7);
+    const int H = a.H, W = a.W, Cin = a.Cin;
+    const int NB = a.Cout >> 5;
+    const size_t bstride = (size_t)NB * 8 * 64;          // float4 per chunk
+
+    const int nb8 = (a.n_blocks + 7) >> 3;
+    const int xcd = (int)(blockIdx.x & 7), slot = (int)(blockIdx.x >> 3), nslots = (int)(gridDim.x >> 3);
+    const int blk_end = min((xcd + 1) * nb8, a.n_blocks);
+    int blk = xcd * nb8 + slot;
+    if (blk >= blk_end) return;
+
+    struct Tile {
+        const float *src[QW];
+        bool ok[QW];
+        const f32x4 *b;                  // this wave's half of the packed filters (pieces 4 ph .. 4 ph + 3), chunk 0
+        int bidx, by, bx, nb;
+    };
+    auto make_tile = [&](int blk_) {
+        Tile tl;
+        const int ng = blk_ % a.n_groups;
+        blk_ /= a.n_groups;
+        tl.bx = blk_ % a.blocks_x;
+        blk_ /= a.blocks_x;
+        tl.by = blk_ % a.blocks_y;
+        tl.bidx = blk_ / a.blocks_y;
+        tl.nb = ng * NW + nw;
+        tl.b = reinterpret_cast<const f32x4 *>(a.upk) + ((size_t)tl.nb * 8 + 4 * ph) * 64 + l;
+        const int R0 = 2 * TYW * MW * tl.by - 1, C0 = 2 * TXW * tl.bx - 1;
+#pragma unroll
+        for (int k = 0; k < QW; ++k) {
+            const int q = wv + 8 * k;
+            const int p = q * 64 + l;
+            const int ry = p / RW, rx = p - ry * RW;
+            const int gy = R0 + ry, gx = C0 + rx;
+            tl.ok[k] = (q < NQ) && (p < RH * RW) && gy >= 0 && gy < H && gx >= 0 && gx < W;
+            tl.src[k] = tl.ok[k] ? a.in + (((size_t)tl.bidx * H + gy) * W + gx) * Cin : (const float *)&g_wino_zero;
+        }
+        return tl;
+    };
+    auto dma = [&](const Tile &tl, int c, int buf) {
+#pragma unroll
+        for (int k = 0; k < QW; ++k) {
+            const int q = wv + 8 * k;
+            if (q < NQ) {
+                const float *g = tl.ok[k] ? tl.src[k] + 4 * c : tl.src[k];
+                __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)g,
+                                                 (__attribute__((address_space(3))) void *)(s_raw + buf * RP + q * 64), 16, 0, 0);
+            }
+        }
+    };
+    // transform rows: the 2 NW waves of a tile block share its four rows — wave u = nw + NW * ph takes row u (NW = 4: the ph = 0 waves;
+    // NW = 2: one row per wave)
+    const int slot0 = (2 * TYW * mw + 2 * ty) * RW + 2 * tx;
+    // (NW = 4: the ph = 1 waves recompute their partner's row and store the same values to the same place — cheaper than a branch
+    // in every step of the loop, which also split the scheduling regions and spilled)
+    const int xy = (nw + NW * ph) & 3;                    // wave-uniform
+    const int tra = xy == 0 ? 0 : (xy == 2 ? 2 : 1), trb = xy < 2 ? 2 : (xy == 2 ? 1 : 3);
+    const float tsg = xy == 1 ? 1.f : -1.f;
+    auto transform = [&](int rbuf, int vbuf) {
+        const f32x2 *base = reinterpret_cast<const f32x2 *>(s_raw + rbuf * RP + slot0) + h;
+        f32x2 *vdst = s_v + ((size_t)(vbuf * MW + mw) * 16) * 64 + l;
+        f32x2 tr[4];
+#pragma unroll
+        for (int x = 0; x < 4; ++x) {
+            const f32x2 da = base[(tra * RW + x) * 2], db = base[(trb * RW + x) * 2];
+            tr[x][0] = __builtin_fmaf(tsg, db[0], da[0]);
+            tr[x][1] = __builtin_fmaf(tsg, db[1], da[1]);
+        }
+        vdst[(xy * 4 + 0) * 64] = tr[0] - tr[2];
+        vdst[(xy * 4 + 1) * 64] = tr[1] + tr[2];
+        vdst[(xy * 4 + 2) * 64] = tr[2] - tr[1];
+        vdst[(xy * 4 + 3) * 64] = tr[1] - tr[3];
+    };
+    auto load_v = [&](int vbuf, f32x2 (&v)[8]) {          // this wave's positions 8 ph .. 8 ph + 7
+        const f32x2 *vsrc = s_v + ((size_t)(vbuf * MW + mw) * 16 + 8 * ph) * 64 + l;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) v[e] = vsrc[e * 64];
+    };
+    auto load_b = [&](const Tile &tl, int c, f32x4 (&bb)[4]) {
+        const f32x4 *p = tl.b + (size_t)c * bstride;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) bb[e] = p[e * 64];
+    };
+
+    f32x16 acc[8];
+    const int NC = Cin >> 2;
+    f32x4 b0[4], b1[4];
+    f32x2 vv[8];
+    Tile cur = make_tile(blk), nxt = cur;
+
+    dma(cur, 0, 0);
+    dma(cur, 1, 1);
+    load_b(cur, 0, b0);
+    __syncthreads();
+    transform(0, 0);
+    __syncthreads();
+    if (2 < NC) dma(cur, 2, 0);
+    transform(1, 1);
+    load_v(0, vv);
+    __syncthreads();
+
+    // chunk c (parity P): as in the one-wave kernel, 16 MFMAs per wave.  position e (0..7) of this wave, K-step s: B piece e >> 1,
+    // component 2 (e & 1) + s
+#define WINO2_CHUNK(c, P, FIRST, BC, BN)                                                                                           \
+    {                                                                                                                              \
+        if ((c) > 0) __syncthreads();                                                                                              \
+        else if (!first_block) {                                                                                                   \
+            __builtin_amdgcn_s_waitcnt(0xC07F);                                                                                    \
+            __builtin_amdgcn_s_barrier();                                                                                          \
+        }                                                                                                                          \
+        if ((c) + 3 < NC) dma(cur, (c) + 3, 1 - (P));                                                                              \
+        else if (has_next) dma(nxt, (c) + 3 - NC, 1 - (P));                                                                        \
+        const f32x4 *bp_ = ((c) + 1 < NC) ? cur.b + (size_t)((c) + 1) * bstride : (has_next ? nxt.b : cur.b);                      \
+        const f32x2 *rb_ = reinterpret_cast<const f32x2 *>(s_raw + (P) * RP + slot0) + h;                                          \
+        const f32x2 *vs_ = s_v + ((size_t)((1 - (P)) * MW + mw) * 16 + 8 * ph) * 64 + l;                                           \
+        f32x2 *vd_ = s_v + ((size_t)((P) * MW + mw) * 16) * 64 + l;                                                                \
+        f32x2 da_[4], db_[4];                                                                                                      \
+        __builtin_amdgcn_sched_barrier(0);                                                                                         \
+        _Pragma("unroll") for (int k = 0; k < 16; ++k) {                                                                           \
+            const float bop_ = BC[(k & 7) >> 1][((k & 1) << 1) + (k >> 3)];                                                        \
+            if (FIRST && k < 8) {                                                                                                  \
+                f32x16 z_;                                                                                                         \
+                _Pragma("unroll") for (int r_ = 0; r_ < 16; ++r_) z_[r_] = 0.f;                                                    \
+                acc[k & 7] = __builtin_amdgcn_mfma_f32_32x32x2f32(vv[k & 7][k >> 3], bop_, z_, 0, 0, 0);                           \
+            } else {                                                                                                               \
+                acc[k & 7] = __builtin_amdgcn_mfma_f32_32x32x2f32(vv[k & 7][k >> 3], bop_, acc[k & 7], 0, 0, 0);                   \
+            }                                                                                                                      \
+            if (k < 4) BN[k] = bp_[k * 64];                                                                                        \
+            if (k < 4) { da_[k] = rb_[(tra * RW + k) * 2]; db_[k] = rb_[(trb * RW + k) * 2]; }                                     \
+            if (k >= 4 && k < 8) {                                                                                                 \
+                da_[k - 4][0] = __builtin_fmaf(tsg, db_[k - 4][0], da_[k - 4][0]);                                                 \
+                da_[k - 4][1] = __builtin_fmaf(tsg, db_[k - 4][1], da_[k - 4][1]);                                                 \
+            }                                                                                                                      \
+            if (k == 8) {                                                                                                          \
+                vd_[(xy * 4 + 0) * 64] = da_[0] - da_[2];                                                                          \
+                vd_[(xy * 4 + 1) * 64] = da_[1] + da_[2];                                                                          \
+                vd_[(xy * 4 + 2) * 64] = da_[2] - da_[1];                                                                          \
+                vd_[(xy * 4 + 3) * 64] = da_[1] - da_[3];                                                                          \
+            }                                                                                                                      \
+            /* the next chunk's A operands roll into the registers this chunk has finished with: position e is last read by MFMA  \
+               e + 8, so its successor is loaded at step e + 9 (one register set instead of two: 128 VGPRs is all a wave has) */   \
+            if (k >= 9) vv[k - 9] = vs_[(k - 9) * 64];                                                                             \
+            __builtin_amdgcn_sched_barrier(0);                                                                                     \
+        }                                                                                                                          \
+        vv[7] = vs_[7 * 64];                                                                                                       \
+    }
+
+    bool first_block = true;
+    for (;;) {
+        const int blk_next = blk + nslots;
+        const bool has_next = blk_next < blk_end;
+        if (has_next) nxt = make_tile(blk_next);
+        WINO2_CHUNK(0, 0, true, b0, b1)
+        WINO2_CHUNK(1, 1, false, b1, b0)
+        for (int c = 2; c < NC; c += 2) {
+            WINO2_CHUNK(c, 0, false, b0, b1)
+            WINO2_CHUNK(c + 1, 1, false, b1, b0)
+        }
+        // ---- epilogue.  Partial outputs of this wave's half: y[2 i + j][r] += At[i][xi_y] At[j][xi_x] acc[e][r], xi = 8 ph + e,
+        // At = [1 1 1 0; 0 1 -1 -1]; two rounds of 8 accumulator rows (= 16 tiles = 64 pixels) through the pair's staging tile
+        {
+            __builtin_amdgcn_s_waitcnt(0x0F70);            // vmcnt(0): drain the next block's DMA / filter loads before the stores
+            int lo = l;
+            asm volatile("" : "+v"(lo));
+            const int ch0 = 32 * cur.nb;
+            const float4 bv4 = a.bias ? *reinterpret_cast<const float4 *>(a.bias + ch0 + 4 * (lo & 7)) : make_float4(0.f, 0.f, 0.f, 0.f);
+            const bool relu = a.relu != 0;
+            float *stg = s_stg + (size_t)pr * 2 * 64 * 32;
+            float *obase = a.out + (size_t)cur.bidx * H * W * a.out_C + a.out_off + ch0 + 4 * (lo & 7);
+            const int tile_y0 = TYW * (MW * cur.by + mw), tile_x0 = TXW * cur.bx;
+#pragma unroll
+            for (int rnd = 0; rnd < 2; ++rnd) {
+                float yv[4][8];
+#pragma unroll
+                for (int p = 0; p < 4; ++p)
+#pragma unroll
+                    for (int r = 0; r < 8; ++r) yv[p][r] = 0.f;
+#pragma unroll
+                for (int e = 0; e < 8; ++e) {
+                    float m[8];
+#pragma unroll
+                    for (int r = 0; r < 8; ++r) asm volatile("v_accvgpr_read_b32 %0, %1" : "=v"(m[r]) : "a"(acc[e][8 * rnd + r]));
+                    // xi_y = 2 ph + (e >> 2), xi_x = e & 3.  ph is wave-uniform but not a compile-time constant: both cases written out
+                    const int cx[2] = {(e & 3) < 3 ? 1 : 0, (e & 3) == 0 ? 0 : ((e & 3) == 1 ? 1 : -1)};
+#pragma unroll
+                    for (int p = 0; p < 4; ++p) {
+                        // At[i][xi_y]: ph = 0: xi_y 0 -> (1, 0), 1 -> (1, 1);  ph = 1: xi_y 2 -> (1, -1), 3 -> (0, -1)
+                        const int ii = p >> 1;
+                        const int cy0 = (e >> 2) == 0 ? (ii == 0 ? 1 : 0) : 1;            // ph = 0
+                        const int cy1 = (e >> 2) == 0 ? (ii == 0 ? 1 : -1) : (ii == 0 ? 0 : -1);   // ph = 1
+                        const int c0 = cy0 * cx[p & 1], c1 = cy1 * cx[p & 1];
+                        if (c0 == c1) {
+                            if (c0 == 1) { _Pragma("unroll") for (int r = 0; r < 8; ++r) yv[p][r] += m[r]; }
+                            else if (c0 == -1) { _Pragma("unroll") for (int r = 0; r < 8; ++r) yv[p][r] -= m[r]; }
+                        } else {
+                            const float f = ph == 0 ? (float)c0 : (float)c1;             // wave-uniform, in {-1, 0, 1}: exact
+                            _Pragma("unroll") for (int r = 0; r < 8; ++r) yv[p][r] = __builtin_fmaf(f, m[r], yv[p][r]);
+                        }
+                    }
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+                // rows r = 8 rnd + j: tile it = 8 (r >> 2) + 4 h + (r & 3) -> local tile (it - 16 rnd) in 0..15
+                float *mine = stg + (size_t)ph * 64 * 32;
+#pragma unroll
+                for (int j = 0; j < 8; ++j) {
+                    const int itl = 8 * (j >> 2) + 4 * h + (j & 3);
+#pragma unroll
+                    for (int p = 0; p < 4; ++p) mine[(itl * 4 + p) * 32 + i] = yv[p][j];
+                }
+                __syncthreads();                           // both halves of every pair are staged
+                // this wave finishes pixels [32 ph, 32 ph + 32) of the round: 8 lanes per pixel, 4 store instructions
+#pragma unroll
+                for (int k = 0; k < 4; ++k) {
+                    const int pix = 32 * ph + k * 8 + (lo >> 3);
+                    const float4 pa = *reinterpret_cast<const float4 *>(stg + pix * 32 + 4 * (lo & 7));
+                    const float4 pb = *reinterpret_cast<const float4 *>(stg + 64 * 32 + pix * 32 + 4 * (lo & 7));
+                    float4 v = make_float4(pa.x + pb.x + bv4.x, pa.y + pb.y + bv4.y, pa.z + pb.z + bv4.z, pa.w + pb.w + bv4.w);
+                    if (relu) v = make_float4(fmaxf(v.x, 0.f), fmaxf(v.y, 0.f), fmaxf(v.z, 0.f), fmaxf(v.w, 0.f));
+                    const int it = 16 * rnd + (pix >> 2), py = (pix >> 1) & 1, px = pix & 1;
+                    const int oy = 2 * (tile_y0 + (TALL ? (it >> 2) : (it >> 3))) + py, ox = 2 * (tile_x0 + (TALL ? (it & 3) : (it & 7))) + px;
+                    if (oy < H && ox < W) *reinterpret_cast<float4 *>(obase + ((size_t)oy * W + ox) * a.out_C) = v;
+                }
+                if (rnd == 0) __syncthreads();             // the staging tile is rewritten by round 1
+            }
+        }
+        if (!has_next) break;
+        cur = nxt;
+        blk = blk_next;
+        first_block = false;
+    }
+#undef WINO2_CHUNK
+}
+
 // ------------------------------------------------------------------ C ABI
 LIDAR_EXPORT size_t lidar_wino_packed_floats(int Cin, int Cout) {
     if (Cin <= 0 || Cout <= 0 || (Cin & 7) || (Cout & 31)) return 0;       // two 4-channel chunks per loop iteration
@@ -449,9 +715,27 @@ LIDAR_EXPORT int lidar_wino_conv3x3_nhwc(const float *in, int B, int H, int W, i
         }                                                                                                                         \
         hipLaunchKernelGGL((wino_f23_kernel<NWV, TALLV>), grid, blk, wino_lds_bytes(NWV, TALLV), s, a);                           \
     } while (0)
-    if (NW == 4) { if (use_tall) WINO_LAUNCH(4, true); else WINO_LAUNCH(4, false); }
+#define WINO2_LAUNCH(NWV, TALLV) do {                                                                                              \
+        static bool attr_set2 = false;                                                                                            \
+        if (!attr_set2) {                                                                                                         \
+            (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&wino_f23x2_kernel<NWV, TALLV>), hipFuncAttributeMaxDynamicSharedMemorySize, \
+                                      (int)wino2_lds_bytes(NWV, TALLV));                                                           \
+            attr_set2 = true;                                                                                                     \
+        }                                                                                                                         \
+        hipLaunchKernelGGL((wino_f23x2_kernel<NWV, TALLV>), grid, dim3(512), wino2_lds_bytes(NWV, TALLV), s, a);                  \
+    } while (0)
+    // A/B switch: LIDAR_WINO_X2=1 selects the two-waves-per-SIMD kernel.  Default OFF — measured on one box, same process order
+    // (profiles/r04/wino_x2_vs_v3.log): 64 ch 0.389 vs 0.401 ms, 128 ch 0.343-0.349 vs 0.328, 256 ch 0.357-0.362 vs 0.335, SECOND
+    // shapes 0.83 / 0.86 vs 0.82 / 0.84: doubling the occupancy does not recover the 20 % the one-wave kernel loses against its
+    // MFMA-only ablation, i.e. that loss is not per-wave latency (which a partner wave would hide) but issue time the SIMD spends on
+    // the chunk's vector-memory / LDS instructions whichever wave they belong to.
+    static const bool two_waves = getenv("LIDAR_WINO_X2") && atoi(getenv("LIDAR_WINO_X2")) != 0;
+    if (NW == 4 && two_waves) { if (use_tall) WINO2_LAUNCH(4, true); else WINO2_LAUNCH(4, false); }
+    else if (NW == 2 && two_waves) { if (use_tall) WINO2_LAUNCH(2, true); else WINO2_LAUNCH(2, false); }
+    else if (NW == 4) { if (use_tall) WINO_LAUNCH(4, true); else WINO_LAUNCH(4, false); }
     else if (NW == 2) { if (use_tall) WINO_LAUNCH(2, true); else WINO_LAUNCH(2, false); }
     else { if (use_tall) WINO_LAUNCH(1, true); else WINO_LAUNCH(1, false); }
 #undef WINO_LAUNCH
+#undef WINO2_LAUNCH
     return lidar_check_launch("lidar_wino_conv3x3_nhwc");
 }

@@ -88,3 +88,28 @@ def test_wino_boundary_rejects_unsupported_shapes(dev):
         wino.conv3x3(x, torch.zeros(16, device=dev), 64)
     with pytest.raises(_lib.LidarHipError):
         wino.conv3x3(torch.zeros(1, 64, 8, 8, device=dev), wino.pack_weights(torch.zeros(64, 64, 3, 3, device=dev)), 64)   # NCHW strides
+
+
+def test_wino_two_waves_per_simd_kernel_matches(dev):
+    """LIDAR_WINO_X2=1 (csrc/wino_conv.hip wino_f23x2_kernel: the 16 positions split between a wave pair on one SIMD, partial output
+    transforms met in LDS) — measured no faster than the default kernel and therefore off, but kept under test: run in a child
+    process (the switch is read once per process) and compare against the float64 direct convolution at the same 1e-4."""
+    import os
+    import subprocess
+    import sys
+    code = r"""
+import numpy as np, torch, torch.nn.functional as F
+from lidardetection_amd import wino
+dev = torch.device('cuda:0')
+for B, cin, cout, H, W in ((2, 64, 64, 20, 36), (1, 128, 128, 14, 22), (1, 64, 256, 62, 54), (1, 64, 64, 32, 8)):
+    g = torch.Generator(device='cpu').manual_seed(cin + cout + H)
+    x = torch.randn(B, cin, H, W, generator=g); w = torch.randn(cout, cin, 3, 3, generator=g) / np.sqrt(9 * cin); b = torch.randn(cout, generator=g)
+    got = wino.conv3x3(x.to(dev).contiguous(memory_format=torch.channels_last), wino.pack_weights(w.to(dev)), cout, b.to(dev), True)
+    want = torch.relu(F.conv2d(x.double(), w.double(), b.double(), 1, 1))
+    err = float((got.double().cpu() - want).abs().max())
+    assert err <= 1e-4 * max(1.0, float(want.abs().max())), (cin, cout, H, W, err)
+print('x2 ok')
+"""
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    r = subprocess.run([sys.executable, "-c", code], env=dict(os.environ, LIDAR_WINO_X2="1", PYTHONPATH=root), capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0 and "x2 ok" in r.stdout, r.stderr[-800:]
