@@ -399,6 +399,17 @@ int lidar_wino_pack_weights(const float *w, int Cin, int Cout, float *packed, vo
 int lidar_wino_conv3x3_nhwc(const float *in, int B, int H, int W, int Cin, const float *packed, const float *bias, int relu, int Cout,
                             float *out, int out_C, int out_off, void *stream);
 
+/* ConvTranspose2d with kernel == stride == s (the deblocks of BaseBEVBackbone, base_bev_backbone.py:51-57) + folded BatchNorm shift
+ * + ReLU + the write into the layer's channel slice of the concatenated map (base_bev_backbone.py:103) as ONE fp32-MFMA kernel
+ * (csrc/deconv_gemm.hip): out[b][s y + ky][s x + kx][out_off + c] = act(sum_k in[b][y][x][k] W[k][(ky, kx, c)] + bias[c]).
+ * W: (K, s * s * C_up) row-major, columns ordered (ky, kx, c); packed once per weight update (lidar_deconv_pack_weights,
+ * lidar_deconv_packed_floats floats; 0 = unsupported: K % 8 == 0, C_up % 128 == 0 and s * s * C_up % 512 == 0 are supported). */
+size_t lidar_deconv_packed_floats(int K, int N);
+int lidar_deconv_supported(int K, int s, int C_up);
+int lidar_deconv_pack_weights(const float *W, int K, int N, float *packed, void *stream);
+int lidar_deconv_gemm_nhwc(const float *in, int B, int h, int w, int K, const float *packed, const float *bias, int relu, int s, int C_up,
+                           float *out, int out_C, int out_off, void *stream);
+
 /* ------------------------------------------------------------------ anchor-head post-processing feeding NMS (8f rank 1)
  * head: (n_loc = B*H*W, row_stride) rows of the merged head output [cls | box | dir] as the 1x1 heads emit it
  * (pcdet/models/dense_heads/anchor_head_single.py:45-55).  Anchor index = loc * anchors_per_loc + a, class logit

@@ -104,6 +104,10 @@ SIGNATURES = {
     "lidar_wino_supported": (i32, [i32, i32]),
     "lidar_wino_pack_weights": (i32, [vp, i32, i32, vp, vp]),
     "lidar_wino_conv3x3_nhwc": (i32, [vp, i32, i32, i32, i32, vp, vp, i32, i32, vp, i32, i32, vp]),
+    "lidar_deconv_packed_floats": (sz, [i32, i32]),
+    "lidar_deconv_supported": (i32, [i32, i32, i32]),
+    "lidar_deconv_pack_weights": (i32, [vp, i32, i32, vp, vp]),
+    "lidar_deconv_gemm_nhwc": (i32, [vp, i32, i32, i32, i32, vp, vp, i32, i32, i32, vp, i32, i32, vp]),
     "lidar_anchor_scores": (i32, [vp, C.c_longlong, i32, i32, i32, i32, f32, vp, vp, vp]),
     "lidar_decode_topk": (i32, [vp, i32, C.c_longlong, i32, i32, i32, i32, i32, vp, i32, vp, f32, f32, f32, vp, vp]),
     "lidar_topk_workspace_bytes": (sz, [i32, C.c_longlong]),

@@ -42,6 +42,7 @@ def bias_act_(x, bias, relu=True, out=None, out_offset=0):
 _LT_GEMM = [os.environ.get("LIDAR_BEV_LT_GEMM", "1") != "0"]      # the fused stride-1 deblock (csrc/dense_gemm.hip); A/B switch
 _SPLIT = [int(os.environ.get("LIDAR_BEV_SPLIT", "2"))]            # part-batches / streams of FoldedBEVBackbone.merged (1 = off)
 _WINO = [os.environ.get("LIDAR_BEV_WINO", "1") != "0"]            # stride-1 3x3 layers on csrc/wino_conv.hip (0: MIOpen + epilogue pass)
+_DECONV = [os.environ.get("LIDAR_BEV_DECONV", "1") != "0"]        # stride > 1 deblocks on csrc/deconv_gemm.hip (0: library GEMM + pixel-shuffle pass)
 _SPARSE_FIRST = [os.environ.get("LIDAR_BEV_SPARSE_FIRST", "1") != "0"]   # first layer straight from the pillars (0: dense canvas + MIOpen)
 
 
@@ -103,6 +104,39 @@ def rows_gemm(a2d, w_kn, bias=None, out=None):
     if out is None:
         return torch.mm(a2d, w_kn) if bias is None else torch.addmm(bias, a2d, w_kn)
     return torch.mm(a2d, w_kn, out=out) if bias is None else torch.addmm(bias, a2d, w_kn, out=out)
+
+
+def deconv_supported(K, s, c_up):
+    return bool(_lib.lib().lidar_deconv_supported(int(K), int(s), int(c_up)))
+
+
+def deconv_pack(w_kn):
+    """(K, s*s*C_up) folded ConvTranspose2d weight, columns (ky, kx, c) -> packed form of csrc/deconv_gemm.hip"""
+    _lib.require_cuda(w_kn)
+    K, N = w_kn.shape
+    L = _lib.lib()
+    n = L.lidar_deconv_packed_floats(K, N)
+    if n == 0:
+        raise _lib.LidarHipError(f"deconv_pack: unsupported shape ({K}, {N})")
+    packed = torch.empty(n, dtype=torch.float32, device=w_kn.device)
+    _lib.check(L.lidar_deconv_pack_weights(_lib.ptr(w_kn.contiguous()), K, N, _lib.ptr(packed), _lib.stream()), "lidar_deconv_pack_weights")
+    return packed
+
+
+def deconv_gemm_into_(x, packed, bias, s, out, out_offset=0, relu=True):
+    """x (B, K, h, w) channels-last -> out[:, out_offset:out_offset + C_up] (B, C_out, s*h, s*w channels-last) = act(ConvTranspose2d
+    (kernel == stride == s)(x) + bias): one fp32-MFMA kernel, no temporary, no pixel-shuffle pass (csrc/deconv_gemm.hip)"""
+    _lib.require_cuda(packed, bias)
+    B, K, h, w = x.shape
+    c_up = bias.numel()
+    if not (x.is_cuda and x.dtype == torch.float32 and x.is_contiguous(memory_format=torch.channels_last) and out.is_cuda
+            and out.dtype == torch.float32 and out.is_contiguous(memory_format=torch.channels_last) and out.shape[0] == B
+            and tuple(out.shape[2:]) == (s * h, s * w) and 0 <= out_offset and out_offset + c_up <= out.shape[1]
+            and packed.numel() == K * s * s * c_up):
+        raise _lib.LidarHipError("deconv_gemm_into_: shapes / layouts do not match")
+    _lib.check(_lib.lib().lidar_deconv_gemm_nhwc(_lib.ptr(x), B, h, w, K, _lib.ptr(packed), _lib.ptr(bias), int(bool(relu)), int(s), c_up,
+                                                 _lib.ptr(out), out.shape[1], int(out_offset), _lib.stream()), "lidar_deconv_gemm_nhwc")
+    return out
 
 
 def bias_act_upsample_(y2d, bias, batch, h, w, s, out, out_offset=0, relu=True):
@@ -178,7 +212,10 @@ class FoldedBEVBackbone:
                 if tuple(up.kernel_size) == tuple(up.stride) and up.stride[0] == up.stride[1] and \
                         tuple(up.padding) == (0, 0) and tuple(up.output_padding) == (0, 0):
                     # kernel == stride: every input pixel owns its own s x s output patch -> a plain GEMM
-                    upc = ("gemm", w.permute(0, 2, 3, 1).reshape(w.shape[0], -1).contiguous(), b, up.stride[0])
+                    w_kn = w.permute(0, 2, 3, 1).reshape(w.shape[0], -1).contiguous()
+                    upc = ("gemm", w_kn, b, up.stride[0])
+                    if (_DECONV[0] and w.is_cuda and up.stride[0] > 1 and deconv_supported(w_kn.shape[0], up.stride[0], b.numel())):
+                        upc = ("deconv_mfma", deconv_pack(w_kn), b, up.stride[0])           # csrc/deconv_gemm.hip
                 else:
                     upc = ("deconv", w.contiguous(memory_format=torch.channels_last), b, up.stride)
             else:   # stride < 1 in the reference config: a strided Conv2d (base_bev_backbone.py:60-69)
@@ -236,7 +273,9 @@ class FoldedBEVBackbone:
                 bias_act_(x, b)
             B, _, h, w = x.shape
             y = None
-            if kind == "gemm":
+            if kind == "deconv_mfma":
+                oh, ow = h * ustride, w * ustride
+            elif kind == "gemm":
                 oh, ow = h * ustride, w * ustride
                 if not (ustride == 1 and _LT_GEMM[0]):
                     y = rows_gemm(x.permute(0, 2, 3, 1).reshape(B * h * w, -1), uw)  # the NHWC map IS the row-major A
@@ -256,7 +295,9 @@ class FoldedBEVBackbone:
                 if not gemm_bias_act_into_(x, uw, ub, cat, off):
                     _LT_GEMM[0] = False                                             # not available here: the two-step path from now on
                     y = rows_gemm(x.permute(0, 2, 3, 1).reshape(B * h * w, -1), uw)
-            if kind == "gemm":
+            if kind == "deconv_mfma":
+                deconv_gemm_into_(x, uw, ub, ustride, cat, off)
+            elif kind == "gemm":
                 if y is not None:
                     bias_act_upsample_(y, ub, B, h, w, ustride, cat, off)
             else:
