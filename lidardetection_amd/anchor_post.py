@@ -10,10 +10,11 @@ from . import _lib
 _TOPK_WS = {}
 
 
-def topk_supported(n, k, valid_min=None):
-    """lidar_topk_desc / lidar_anchor_scores_hist take N % 4 == 0, k <= 4096 and a POSITIVE threshold (the selection key is
-    bits(score) - bits(threshold) + 1); anything else (e.g. SCORE_THRESH 0) goes to torch.topk in the callers."""
-    return n % 4 == 0 and 0 < k <= 4096 and n < 2 ** 31 and (valid_min is None or float(valid_min) > 0.0)
+def topk_supported(n, k, valid_min=None, hist=False):
+    """lidar_topk_desc takes N % 4 == 0 and k <= 4096, scores and threshold of any sign (r04: order-preserving key).  hist=True: the
+    fused score + histogram kernel (lidar_anchor_scores_hist) additionally needs a POSITIVE threshold — a config with SCORE_THRESH 0
+    goes to the plain score kernel + topk_desc (or torch.topk) in the callers."""
+    return n % 4 == 0 and 0 < k <= 4096 and n < 2 ** 31 and (not hist or valid_min is None or float(valid_min) > 0.0)
 
 
 def drop_topk_workspace(ws):
@@ -38,17 +39,20 @@ def topk_workspace(batch, n, device):
 
 def topk_desc(scores, k, valid_min, ws=None, hist_ready=False, score_max=1.0):
     """scores (B, N) f32 -> (top_scores (B, k) descending, top_idx (B, k) int64, counts (B,) int32): the k best scores >= valid_min
-    of every frame, ties by ascending index; slots past counts[b] hold (-1, 0).  hist_ready: `ws` was handed to anchor_scores
-    (topk_ws=ws) for these very scores."""
+    of every frame, ties by ascending index; slots past counts[b] hold (-1, 0) for valid_min > 0 and (-inf, 0) otherwise.  valid_min may
+    be any float, -inf = no threshold (raw logits: roi_head_template.py:45-99); score_max: an upper bound (shapes the histogram only).
+    hist_ready: `ws` was handed to anchor_scores (topk_ws=ws) for these very scores."""
     _lib.require_cuda(scores)
-    if scores.dtype != torch.float32 or scores.dim() != 2 or not topk_supported(scores.shape[1], k, valid_min):
-        raise _lib.LidarHipError("topk_desc: scores must be float32 (B, N) with N % 4 == 0, k <= 4096 and valid_min > 0")
+    if scores.dtype != torch.float32 or scores.dim() != 2 or not topk_supported(scores.shape[1], k, valid_min, hist=hist_ready):
+        raise _lib.LidarHipError("topk_desc: scores must be float32 (B, N) with N % 4 == 0 and k <= 4096 (valid_min > 0 with hist_ready)")
     B, n = scores.shape
     if ws is None:
         ws, hist_ready = topk_workspace(B, n, scores.device), False
     top_scores = torch.empty((B, k), dtype=torch.float32, device=scores.device)
     top_idx = torch.empty((B, k), dtype=torch.int64, device=scores.device)
     counts = torch.empty((B,), dtype=torch.int32, device=scores.device)
+    if not float(score_max) >= float(valid_min):
+        raise _lib.LidarHipError("topk_desc: score_max must be >= valid_min")
     _lib.check(_lib.lib().lidar_topk_desc(_lib.ptr(scores), B, n, int(k), float(np.float32(valid_min)), float(np.float32(score_max)),
                                           int(bool(hist_ready)), _lib.ptr(top_scores), _lib.ptr(top_idx), _lib.ptr(counts), _lib.ptr(ws),
                                           ws.numel(), _lib.stream()), "lidar_topk_desc")

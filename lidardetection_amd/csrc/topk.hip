@@ -60,10 +60,15 @@ static size_t tk_carve(void *base, int B, long long n, TkWs *w) {
     return off;
 }
 
-// key of a score: 0 = not a candidate (below valid_min: the masked -1), else float_bits(score) - float_bits(valid_min) + 1
+// Order-preserving map of a float's bits onto unsigned integers (any sign; -0.0 sorts just below +0.0): positive floats keep their
+// order with the sign bit set, negative ones are complemented.  For positive scores and thresholds the differences below equal the
+// plain bit-pattern differences the r03 kernels used, so lidar_anchor_scores_hist's histogram (sigmoid scores) stays compatible.
+__device__ __host__ __forceinline__ unsigned tk_ord(unsigned bits) { return bits ^ ((bits & 0x80000000u) ? 0xFFFFFFFFu : 0x80000000u); }
+__device__ __forceinline__ unsigned tk_unord(unsigned o) { return o ^ ((o & 0x80000000u) ? 0x80000000u : 0xFFFFFFFFu); }
+// key of a score: 0 = not a candidate (below valid_min: the masked -1; NaN), else ord(score) - ord(valid_min) + 1; base_bits = ord(valid_min)
 // (positive floats order like their bit patterns)
 __device__ __forceinline__ unsigned tk_key(float s, float valid_min, unsigned base_bits) {
-    return (s >= valid_min) ? __float_as_uint(s) - base_bits + 1u : 0u;
+    return (s >= valid_min) ? tk_ord(__float_as_uint(s + 0.0f)) - base_bits + 1u : 0u;      // (-0.0 + 0.0 = +0.0: the two zeros tie, as they compare)
 }
 __device__ __forceinline__ int tk_bin(unsigned key, int shift) { return (int)min(key >> shift, (unsigned)(TK_BINS - 1)); }
 // list entry: sorts descending by (key, then ascending index)
@@ -304,7 +309,7 @@ __device__ __forceinline__ void tk_sort_desc_regs(tk_u64 *s, int t) {
     __syncthreads();
 }
 
-__global__ __launch_bounds__(1024) void tk_finalize_kernel(long long n, int k, unsigned base_bits, TkWs w, float *__restrict__ top_scores,
+__global__ __launch_bounds__(1024) void tk_finalize_kernel(long long n, int k, unsigned base_bits, float fill, TkWs w, float *__restrict__ top_scores,
                                                            long long *__restrict__ top_idx, int *__restrict__ counts) {
     __shared__ tk_u64 s_list[TK_KMAX];
     __shared__ tk_u64 s_b[TK_LB];
@@ -450,7 +455,7 @@ __global__ __launch_bounds__(1024) void tk_finalize_kernel(long long n, int k, u
     for (int q = t; q < k; q += 1024) {
         const tk_u64 e = s_list[q];
         const bool ok = q < kk;
-        top_scores[(size_t)f * k + q] = ok ? __uint_as_float((unsigned)(e >> 32) - 1u + base_bits) : -1.0f;
+        top_scores[(size_t)f * k + q] = ok ? __uint_as_float(tk_unord((unsigned)(e >> 32) - 1u + base_bits)) : fill;
         top_idx[(size_t)f * k + q] = ok ? (long long)(0xFFFFFFFFu - (unsigned)(e & 0xFFFFFFFFull)) : 0ll;
     }
     if (t == 0) counts[f] = kk;
@@ -467,7 +472,8 @@ static int tk_shift_of(float valid_min, float score_max) {
     unsigned a, b;
     memcpy(&a, &valid_min, 4);
     memcpy(&b, &score_max, 4);
-    const unsigned span = b - a + 2u;                              // largest key of a score <= score_max, + 1
+    const unsigned long long span64 = (unsigned long long)tk_ord(b) - (unsigned long long)tk_ord(a) + 2ull;   // largest key of a score <= score_max, + 1
+    const unsigned span = span64 > 0xFFFFFFFFull ? 0xFFFFFFFFu : (unsigned)span64;
     int bits = 0;
     while ((span >> bits) != 0u && bits < 32) ++bits;
     return bits > 11 ? bits - 11 : 0;
@@ -507,22 +513,28 @@ LIDAR_EXPORT int lidar_anchor_scores_hist(const float *head, int batch, long lon
 }
 
 // scores (batch, n) f32 -> top_scores (batch, k) descending, top_idx (batch, k) i64, counts (batch) = entries >= valid_min.
-// Candidates are the scores >= valid_min (> 0); slots past counts[b] hold (-1, 0).  hist_ready != 0: the workspace histogram
-// was filled by lidar_anchor_scores_hist with score_thresh == valid_min and scores <= score_max == 1 (sigmoid outputs).
+// Candidates are the scores >= valid_min (any sign, -inf = every non-NaN score; NaNs are never candidates); slots past counts[b] hold
+// (-1, 0) when valid_min > 0 (the masked-score convention of class_agnostic_nms's callers) and (-inf, 0) otherwise.  score_max: an
+// upper bound of the scores (it only shapes the histogram bins: results are exact for any input).  hist_ready != 0: the workspace
+// histogram was filled by lidar_anchor_scores_hist with score_thresh == valid_min (> 0) and score_max == 1 (sigmoid outputs).
 LIDAR_EXPORT int lidar_topk_desc(const float *scores, int batch, long long n, int k, float valid_min, float score_max, int hist_ready,
                                  float *top_scores, long long *top_idx, int *counts, void *ws, size_t ws_bytes, void *stream) {
-    if (batch <= 0 || n <= 0 || k <= 0 || k > TK_KMAX || (n & 3) || n > 0x7fffffffll || !(valid_min > 0.f) || !(score_max >= valid_min))
+    if (batch <= 0 || n <= 0 || k <= 0 || k > TK_KMAX || (n & 3) || n > 0x7fffffffll || !(score_max >= valid_min) ||
+        (hist_ready && !(valid_min > 0.f)))
         return LIDAR_ERR_ARG;
     if (!scores || !top_scores || !top_idx || !counts || !ws || (reinterpret_cast<uintptr_t>(scores) & 15)) return LIDAR_ERR_ARG;
     TkWs w;
     if (tk_carve(ws, batch, n, &w) > ws_bytes) return LIDAR_ERR_WORKSPACE;
     hipStream_t s = (hipStream_t)stream;
     unsigned base_bits;
-    memcpy(&base_bits, &valid_min, 4);
+    const float vm0 = valid_min + 0.0f;                   // a threshold of -0.0 is +0.0
+    memcpy(&base_bits, &vm0, 4);
+    base_bits = tk_ord(base_bits);
+    const float fill = valid_min > 0.f ? -1.0f : -INFINITY;
     const int shift = tk_shift_of(valid_min, score_max);
     if (!hist_ready)
         hipLaunchKernelGGL(tk_hist_kernel, dim3(256, batch), dim3(256), 0, s, scores, n, valid_min, base_bits, shift, w.hist);
     hipLaunchKernelGGL(tk_collect_kernel, dim3(TK_W, batch), dim3(1024), 0, s, scores, n, k, valid_min, base_bits, shift, w);
-    hipLaunchKernelGGL(tk_finalize_kernel, dim3(batch), dim3(1024), 0, s, n, k, base_bits, w, top_scores, top_idx, counts);
+    hipLaunchKernelGGL(tk_finalize_kernel, dim3(batch), dim3(1024), 0, s, n, k, base_bits, fill, w, top_scores, top_idx, counts);
     return lidar_check_launch("lidar_topk_desc");
 }

@@ -209,7 +209,7 @@ class PointPillarKITTI(nn.Module):
         a = self.num_anchor_per_loc
         n = head.shape[1] * head.shape[2] * a if head.dim() == 4 else head.shape[1] * a
         k = min(self.nms_pre, n)
-        if anchor_post.topk_supported(n, k, self.score_thresh):   # scores + histogram, collect, finalize: 3 launches, ties by ascending anchor index
+        if anchor_post.topk_supported(n, k, self.score_thresh, hist=True):   # scores + histogram, collect, finalize: 3 launches, ties by ascending anchor index
             ws = anchor_post.topk_workspace(head.shape[0], n, head.device)
             try:
                 masked, labels_all = anchor_post.anchor_scores(head, a, self.num_class, self.score_thresh, cls_off=0, topk_ws=ws)

@@ -188,7 +188,11 @@ class PVRCNNKitti(SECONDKitti):
         cls = head[..., :a * nc].reshape(self.B, -1, nc)
         scores_all, labels_all = cls.max(dim=-1)                                   # raw logits: cls_preds_normalized is False
         k = min(self.roi_pre, scores_all.shape[1])
-        top_scores, top_idx = torch.topk(scores_all, k, dim=1)
+        if scores_all.is_cuda and anchor_post.topk_supported(scores_all.shape[1], k):
+            # raw logits, no threshold: the exact device top-k with its signed key (csrc/topk.hip; ties by ascending anchor index)
+            top_scores, top_idx, _ = anchor_post.topk_desc(scores_all.contiguous(), k, float("-inf"), score_max=float(np.finfo(np.float32).max))
+        else:
+            top_scores, top_idx = torch.topk(scores_all, k, dim=1)
         boxes = anchor_post.decode_topk(head, top_idx, self.anchors, a, box_off=a * nc, dir_off=a * (nc + 7),
                                         num_dir_bins=self.num_dir_bins, dir_offset=self.dir_offset,
                                         dir_limit_offset=self.dir_limit_offset)
@@ -286,8 +290,11 @@ class PVRCNNKitti(SECONDKitti):
         scores = torch.sigmoid(rcnn_cls.view(B, R))
         masked = torch.where(scores >= self.score_thresh, scores, scores.new_full((), -1.0))
         k = min(self.nms_pre, R)
-        top, idx = torch.topk(masked, k, dim=1)
-        counts = (top >= self.score_thresh).sum(1).to(torch.int32)
+        if masked.is_cuda and R >= 4096 and anchor_post.topk_supported(R, k, self.score_thresh):     # (100 RoIs per frame: torch.topk)
+            top, idx, counts = anchor_post.topk_desc(masked.contiguous(), k, self.score_thresh)
+        else:
+            top, idx = torch.topk(masked, k, dim=1)
+            counts = (top >= self.score_thresh).sum(1).to(torch.int32)
         cand = torch.gather(boxes, 1, idx.unsqueeze(-1).expand(-1, -1, 7)).contiguous()
         post = min(self.nms_post, k)
         keep, num = iou3d_nms_cuda.nms_batch(cand, counts, self.nms_thresh, max_keep=post)

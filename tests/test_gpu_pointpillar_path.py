@@ -569,6 +569,44 @@ def test_topk_desc_exact_deterministic_with_ties(dev, case):
         assert torch.equal(tt, ts) and torch.equal(it, ti)
 
 
+@pytest.mark.parametrize("case", ["logits_no_threshold", "negative_threshold", "zero_threshold", "all_negative_ties", "with_nan_and_inf"])
+def test_topk_desc_signed_scores(dev, case):
+    """r04: the selection key is an order-preserving map of the float bits, so lidar_topk_desc ranks scores of any sign — the raw class
+    logits PV-RCNN's proposal layer ranks (pcdet/models/roi_heads/roi_head_template.py:45-99: no threshold) — against a stable CPU sort;
+    slots past the count hold (-inf, 0) when the threshold is not positive.  For distinct scores torch.topk agrees."""
+    from lidardetection_amd import anchor_post
+    r = np.random.default_rng(__import__("zlib").crc32(case.encode()) % 1000)
+    B, n, k = 2, 211200, 1024
+    s = r.normal(-4.0, 2.0, (B, n)).astype(np.float32)
+    thr, smax = -np.inf, float(np.finfo(np.float32).max)
+    if case == "negative_threshold":
+        thr, smax = -0.5, 20.0
+    elif case == "zero_threshold":
+        s = r.normal(0.0, 1.0, (B, n)).astype(np.float32)
+        s[:, ::7] = 0.0
+        s[:, 3::11] = -0.0                                                   # -0.0 >= 0.0 is true: a candidate, and it TIES with +0.0
+        thr, smax = 0.0, 10.0
+    elif case == "all_negative_ties":
+        s = (np.round(s * 4) / 4).astype(np.float32)                            # quarter steps: thousands of equal negative scores
+    elif case == "with_nan_and_inf":
+        s[0, 5], s[0, 77], s[1, 9], s[1, 100] = np.nan, np.inf, -np.inf, np.nan
+    td = torch.from_numpy(s).to(dev)
+    ts, ti, cnt = anchor_post.topk_desc(td, k, thr, score_max=smax)
+    for b in range(B):
+        valid = np.nonzero(s[b] >= np.float32(thr))[0]                          # (NaN >= x is False: never a candidate)
+        sv = s[b][valid]
+        order = valid[np.lexsort((valid, -sv.astype(np.float64)))][:k]          # descending value, ties (incl. -0.0 / +0.0) by ascending index
+        assert int(cnt[b]) == len(order), case
+        got_i, got_s = ti[b, :len(order)].cpu().numpy(), ts[b, :len(order)].cpu().numpy()
+        assert np.array_equal(got_s, s[b][order]), case                         # (value equality: a -0.0 comes back as +0.0)
+        assert np.array_equal(got_i, order), case
+        if len(order) < k:
+            assert np.all(np.isneginf(ts[b, len(order):].cpu().numpy())) and not ti[b, len(order):].any()
+    if case == "logits_no_threshold":
+        tt, it = torch.topk(td, k, dim=1)
+        assert torch.equal(tt, ts) and torch.equal(it, ti)
+
+
 def test_nms_batch_max_keep_is_a_prefix_of_the_full_result(dev):
     """max_keep (NMS_POST_MAXSIZE) stops the greedy pass early: the survivors it reports are the first ones of the full run"""
     from lidardetection_amd.ext import iou3d_nms_cuda

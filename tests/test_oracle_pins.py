@@ -183,3 +183,24 @@ def test_sparse_inverse_conv_oracle_equals_dense_transposed_conv_oracle(ksize, s
     got = sp.inverse_conv(feats, oidx, oshape, idx, shape, w, bias, list(ksize), list(stride), list(padding))
     want = so.inverse_conv_features(feats, oidx, B, oshape, w, bias, list(ksize), list(stride), list(padding), idx, shape).numpy()
     np.testing.assert_allclose(got, want, rtol=0, atol=1e-12)
+
+
+def test_spconv_nk_fixture_is_what_the_sparse_oracle_produces():
+    """the sparse-conv FLOP count of the bench (`extra.spconv_gemm.gflop_useful`) is 2 * sum n_k * Cin * Cout with n_k from
+    the ORACLE rulebook of the fixed synthetic batch, committed as tests/golden/spconv_nk_second_kitti_bs16.json.  Regenerates the table
+    (C-oracle voxelisation + sparse fp64 oracle rulebooks, no GPU) and compares it entry by entry; SubM layers must be symmetric
+    (n_k == n_{26-k}) and share their centre count with their row count."""
+    import json
+    import os
+    import sys
+    here = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+    sys.path.insert(0, here)
+    import make_nk_fixture
+    want = json.load(open(os.path.join(here, "spconv_nk_second_kitti_bs16.json")))
+    got = make_nk_fixture.build()
+    assert got["voxels"] == want["voxels"]
+    for a, b in zip(got["layers"], want["layers"]):
+        assert a["layer"] == b["layer"] and a["rows_out"] == b["rows_out"] and a["n_k"] == b["n_k"], a["layer"]
+        if a["kind"] == "subm":
+            assert a["n_k"] == a["n_k"][::-1] and a["n_k"][13] == a["rows_out"]
+    assert abs(got["gflop_useful_total"] - want["gflop_useful_total"]) < 1e-9

@@ -60,6 +60,7 @@ def second_kitti(dev, B=16):
         # implicit-GEMM time of every sparse conv of the stack on its own table (mask order), useful FLOPs = 2 * pairs * Cin * Cout
         x = spconv.SparseConvTensor(feats, coords.int(), m.backbone3d.sparse_shape, B)
         tot_ms, tot_fl = 0.0, 0.0
+        dev_pairs = []
 
         def walk(mod, x):
             nonlocal tot_ms, tot_fl
@@ -75,16 +76,31 @@ def second_kitti(dev, B=16):
                     pk = ops.pack_gemm_weights(w) if st is not None else None       # what forward_fused runs (csrc/sparse_conv.hip pk kernel)
                     t, _ = _events(lambda: ops.indice_conv_fused(f, nbr, w, None, None, True, st, pk), n=5, warm=2)
                     tot_ms += t
-                    tot_fl += 2.0 * float((nbr >= 0).sum()) * c.in_channels * c.out_channels
+                    dev_pairs.append(int((nbr >= 0).sum()))
+                    tot_fl += 2.0 * dev_pairs[-1] * c.in_channels * c.out_channels
                     x = y
                 else:
                     x.features = c(x.features)
             return x
         for name in ("conv_input", "conv1", "conv2", "conv3", "conv4", "conv_out"):
             x = walk(getattr(m.backbone3d, name), x)
+        # the FLOP count is the ORACLE rulebook's (tests/golden/spconv_nk_second_kitti_bs16.json: per-layer n_k of this very
+        # batch from the sparse fp64 oracle); the device tables must agree with it pair for pair
+        fx, match = None, None
+        try:
+            import json, os
+            with open(os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tests", "golden", "spconv_nk_second_kitti_bs16.json")) as fh:
+                fx = json.load(fh)
+            match = (B == 16) and [r["pairs"] for r in fx["layers"]] == dev_pairs
+            if match:
+                tot_fl = fx["gflop_useful_total"] * 1e9
+        except Exception:
+            pass
         tf = tot_fl / (tot_ms * 1e-3) / 1e12
         out["spconv_gemm"] = {"tflops_useful": tf, "frac_of_157.3": tf / FP32_MFMA_PEAK_TFLOPS, "ms": tot_ms,
-                              "gflop_useful": tot_fl / 1e9, "note": "12 implicit GEMMs of VoxelBackBone8x, fp32 MFMA, mask-ordered rows"}
+                              "gflop_useful": tot_fl / 1e9, "pairs_equal_oracle_fixture": match,
+                              "flop_source": "tests/golden/spconv_nk_second_kitti_bs16.json (oracle rulebook n_k)" if match else "device tables",
+                              "note": "12 implicit GEMMs of VoxelBackBone8x, fp32 MFMA, mask-ordered rows"}
     return out
 
 

@@ -13,10 +13,10 @@ orig = ops.indice_conv_fused
 log = []
 
 
-def timed(feats, nbr, w, b, residual=None, relu=False, order=None):
+def timed(feats, nbr, w, b, residual=None, relu=False, order=None, packed=None):
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     torch.cuda.synchronize(); e0.record()
-    out = orig(feats, nbr, w, b, residual, relu, order)
+    out = orig(feats, nbr, w, b, residual, relu, order, packed)
     e1.record(); torch.cuda.synchronize()
     K, cin, cout = w.shape
     log.append((e0.elapsed_time(e1) * 1e3, 2.0 * float((nbr >= 0).sum()) * cin * cout, nbr.shape[0], cin, cout, K))
