@@ -1,8 +1,9 @@
 """bench.py — frames/s of PointPillar-KITTI forward + NMS (BASELINE.json metric) on N MI355X.
 
 Step  = one pass of the hot path over one batch of 16 synthetic KITTI-shaped frames resident in HBM:
-        HIP voxelise -> HIP PillarVFE -> HIP BEV scatter -> stock-torch 2D backbone + head (fp32)
-        -> masked top-k + decode -> HIP batched rotated NMS (device greedy).
+        HIP voxelise -> HIP PillarVFE -> dense 2D backbone + head in fp32 (r04: first layer from the pillars, Winograd 3x3 layers and
+        fused deblocks are this repo's MFMA kernels; two stride-2 layers MIOpen, stride-1 deblock + heads hipBLASLt)
+        -> exact top-k + decode -> HIP batched rotated NMS (device greedy).
 N > 1 = one process per GPU (torch.distributed / RCCL only for the barrier + max-over-ranks
         timing); frames are independent, every rank processes its own batch: replicas, weak scaling,
         no data-path collective.
@@ -464,9 +465,11 @@ def main():
         "metric": "frames/sec (fwd+NMS) PointPillar-KITTI", "value": frames_total / dt, "unit": "frames/s",
         "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": dt / args.steps * 1e3,
         "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-        "config": {"workload": "PointPillar-KITTI bs=16 per GPU: HIP voxelize + PFN + scatter + rotated NMS, "
-                               "stock-torch (MIOpen) fp32 2D backbone/head convolutions, channels_last, BN folded + HIP bias/ReLU epilogue; cloud_uniform 20k pts/frame, 16k pillars/frame "
-                               "(max_voxels cap), NMS pre 4096 / post 500 / thr 0.01",
+        "config": {"workload": "PointPillar-KITTI bs=16 per GPU, fp32, eval BN folded: HIP voxelize + PFN; dense 2D backbone = first layer from the "
+                               "pillars (sparse implicit GEMM), stride-1 3x3 layers as Winograd F(2x2,3x3) on the fp32 MFMA, strided deblocks as one "
+                               "fused MFMA GEMM (all this repo's HIP), the two stride-2 3x3 layers MIOpen, stride-1 deblock + 1x1 heads hipBLASLt; exact "
+                               "HIP top-k + decode + batched rotated NMS; cloud_uniform 20k pts/frame, 16k pillars/frame (max_voxels cap), NMS pre 4096 "
+                               "/ post 500 / thr 0.01",
                    "frames_per_step": args.batch, "replicas": world},
         "roofline": {"bound": "hbm", "kernel": "lidar_voxelize = vxl_keybin_kernel (bin + zero-fill roles in one launch) + vxl_emit_kernel",
                      "achieved": roof["achieved"], "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": roof["frac"], "path": roof["path"],

@@ -398,6 +398,17 @@ int lidar_wino_supported(int Cin, int Cout);
 int lidar_wino_pack_weights(const float *w, int Cin, int Cout, float *packed, void *stream);
 int lidar_wino_conv3x3_nhwc(const float *in, int B, int H, int W, int Cin, const float *packed, const float *bias, int relu, int Cout,
                             float *out, int out_C, int out_off, void *stream);
+/* Grouped form — n_groups independent 3x3 convolutions in one launch: group g reads input channels [g * group_cin, (g + 1) *
+ * group_cin) of the (B, H, W, in_C) map and writes output channels [32 g, 32 g + 32) (fewer real outputs: zero-padded filters) — the
+ * second-layer branch convolutions of AnchorHeadMulti's SEPARATE_MULTIHEAD heads (pcdet/models/dense_heads/anchor_head_multi.py:60-110).
+ * packed = lidar_wino_pack_weights of the stacked (32 n_groups, group_cin, 3, 3) filters; bias: 32 n_groups values or null. */
+int lidar_wino_conv3x3_grouped_nhwc(const float *in, int B, int H, int W, int in_C, int group_cin, int n_groups, const float *packed,
+                                    const float *bias, int relu, float *out, int out_C, int out_off, void *stream);
+/* ... with a COMPACT output: group g keeps its grp_cout[g] (<= 32) real channels at [out_off + grp_ooff[g], + grp_cout[g]) of the
+ * (B, H, W, out_C) map (device int arrays; ranges must fit and not overlap); the padded channels never reach memory. */
+int lidar_wino_conv3x3_grouped_compact_nhwc(const float *in, int B, int H, int W, int in_C, int group_cin, int n_groups,
+                                            const float *packed, const float *bias, int relu, const int *grp_cout, const int *grp_ooff,
+                                            float *out, int out_C, int out_off, void *stream);
 
 /* ConvTranspose2d with kernel == stride == s (the deblocks of BaseBEVBackbone, base_bev_backbone.py:51-57) + folded BatchNorm shift
  * + ReLU + the write into the layer's channel slice of the concatenated map (base_bev_backbone.py:103) as ONE fp32-MFMA kernel

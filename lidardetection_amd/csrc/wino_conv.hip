@@ -91,6 +91,8 @@ struct WinoArgs {
     const float *bias;       // (Cout) or null
     float *out;              // (B, H, W, out_C), this layer's channels at [out_off, out_off + Cout)
     int B, H, W, Cin, Cout, out_C, out_off, relu;
+    const int *grp_cout, *grp_ooff;                  // grouped + compact output: real output channels and first output channel of every group (null: 32 each, at 32 g)
+    int in_C, in_goff;                               // pixel pitch of `in` (floats) and input-channel offset per 32-output-channel block (grouped: its group's first channel; else 0)
     int blocks_y, blocks_x, n_groups, n_blocks;       // grid decomposition (n_blocks = B * blocks_y * blocks_x * n_groups)
 };
 
@@ -160,7 +162,7 @@ __global__ __launch_bounds__(256) void wino_f23_kernel(const WinoArgs a) {
             const int ry = p / RW, rx = p - ry * RW;
             const int gy = R0 + ry, gx = C0 + rx;
             tl.ok[k] = (q < NQ) && (p < RH * RW) && gy >= 0 && gy < H && gx >= 0 && gx < W;
-            tl.src[k] = tl.ok[k] ? a.in + (((size_t)tl.bidx * H + gy) * W + gx) * Cin : (const float *)&g_wino_zero;
+            tl.src[k] = tl.ok[k] ? a.in + (((size_t)tl.bidx * H + gy) * W + gx) * a.in_C + (size_t)tl.nb * a.in_goff : (const float *)&g_wino_zero;
         }
         return tl;
     };
@@ -366,16 +368,39 @@ __global__ __launch_bounds__(256) void wino_f23_kernel(const WinoArgs a) {
                 for (int p = 0; p < 4; ++p) stg[(it * 4 + p) * WINO_STG_PITCH + i] = relu ? fmaxf(yv[p][r], 0.f) : yv[p][r];
             }
             // (only this wave reads its staging tile back: its own LDS operations are ordered, no barrier)
-            float *obase = a.out + (size_t)cur.bidx * H * W * a.out_C + a.out_off + ch0 + 4 * (lo & 7);
             const int tile_y0 = TYW * (MW * cur.by + mw), tile_x0 = TXW * cur.bx;
+            if (a.grp_cout) {
+                // compact grouped output: this block's group keeps only its cg real channels, at channel offset oo of the map
+                // (any alignment: 4-byte stores; the padded channels are never written)
+                const int cg = a.grp_cout[cur.nb], oo = a.grp_ooff[cur.nb];
+                float *ob = a.out + (size_t)cur.bidx * H * W * a.out_C + a.out_off + oo + 4 * (lo & 7);
 #pragma unroll
-            for (int k = 0; k < 16; ++k) {
-                const int pix = k * 8 + (lo >> 3);        // staged pixel: tile pix >> 2, position pix & 3
-                const int it = pix >> 2, py = (pix >> 1) & 1, px = pix & 1;
-                const int oy = 2 * (tile_y0 + (TALL ? (it >> 2) : (it >> 3))) + py, ox = 2 * (tile_x0 + (TALL ? (it & 3) : (it & 7))) + px;
-                const float4 v = *reinterpret_cast<const float4 *>(stg + pix * WINO_STG_PITCH + 4 * (lo & 7));
-                if (oy < H && ox < W) *reinterpret_cast<float4 *>(obase + ((size_t)oy * W + ox) * a.out_C) = v;
-                if ((k & 3) == 3) __builtin_amdgcn_sched_barrier(0);      // four stores in flight at a time: all 16 at once spill
+                for (int k = 0; k < 16; ++k) {
+                    const int pix = k * 8 + (lo >> 3);
+                    const int it = pix >> 2, py = (pix >> 1) & 1, px = pix & 1;
+                    const int oy = 2 * (tile_y0 + (TALL ? (it >> 2) : (it >> 3))) + py, ox = 2 * (tile_x0 + (TALL ? (it & 3) : (it & 7))) + px;
+                    const float4 v = *reinterpret_cast<const float4 *>(stg + pix * WINO_STG_PITCH + 4 * (lo & 7));
+                    if (oy < H && ox < W) {
+                        float *o = ob + ((size_t)oy * W + ox) * a.out_C;
+                        const int c = 4 * (lo & 7);
+                        if (c < cg) o[0] = v.x;
+                        if (c + 1 < cg) o[1] = v.y;
+                        if (c + 2 < cg) o[2] = v.z;
+                        if (c + 3 < cg) o[3] = v.w;
+                    }
+                    if ((k & 3) == 3) __builtin_amdgcn_sched_barrier(0);
+                }
+            } else {
+                float *obase = a.out + (size_t)cur.bidx * H * W * a.out_C + a.out_off + ch0 + 4 * (lo & 7);
+#pragma unroll
+                for (int k = 0; k < 16; ++k) {
+                    const int pix = k * 8 + (lo >> 3);    // staged pixel: tile pix >> 2, position pix & 3
+                    const int it = pix >> 2, py = (pix >> 1) & 1, px = pix & 1;
+                    const int oy = 2 * (tile_y0 + (TALL ? (it >> 2) : (it >> 3))) + py, ox = 2 * (tile_x0 + (TALL ? (it & 3) : (it & 7))) + px;
+                    const float4 v = *reinterpret_cast<const float4 *>(stg + pix * WINO_STG_PITCH + 4 * (lo & 7));
+                    if (oy < H && ox < W) *reinterpret_cast<float4 *>(obase + ((size_t)oy * W + ox) * a.out_C) = v;
+                    if ((k & 3) == 3) __builtin_amdgcn_sched_barrier(0);  // four stores in flight at a time: all 16 at once spill
+                }
             }
         }
 #endif
@@ -454,7 +479,7 @@ __global__ __launch_bounds__(512) void wino_f23x2_kernel(const WinoArgs a) {
             const int ry = p / RW, rx = p - ry * RW;
             const int gy = R0 + ry, gx = C0 + rx;
             tl.ok[k] = (q < NQ) && (p < RH * RW) && gy >= 0 && gy < H && gx >= 0 && gx < W;
-            tl.src[k] = tl.ok[k] ? a.in + (((size_t)tl.bidx * H + gy) * W + gx) * Cin : (const float *)&g_wino_zero;
+            tl.src[k] = tl.ok[k] ? a.in + (((size_t)tl.bidx * H + gy) * W + gx) * a.in_C + (size_t)tl.nb * a.in_goff : (const float *)&g_wino_zero;
         }
         return tl;
     };
@@ -678,16 +703,22 @@ static int wino_cu_count() {
 }
 
 // out[b][y][x][out_off + co] = act(sum_{ky,kx,ci} in[b][y+ky-1][x+kx-1][ci] * w[co][ci][ky][kx] + bias[co])   (zero padding)
-LIDAR_EXPORT int lidar_wino_conv3x3_nhwc(const float *in, int B, int H, int W, int Cin, const float *packed, const float *bias, int relu,
-                                         int Cout, float *out, int out_C, int out_off, void *stream) {
-    if (!in || !packed || !out || B <= 0 || H <= 0 || W <= 0 || !lidar_wino_supported(Cin, Cout) || out_off < 0 || out_off + Cout > out_C)
+// grouped (in_goff > 0): 32-output-channel block nb reads input channels [nb * in_goff, nb * in_goff + Cin) of `in` (pixel pitch in_C)
+static int wino_launch(const float *in, int B, int H, int W, int Cin, int in_C, int in_goff, const float *packed, const float *bias, int relu,
+                       int Cout, float *out, int out_C, int out_off, void *stream, const int *grp_cout = nullptr, const int *grp_ooff = nullptr) {
+    const bool compact = grp_cout != nullptr;
+    if (!in || !packed || !out || B <= 0 || H <= 0 || W <= 0 || !lidar_wino_supported(Cin, Cout) || out_off < 0 ||
+        (!compact && out_off + Cout > out_C) || (compact && (!grp_ooff || in_goff <= 0)))
         return LIDAR_ERR_ARG;
-    if ((reinterpret_cast<uintptr_t>(in) & 15) || (reinterpret_cast<uintptr_t>(packed) & 15)) return LIDAR_ERR_ARG;
-    if ((reinterpret_cast<uintptr_t>(out) & 15) || (out_C & 3) || (out_off & 3)) return LIDAR_ERR_ARG;       // 16-byte output stores
+    if ((reinterpret_cast<uintptr_t>(in) & 15) || (reinterpret_cast<uintptr_t>(packed) & 15) || (in_C & 3) || (in_goff & 3)) return LIDAR_ERR_ARG;
+    if (!compact && ((reinterpret_cast<uintptr_t>(out) & 15) || (out_C & 3) || (out_off & 3))) return LIDAR_ERR_ARG;   // 16-byte output stores
     WinoArgs a;
     a.in = in; a.upk = packed; a.bias = bias; a.out = out;
     a.B = B; a.H = H; a.W = W; a.Cin = Cin; a.Cout = Cout; a.out_C = out_C; a.out_off = out_off; a.relu = relu;
-    const int NW = (Cout % 128 == 0) ? 4 : (Cout % 64 == 0) ? 2 : 1, MW = 4 / NW;
+    a.in_C = in_C; a.in_goff = in_goff; a.grp_cout = grp_cout; a.grp_ooff = grp_ooff;
+    // grouped: every 32-channel block has its own input slice, so the waves of a workgroup (which share ONE region image) must
+    // share the channel block: four tile blocks x one block of 32 output channels
+    const int NW = in_goff > 0 ? 1 : (Cout % 128 == 0) ? 4 : (Cout % 64 == 0) ? 2 : 1, MW = 4 / NW;
     const int tiles_y = (H + 1) / 2, tiles_x = (W + 1) / 2;
     // wave tile 4 x 8 tiles (wide) or 8 x 4 (tall): whichever covers the map with fewer tile blocks (62 x 54: 28 instead of 32)
     const long long wide = (long long)divup(tiles_y, 4 * MW) * divup(tiles_x, 8), tall = (long long)divup(tiles_y, 8 * MW) * divup(tiles_x, 4);
@@ -729,7 +760,8 @@ LIDAR_EXPORT int lidar_wino_conv3x3_nhwc(const float *in, int B, int H, int W, i
     // shapes 0.83 / 0.86 vs 0.82 / 0.84: doubling the occupancy does not recover the 20 % the one-wave kernel loses against its
     // MFMA-only ablation, i.e. that loss is not per-wave latency (which a partner wave would hide) but issue time the SIMD spends on
     // the chunk's vector-memory / LDS instructions whichever wave they belong to.
-    static const bool two_waves = getenv("LIDAR_WINO_X2") && atoi(getenv("LIDAR_WINO_X2")) != 0;
+    static const bool two_waves_env = getenv("LIDAR_WINO_X2") && atoi(getenv("LIDAR_WINO_X2")) != 0;
+    const bool two_waves = two_waves_env && in_goff == 0;
     if (NW == 4 && two_waves) { if (use_tall) WINO2_LAUNCH(4, true); else WINO2_LAUNCH(4, false); }
     else if (NW == 2 && two_waves) { if (use_tall) WINO2_LAUNCH(2, true); else WINO2_LAUNCH(2, false); }
     else if (NW == 4) { if (use_tall) WINO_LAUNCH(4, true); else WINO_LAUNCH(4, false); }
@@ -738,4 +770,29 @@ LIDAR_EXPORT int lidar_wino_conv3x3_nhwc(const float *in, int B, int H, int W, i
 #undef WINO_LAUNCH
 #undef WINO2_LAUNCH
     return lidar_check_launch("lidar_wino_conv3x3_nhwc");
+}
+
+LIDAR_EXPORT int lidar_wino_conv3x3_nhwc(const float *in, int B, int H, int W, int Cin, const float *packed, const float *bias, int relu,
+                                         int Cout, float *out, int out_C, int out_off, void *stream) {
+    return wino_launch(in, B, H, W, Cin, Cin, 0, packed, bias, relu, Cout, out, out_C, out_off, stream);
+}
+
+// Grouped form: n_groups independent 3x3 convolutions, group g: input channels [g * group_cin, (g + 1) * group_cin) of the (B, H, W, in_C)
+// map -> output channels [32 g, 32 g + 32) (a group with fewer than 32 real output channels pads its filters with zeros): the 36
+// second-layer branch convolutions of AnchorHeadMulti's separate heads (pcdet/models/dense_heads/anchor_head_multi.py:60-110) in ONE
+// launch.  packed = lidar_wino_pack_weights of the (32 n_groups, group_cin, 3, 3) stacked filters.
+LIDAR_EXPORT int lidar_wino_conv3x3_grouped_nhwc(const float *in, int B, int H, int W, int in_C, int group_cin, int n_groups, const float *packed,
+                                                 const float *bias, int relu, float *out, int out_C, int out_off, void *stream) {
+    if (n_groups <= 0 || group_cin <= 0 || (long long)group_cin * n_groups > in_C) return LIDAR_ERR_ARG;
+    return wino_launch(in, B, H, W, group_cin, in_C, group_cin, packed, bias, relu, 32 * n_groups, out, out_C, out_off, stream);
+}
+
+// The grouped form with a COMPACT output: group g keeps only its grp_cout[g] (<= 32) real output channels and writes them at channels
+// [out_off + grp_ooff[g], + grp_cout[g]) of the (B, H, W, out_C) map (device int arrays of n_groups entries; the caller guarantees the
+// ranges fit and do not overlap) — the padded channels never reach memory (AnchorHeadMulti: 236 real channels of 36 x 32).
+LIDAR_EXPORT int lidar_wino_conv3x3_grouped_compact_nhwc(const float *in, int B, int H, int W, int in_C, int group_cin, int n_groups,
+                                                         const float *packed, const float *bias, int relu, const int *grp_cout,
+                                                         const int *grp_ooff, float *out, int out_C, int out_off, void *stream) {
+    if (n_groups <= 0 || group_cin <= 0 || (long long)group_cin * n_groups > in_C || !grp_cout || !grp_ooff) return LIDAR_ERR_ARG;
+    return wino_launch(in, B, H, W, group_cin, in_C, group_cin, packed, bias, relu, 32 * n_groups, out, out_C, out_off, stream, grp_cout, grp_ooff);
 }

@@ -185,7 +185,21 @@ class SECONDMultiHeadNuScenes(nn.Module):
                 # both merged 3x3 layers are stride 1 / padding 1: Winograd F(2x2, 3x3) with shift + ReLU in the kernel (csrc/wino_conv.hip)
                 pk = None
                 if _WINO[0] and ws.is_cuda and wino.supported(ws.shape[1], ws.shape[0]) and wino.supported(w1c.shape[1], w1c.shape[0]):
-                    pk = (wino.pack_weights(ws), wino.pack_weights(w1c))
+                    # the 36 second-layer branch convolutions (64 -> 2..12 channels each) as ONE grouped Winograd launch: group g =
+                    # branch g, its filters zero-padded to 32 output channels (36 MIOpen launches + zero-fills + bias adds before)
+                    mid0 = w1c.shape[0] // len(second)
+                    ok2 = all(tuple(c.kernel_size) == (3, 3) and tuple(c.stride) == (1, 1) and tuple(c.padding) == (1, 1)
+                              and c.weight.shape[0] <= 32 and c.weight.shape[1] == mid0 for c in second) and wino.supported(mid0, 32 * len(second))
+                    pk2 = None
+                    if ok2:
+                        w2 = ws.new_zeros((32 * len(second), mid0, 3, 3))
+                        b2 = ws.new_zeros((32 * len(second),))
+                        for g_, c in enumerate(second):
+                            w2[32 * g_:32 * g_ + c.weight.shape[0]] = c.weight.detach()
+                            if c.bias is not None:
+                                b2[32 * g_:32 * g_ + c.weight.shape[0]] = c.bias.detach()
+                        pk2 = [wino.pack_weights(w2), b2, mid0, [c.weight.shape[0] for c in second], None]
+                    pk = (wino.pack_weights(ws), wino.pack_weights(w1c), pk2)
                 cache = (key, cl(ws), bs.contiguous(), cl(w1c), torch.cat(b1, 0).contiguous(), second, pk)
             self.__dict__["_heads_folded"] = cache
         return cache[1:]
@@ -200,7 +214,13 @@ class SECONDMultiHeadNuScenes(nn.Module):
             x = bias_act_(F.conv2d(spatial_2d, ws, None, padding=1), bs, True)
             y = bias_act_(F.conv2d(x, w1, None, padding=1), b1, True)
         mid = w1.shape[0] // len(second)
-        z = [conv(y[:, g * mid:(g + 1) * mid]) for g, conv in enumerate(second)]
+        if pk is not None and pk[2] is not None and _WINO[0] and y.is_contiguous(memory_format=torch.channels_last):
+            p2, b2, mid0, couts, tables = pk[2]
+            z_all, pk[2][4] = wino.conv3x3_grouped_compact(y, p2, mid0, couts, b2, False, tables)     # (B, 236, H, W): real channels only
+            offs = np.concatenate([[0], np.cumsum(couts)])
+            z = [z_all[:, int(offs[g]):int(offs[g + 1])] for g in range(len(second))]
+        else:
+            z = [conv(y[:, g * mid:(g + 1) * mid]) for g, conv in enumerate(second)]
         B, _, H, W = y.shape
         out, g = [], 0
         for head in self.rpn_heads:

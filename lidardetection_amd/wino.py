@@ -43,3 +43,54 @@ def conv3x3(x, packed, cout, bias=None, relu=True, out=None, out_offset=0):
     _lib.check(L.lidar_wino_conv3x3_nhwc(_lib.ptr(x), B, H, W, cin, _lib.ptr(packed), _lib.ptr(bias), int(bool(relu)), int(cout),
                                          _lib.ptr(out), out.shape[1], int(out_offset), _lib.stream()), "lidar_wino_conv3x3_nhwc")
     return out
+
+
+def conv3x3_grouped_compact(x, packed, group_cin, couts, bias=None, relu=False, tables=None):
+    """conv3x3_grouped with only the REAL output channels written: -> (B, sum(couts), H, W) channels-last, group g at channels
+    [sum(couts[:g]), + couts[g]).  tables = (grp_cout, grp_ooff) device int32 tensors from a previous call (returned as second value)."""
+    _lib.require_cuda(packed, bias)
+    if not (x.is_cuda and x.dim() == 4 and x.dtype == torch.float32 and x.is_contiguous(memory_format=torch.channels_last)):
+        raise _lib.LidarHipError("wino.conv3x3_grouped_compact: expected a channels-last float32 CUDA tensor")
+    B, C, H, W = x.shape
+    n = len(couts)
+    L = _lib.lib()
+    if n * group_cin > C or packed.numel() != L.lidar_wino_packed_floats(group_cin, 32 * n) or packed.numel() == 0 or max(couts) > 32 or min(couts) < 1:
+        raise _lib.LidarHipError("wino.conv3x3_grouped_compact: groups / packed filters do not match the input")
+    if bias is not None and bias.numel() != 32 * n:
+        raise _lib.LidarHipError("wino.conv3x3_grouped_compact: bias must hold 32 * n_groups values (padded like the filters)")
+    if tables is None:
+        offs = [0]
+        for c in couts[:-1]:
+            offs.append(offs[-1] + int(c))
+        tables = (torch.tensor([int(c) for c in couts], dtype=torch.int32, device=x.device), torch.tensor(offs, dtype=torch.int32, device=x.device))
+    ctot = int(sum(couts))
+    out = torch.empty((B, ctot, H, W), dtype=torch.float32, device=x.device, memory_format=torch.channels_last)
+    _lib.check(L.lidar_wino_conv3x3_grouped_compact_nhwc(_lib.ptr(x), B, H, W, C, int(group_cin), n, _lib.ptr(packed), _lib.ptr(bias),
+                                                         int(bool(relu)), _lib.ptr(tables[0]), _lib.ptr(tables[1]), _lib.ptr(out), ctot, 0,
+                                                         _lib.stream()), "lidar_wino_conv3x3_grouped_compact_nhwc")
+    return out, tables
+
+
+def conv3x3_grouped(x, packed, group_cin, n_groups, bias=None, relu=False, out=None, out_offset=0):
+    """n_groups independent 3x3 / padding-1 convolutions in one launch: group g reads channels [g * group_cin, (g + 1) * group_cin) of the
+    channels-last x (B, C >= n_groups * group_cin, H, W) and writes channels [32 g, 32 g + 32) of the result (B, 32 n_groups, H, W).
+    packed = pack_weights of the stacked (32 n_groups, group_cin, 3, 3) filters (groups with fewer outputs: zero rows)."""
+    _lib.require_cuda(packed, bias)
+    if not (x.is_cuda and x.dim() == 4 and x.dtype == torch.float32 and x.is_contiguous(memory_format=torch.channels_last)):
+        raise _lib.LidarHipError("wino.conv3x3_grouped: expected a channels-last float32 CUDA tensor")
+    B, C, H, W = x.shape
+    cout = 32 * int(n_groups)
+    L = _lib.lib()
+    if n_groups * group_cin > C or packed.numel() != L.lidar_wino_packed_floats(group_cin, cout) or packed.numel() == 0:
+        raise _lib.LidarHipError("wino.conv3x3_grouped: groups / packed filters do not match the input")
+    if bias is not None and bias.numel() != cout:
+        raise _lib.LidarHipError("wino.conv3x3_grouped: bias must hold 32 * n_groups values")
+    if out is None:
+        out, out_offset = torch.empty((B, cout, H, W), dtype=torch.float32, device=x.device, memory_format=torch.channels_last), 0
+    elif not (out.is_cuda and out.dtype == torch.float32 and out.is_contiguous(memory_format=torch.channels_last)
+              and out.shape[0] == B and tuple(out.shape[2:]) == (H, W) and 0 <= out_offset and out_offset + cout <= out.shape[1]):
+        raise _lib.LidarHipError("wino.conv3x3_grouped: output must be channels-last (B, C_out, H, W) with room for the slice")
+    _lib.check(L.lidar_wino_conv3x3_grouped_nhwc(_lib.ptr(x), B, H, W, C, int(group_cin), int(n_groups), _lib.ptr(packed), _lib.ptr(bias),
+                                                 int(bool(relu)), _lib.ptr(out), out.shape[1], int(out_offset), _lib.stream()),
+               "lidar_wino_conv3x3_grouped_nhwc")
+    return out

@@ -113,3 +113,49 @@ print('x2 ok')
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     r = subprocess.run([sys.executable, "-c", code], env=dict(os.environ, LIDAR_WINO_X2="1", PYTHONPATH=root), capture_output=True, text=True, timeout=300)
     assert r.returncode == 0 and "x2 ok" in r.stdout, r.stderr[-800:]
+
+
+def test_wino_grouped_conv_vs_float64(dev):
+    """lidar_wino_conv3x3_grouped_nhwc: n independent 3x3 convolutions in one launch, group g reading its own 64-channel slice of the
+    input and writing output channels [32 g, 32 g + 32) (AnchorHeadMulti's second-layer branch convolutions, pcdet/models/dense_heads/
+    anchor_head_multi.py:60-110: 2..12 real output channels per branch, filters zero-padded to 32) against per-branch float64 convolutions."""
+    g = torch.Generator(device="cpu").manual_seed(21)
+    B, H, W, cin, couts = 2, 18, 26, 64, [4, 12, 2, 6, 32, 10, 8]
+    n = len(couts)
+    x = torch.randn(B, n * cin + 8, H, W, generator=g)                          # a wider map: 8 trailing channels nobody reads
+    ws = [torch.randn(c, cin, 3, 3, generator=g) / 24.0 for c in couts]
+    bs = [torch.randn(c, generator=g) for c in couts]
+    w_all, b_all = torch.zeros(32 * n, cin, 3, 3), torch.zeros(32 * n)
+    for k, (w, b) in enumerate(zip(ws, bs)):
+        w_all[32 * k:32 * k + w.shape[0]], b_all[32 * k:32 * k + w.shape[0]] = w, b
+    xd = x.to(dev).contiguous(memory_format=torch.channels_last)
+    out = wino.conv3x3_grouped(xd, wino.pack_weights(w_all.to(dev)), cin, n, b_all.to(dev), False)
+    assert out.shape == (B, 32 * n, H, W) and out.is_contiguous(memory_format=torch.channels_last)
+    for k, (w, b) in enumerate(zip(ws, bs)):
+        want = F.conv2d(x[:, k * cin:(k + 1) * cin].double(), w.double(), b.double(), 1, 1)
+        got = out[:, 32 * k:32 * k + w.shape[0]].double().cpu()
+        assert float((got - want).abs().max()) <= 1e-4 * max(1.0, float(want.abs().max())), k
+        assert not out[:, 32 * k + w.shape[0]:32 * (k + 1)].any()                 # padded output channels: zero filters, zero bias
+    with pytest.raises(_lib.LidarHipError):
+        wino.conv3x3_grouped(xd, wino.pack_weights(w_all.to(dev)), cin, n + 1)   # more groups than the input holds
+
+
+def test_wino_grouped_compact_output(dev):
+    """the compact form writes only each group's real channels, back to back: equal to slicing the padded result"""
+    g = torch.Generator(device="cpu").manual_seed(22)
+    B, H, W, cin, couts = 1, 10, 14, 64, [2, 4, 2, 6, 4, 4, 8, 8, 4, 12, 8, 8, 5]
+    n = len(couts)
+    x = torch.randn(B, n * cin, H, W, generator=g).to(dev).contiguous(memory_format=torch.channels_last)
+    w_all, b_all = torch.zeros(32 * n, cin, 3, 3), torch.zeros(32 * n)
+    for k, c in enumerate(couts):
+        w_all[32 * k:32 * k + c] = torch.randn(c, cin, 3, 3, generator=g) / 24.0
+        b_all[32 * k:32 * k + c] = torch.randn(c, generator=g)
+    packed = wino.pack_weights(w_all.to(dev))
+    padded = wino.conv3x3_grouped(x, packed, cin, n, b_all.to(dev), True)
+    out, tables = wino.conv3x3_grouped_compact(x, packed, cin, couts, b_all.to(dev), True)
+    out2, _ = wino.conv3x3_grouped_compact(x, packed, cin, couts, b_all.to(dev), True, tables)
+    assert out.shape == (B, sum(couts), H, W) and torch.equal(out, out2)
+    off = 0
+    for k, c in enumerate(couts):
+        assert torch.equal(out[:, off:off + c], padded[:, 32 * k:32 * k + c]), k
+        off += c
