@@ -219,12 +219,12 @@ LIDAR_EXPORT int lidar_deconv_pack_weights(const float *W, int K, int N, float *
 }
 
 static int dc_cu_count() {
-    static int cus = 0;
-    if (cus == 0) {
-        int dev = 0, n = 0;
-        cus = (hipGetDevice(&dev) == hipSuccess && hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && n > 0) ? n : 256;
-    }
-    return cus;
+    static int cus[64] = {};
+    int dev = 0, n = 0;
+    if (hipGetDevice(&dev) != hipSuccess) return 256;
+    dev &= 63;
+    if (cus[dev] == 0) cus[dev] = (hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && n > 0) ? n : 256;
+    return cus[dev];
 }
 
 // out[b][s y + ky][s x + kx][out_off + c] = act(sum_k in[b][y][x][k] W[k][(ky, kx, c)] + bias[c])
@@ -246,10 +246,13 @@ LIDAR_EXPORT int lidar_deconv_gemm_nhwc(const float *in, int B, int h, int w, in
     long long want = ((nblk + 7) / 8) * 8;
     const long long cap = ((long long)dc_cu_count() / 8) * 8;
     if (cap >= 8 && want > cap) want = cap;
-    static bool attr_set = false;
-    if (!attr_set) {
+    static bool attr_set[64] = {};                        // the LDS opt-in is a per-device function attribute
+    int dev_id = 0;
+    (void)hipGetDevice(&dev_id);
+    dev_id &= 63;
+    if (!attr_set[dev_id]) {
         (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&dc_gemm_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)dc_lds_bytes());
-        attr_set = true;
+        attr_set[dev_id] = true;
     }
     hipLaunchKernelGGL(dc_gemm_kernel, dim3((unsigned)want), dim3(256), dc_lds_bytes(), (hipStream_t)stream, a);
     return lidar_check_launch("lidar_deconv_gemm_nhwc");

@@ -254,12 +254,13 @@ struct NmsWaveLds {
 template <bool NORMAL>
 __global__ __launch_bounds__(256) void nms_mask_kernel(const float *__restrict__ boxes_all, const BoxPre *__restrict__ pre_all,
                                                        const int *__restrict__ counts, int n_max, float thresh,
-                                                       unsigned long long *__restrict__ mask_all) {
+                                                       unsigned long long *__restrict__ mask_all, int n_lim, const int *__restrict__ gate) {
     __shared__ BoxPre s_pre[64];       // column boxes (rotated)   | NORMAL: raw boxes in the same bytes
     __shared__ NmsWaveLds s_w[4];
     const int wv = threadIdx.x >> 6, l = threadIdx.x & 63;
     const int rb = blockIdx.y * 4 + wv, cbk = blockIdx.x, f = blockIdx.z;
-    const int n = counts ? min(counts[f], n_max) : n_max;
+    if (gate && gate[f] == 0) return;                          // second stage of a limited call: only frames that still need boxes
+    const int n = min(counts ? min(counts[f], n_max) : n_max, n_lim);
     const int cb_total = (n_max + 63) / 64;
     const float *boxes = boxes_all + (size_t)f * n_max * 7;
     const BoxPre *pre = pre_all + (size_t)f * n_max;
@@ -433,11 +434,14 @@ __global__ __launch_bounds__(GREEDY_TPB) void nms_greedy_kernel(const unsigned l
 __global__ __launch_bounds__(GF_TPB) void nms_greedy_fast_kernel(const unsigned long long *__restrict__ mask_all,
                                                                  const int *__restrict__ counts, int n_max, int max_keep,
                                                                  long long *__restrict__ keep_all,
-                                                                 int *__restrict__ num_keep) {
+                                                                 int *__restrict__ num_keep, int n_lim, const int *__restrict__ gate,
+                                                                 int *__restrict__ need_more) {
     __shared__ unsigned long long s_tile[2][64][64];
     __shared__ int s_stop;
     const int f = blockIdx.x;
-    const int n = counts ? min(counts[f], n_max) : n_max;
+    if (gate && gate[f] == 0) return;
+    const int n_all = counts ? min(counts[f], n_max) : n_max;
+    const int n = min(n_all, n_lim);
     const int cb_total = (n_max + 63) / 64;   // <= 64
     const int cb = (n + 63) / 64;
     const unsigned long long *mask = mask_all + (size_t)f * n_max * cb_total;
@@ -515,7 +519,12 @@ __global__ __launch_bounds__(GF_TPB) void nms_greedy_fast_kernel(const unsigned 
             __syncthreads();
         }
     }
-    if (t == 0) num_keep[f] = min(nkeep, max_keep);
+    if (t == 0) {
+        num_keep[f] = min(nkeep, max_keep);
+        // first stage of a limited call: the greedy order is a prefix property, so max_keep survivors among the first n_lim boxes ARE
+        // the answer; a frame that ran out of boxes first asks for the full pass
+        if (need_more) need_more[f] = (nkeep < max_keep && n_all > n_lim) ? 1 : 0;
+    }
 }
 
 // ------------------------------------------------------------------ C ABI
@@ -543,7 +552,8 @@ LIDAR_EXPORT int lidar_boxes_pairwise_bev(const float *boxes_a, int n_a, const f
 LIDAR_EXPORT size_t lidar_nms_workspace_bytes(int batch, int n_max) {
     if (batch <= 0 || n_max <= 0) return 256;
     const size_t cb = (size_t)(n_max + 63) / 64;
-    return align_up((size_t)batch * n_max * sizeof(BoxPre), 256) + align_up((size_t)batch * n_max * cb * 8, 256);
+    return align_up((size_t)batch * n_max * sizeof(BoxPre), 256) + align_up((size_t)batch * n_max * cb * 8, 256) +
+           align_up((size_t)batch * sizeof(int), 256);          // + the limited call's per-frame "needs the full pass" flags
 }
 
 // Batched NMS on already score-sorted boxes.  boxes (batch, n_max, 7); counts (batch) device ints or
@@ -563,15 +573,34 @@ LIDAR_EXPORT int lidar_nms_batch_limited(const float *boxes, const int *counts, 
     if (!normal)
         hipLaunchKernelGGL(iou_prep_kernel, dim3(divup((long long)batch * n_max, 256)), dim3(256), 0, s, boxes,
                            batch * n_max, pre);
-    const dim3 grid(cb, divup(cb, 4), batch);
+    // Speculative two-stage form when the caller wants only the first max_keep survivors (NMS_POST_MAXSIZE, model_nms_utils.py:19-21):
+    // stage 1 builds the mask of, and runs the greedy pass over, the first n1 candidates only — max_keep survivors among them are the
+    // exact answer (greedy NMS is a prefix property); a frame that ran out of candidates first raises its flag and stage 2 — the full
+    // mask + greedy, whose workgroups exit at once for every other frame — redoes exactly that frame.  n1 = 2 max_keep rounded up to
+    // 256 (bench frames, tools/nms_keep_pos.py: the 500th survivor is candidate 589-633 of 4 096, so the mask shrinks 16 x; a
+    // trained model's frames hold fewer candidates than n1 after the score threshold and never reach the second stage either).
+    const int n1 = (cb <= 64 && max_keep < n_max) ? ((2 * max_keep + 255) / 256) * 256 : n_max;
+    const bool two_stage = n1 < n_max;
+    int *need_more = two_stage ? (int *)((char *)mask + align_up((size_t)batch * n_max * cb * sizeof(unsigned long long), 256)) : nullptr;
+    const int cb1 = two_stage ? (n1 + 63) / 64 : cb;
+    const dim3 grid1(cb1, divup(cb1, 4), batch), grid(cb, divup(cb, 4), batch);
     if (normal)
-        hipLaunchKernelGGL(nms_mask_kernel<true>, grid, dim3(256), 0, s, boxes, pre, counts, n_max, thresh, mask);
+        hipLaunchKernelGGL(nms_mask_kernel<true>, grid1, dim3(256), 0, s, boxes, pre, counts, n_max, thresh, mask, two_stage ? n1 : n_max, (const int *)nullptr);
     else
-        hipLaunchKernelGGL(nms_mask_kernel<false>, grid, dim3(256), 0, s, boxes, pre, counts, n_max, thresh, mask);
+        hipLaunchKernelGGL(nms_mask_kernel<false>, grid1, dim3(256), 0, s, boxes, pre, counts, n_max, thresh, mask, two_stage ? n1 : n_max, (const int *)nullptr);
     if (cb <= 64)
-        hipLaunchKernelGGL(nms_greedy_fast_kernel, dim3(batch), dim3(GF_TPB), 0, s, mask, counts, n_max, max_keep, keep, num_keep);
+        hipLaunchKernelGGL(nms_greedy_fast_kernel, dim3(batch), dim3(GF_TPB), 0, s, mask, counts, n_max, max_keep, keep, num_keep,
+                           two_stage ? n1 : n_max, (const int *)nullptr, need_more);
     else
         hipLaunchKernelGGL(nms_greedy_kernel, dim3(batch), dim3(GREEDY_TPB), 0, s, mask, counts, n_max, max_keep, keep, num_keep);
+    if (two_stage) {
+        if (normal)
+            hipLaunchKernelGGL(nms_mask_kernel<true>, grid, dim3(256), 0, s, boxes, pre, counts, n_max, thresh, mask, n_max, (const int *)need_more);
+        else
+            hipLaunchKernelGGL(nms_mask_kernel<false>, grid, dim3(256), 0, s, boxes, pre, counts, n_max, thresh, mask, n_max, (const int *)need_more);
+        hipLaunchKernelGGL(nms_greedy_fast_kernel, dim3(batch), dim3(GF_TPB), 0, s, mask, counts, n_max, max_keep, keep, num_keep, n_max,
+                           (const int *)need_more, (int *)nullptr);
+    }
     return lidar_check_launch("lidar_nms_batch");
 }
 

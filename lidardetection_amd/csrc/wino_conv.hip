@@ -693,13 +693,12 @@ LIDAR_EXPORT int lidar_wino_pack_weights(const float *w, int Cin, int Cout, floa
 }
 
 static int wino_cu_count() {
-    static int cus = 0;
-    if (cus == 0) {
-        int dev = 0, n = 0;
-        if (hipGetDevice(&dev) == hipSuccess && hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && n > 0) cus = n;
-        else cus = 256;
-    }
-    return cus;
+    static int cus[64] = {};
+    int dev = 0, n = 0;
+    if (hipGetDevice(&dev) != hipSuccess) return 256;
+    dev &= 63;
+    if (cus[dev] == 0) cus[dev] = (hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && n > 0) ? n : 256;
+    return cus[dev];
 }
 
 // out[b][y][x][out_off + co] = act(sum_{ky,kx,ci} in[b][y+ky-1][x+kx-1][ci] * w[co][ci][ky][kx] + bias[co])   (zero padding)
@@ -737,21 +736,24 @@ static int wino_launch(const float *in, int B, int H, int W, int Cin, int in_C, 
 #endif
     const dim3 grid((unsigned)want), blk(256);
     hipStream_t s = (hipStream_t)stream;
+    int dev_id = 0;                                       // the LDS opt-in is a per-device function attribute: one flag per device
+    (void)hipGetDevice(&dev_id);
+    dev_id &= 63;
 #define WINO_LAUNCH(NWV, TALLV) do {                                                                                               \
-        static bool attr_set = false;                                                                                             \
-        if (!attr_set) {                                                                                                          \
+        static bool attr_set[64] = {};                                                                                            \
+        if (!attr_set[dev_id]) {                                                                                                  \
             (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&wino_f23_kernel<NWV, TALLV>), hipFuncAttributeMaxDynamicSharedMemorySize, \
                                       (int)wino_lds_bytes(NWV, TALLV));                                                            \
-            attr_set = true;                                                                                                      \
+            attr_set[dev_id] = true;                                                                                              \
         }                                                                                                                         \
         hipLaunchKernelGGL((wino_f23_kernel<NWV, TALLV>), grid, blk, wino_lds_bytes(NWV, TALLV), s, a);                           \
     } while (0)
 #define WINO2_LAUNCH(NWV, TALLV) do {                                                                                              \
-        static bool attr_set2 = false;                                                                                            \
-        if (!attr_set2) {                                                                                                         \
+        static bool attr_set2[64] = {};                                                                                           \
+        if (!attr_set2[dev_id]) {                                                                                                 \
             (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&wino_f23x2_kernel<NWV, TALLV>), hipFuncAttributeMaxDynamicSharedMemorySize, \
                                       (int)wino2_lds_bytes(NWV, TALLV));                                                           \
-            attr_set2 = true;                                                                                                     \
+            attr_set2[dev_id] = true;                                                                                             \
         }                                                                                                                         \
         hipLaunchKernelGGL((wino_f23x2_kernel<NWV, TALLV>), grid, dim3(512), wino2_lds_bytes(NWV, TALLV), s, a);                  \
     } while (0)

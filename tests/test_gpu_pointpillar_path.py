@@ -625,6 +625,44 @@ def test_nms_batch_max_keep_is_a_prefix_of_the_full_result(dev):
             assert torch.equal(keep[f, :int(want[f])], full_keep[f, :int(want[f])])
 
 
+def test_nms_batch_limited_second_stage_frames(dev):
+    """The limited call builds the mask of the first 2 max_keep candidates only and redoes, in full, just the frames that ran out of
+    survivors there (csrc/iou3d.hip lidar_nms_batch_limited).  Frame 0: 60 tight clusters -> far fewer than max_keep survivors, the
+    second stage must supply the complete answer; frame 1: spread boxes -> finished by the first stage; frame 2: clusters in the
+    first 1 500 candidates, spread boxes after them -> the survivors straddle the first-stage limit."""
+    from lidardetection_amd.ext import iou3d_nms_cuda
+    r = np.random.default_rng(77)
+    n = 4096
+
+    def clustered(m, k):
+        c = r.uniform(-60, 60, (k, 2)).astype(np.float32)
+        idx = r.integers(0, k, m)
+        b = np.zeros((m, 7), np.float32)
+        b[:, :2] = c[idx] + r.normal(0, 0.05, (m, 2)).astype(np.float32)
+        b[:, 3:6] = (3.9, 1.6, 1.5)
+        b[:, 6] = r.uniform(-0.1, 0.1, m)
+        return b
+
+    def spread(m):
+        b = np.zeros((m, 7), np.float32)
+        b[:, :2] = r.uniform(-200, 200, (m, 2))
+        b[:, 3:6] = (3.9, 1.6, 1.5)
+        b[:, 6] = r.uniform(-3.1, 3.1, m)
+        return b
+
+    frames = [clustered(n, 60), spread(n), np.concatenate([clustered(1500, 40), spread(n - 1500)])]
+    boxes = torch.from_numpy(np.stack(frames)).to(dev)
+    counts = torch.tensor([n, n, 3900], dtype=torch.int32, device=dev)
+    full_keep, full_num = iou3d_nms_cuda.nms_batch(boxes, counts, 0.1)
+    assert int(full_num[0]) < 100 and int(full_num[1]) > 2000
+    for mk in (100, 300, 500):
+        keep, num = iou3d_nms_cuda.nms_batch(boxes, counts, 0.1, max_keep=mk)
+        want = torch.clamp(full_num, max=mk)
+        assert torch.equal(num, want), (mk, num, want)
+        for f in range(3):
+            assert torch.equal(keep[f, :int(want[f])], full_keep[f, :int(want[f])]), (mk, f)
+
+
 def test_bev_backbone_and_box_decode_vs_reference_golden(dev, golden_dir):
     """tests/golden/bev_head.npz was emitted by the REFERENCE's own BaseBEVBackbone and ResidualCoder.decode_torch
     (tests/golden/make_golden.py).  The folded backbone (BN folded, HIP epilogues, GEMM deblocks writing the concat slice) must
