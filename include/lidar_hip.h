@@ -410,6 +410,17 @@ int lidar_wino_conv3x3_grouped_compact_nhwc(const float *in, int B, int H, int W
                                             const float *packed, const float *bias, int relu, const int *grp_cout, const int *grp_ooff,
                                             float *out, int out_C, int out_off, void *stream);
 
+/* The same stride-1 3x3 layers as Winograd F(4x4, 3x3) (csrc/wino43_conv.hip): 4x fewer MFMA cycles than the direct form (F(2x2):
+ * 2.25x), interpolation points {0, 1, -1, 1/2, -2, inf}, filter transform in fp64; |error| ~ 1e-5 of the output scale (asserted at
+ * 1e-4 against the fp64 convolution).  Supported: Cin % 8 == 0, Cout % 64 == 0 (lidar_wino43_packed_floats = 36 Cin Cout, 0 =
+ * unsupported).  `in` is (B, H, W, in_C) and the layer reads channels [0, Cin); B * H * W * in_C < 2^31.  Replaces the same reference
+ * layers as lidar_wino_conv3x3_nhwc (pcdet/models/backbones_2d/base_bev_backbone.py:34-45). */
+size_t lidar_wino43_packed_floats(int Cin, int Cout);
+int lidar_wino43_supported(int Cin, int Cout);
+int lidar_wino43_pack_weights(const float *w, int Cin, int Cout, float *packed, void *stream);
+int lidar_wino43_conv3x3_nhwc(const float *in, int B, int H, int W, int Cin, int in_C, const float *packed, const float *bias, int relu,
+                              int Cout, float *out, int out_C, int out_off, void *stream);
+
 /* ConvTranspose2d with kernel == stride == s (the deblocks of BaseBEVBackbone, base_bev_backbone.py:51-57) + folded BatchNorm shift
  * + ReLU + the write into the layer's channel slice of the concatenated map (base_bev_backbone.py:103) as ONE fp32-MFMA kernel
  * (csrc/deconv_gemm.hip): out[b][s y + ky][s x + kx][out_off + c] = act(sum_k in[b][y][x][k] W[k][(ky, kx, c)] + bias[c]).

@@ -104,6 +104,10 @@ SIGNATURES = {
     "lidar_wino_supported": (i32, [i32, i32]),
     "lidar_wino_pack_weights": (i32, [vp, i32, i32, vp, vp]),
     "lidar_wino_conv3x3_nhwc": (i32, [vp, i32, i32, i32, i32, vp, vp, i32, i32, vp, i32, i32, vp]),
+    "lidar_wino43_packed_floats": (sz, [i32, i32]),
+    "lidar_wino43_supported": (i32, [i32, i32]),
+    "lidar_wino43_pack_weights": (i32, [vp, i32, i32, vp, vp]),
+    "lidar_wino43_conv3x3_nhwc": (i32, [vp, i32, i32, i32, i32, i32, vp, vp, i32, i32, vp, i32, i32, vp]),
     "lidar_wino_conv3x3_grouped_nhwc": (i32, [vp, i32, i32, i32, i32, i32, i32, vp, vp, i32, vp, i32, i32, vp]),
     "lidar_wino_conv3x3_grouped_compact_nhwc": (i32, [vp, i32, i32, i32, i32, i32, i32, vp, vp, i32, vp, vp, vp, i32, i32, vp]),
     "lidar_deconv_packed_floats": (sz, [i32, i32]),

@@ -45,6 +45,47 @@ def conv3x3(x, packed, cout, bias=None, relu=True, out=None, out_offset=0):
     return out
 
 
+def supported43(cin, cout):
+    """the F(4x4, 3x3) kernel (csrc/wino43_conv.hip) takes this layer: Cin % 8 == 0, Cout % 64 == 0"""
+    return bool(_lib.lib().lidar_wino43_supported(int(cin), int(cout)))
+
+
+def pack_weights43(w):
+    """w (Cout, Cin, 3, 3) fp32 -> the packed F(4x4, 3x3) filters (36 Cin Cout floats; the filter transform runs in fp64)"""
+    _lib.require_cuda(w.contiguous())
+    if w.dim() != 4 or tuple(w.shape[2:]) != (3, 3) or w.dtype != torch.float32 or not supported43(w.shape[1], w.shape[0]):
+        raise _lib.LidarHipError(f"wino.pack_weights43: expected a float32 (Cout % 64 == 0, Cin % 8 == 0, 3, 3) weight, got {tuple(w.shape)}")
+    wc = w.detach().contiguous()
+    if wc.stride() != (wc.shape[1] * 9, 9, 3, 1):
+        wc = wc.clone(memory_format=torch.contiguous_format)
+    L = _lib.lib()
+    packed = torch.empty(L.lidar_wino43_packed_floats(w.shape[1], w.shape[0]), dtype=torch.float32, device=w.device)
+    _lib.check(L.lidar_wino43_pack_weights(_lib.ptr(wc), w.shape[1], w.shape[0], _lib.ptr(packed), _lib.stream()), "lidar_wino43_pack_weights")
+    return packed
+
+
+def conv3x3_f43(x, packed, cout, bias=None, relu=True, out=None, out_offset=0, cin=None):
+    """conv3x3 through the F(4x4, 3x3) kernel.  cin: the layer reads channels [0, cin) of x (default: all of them)."""
+    _lib.require_cuda(packed, bias)
+    if not (x.is_cuda and x.dim() == 4 and x.dtype == torch.float32 and x.is_contiguous(memory_format=torch.channels_last)):
+        raise _lib.LidarHipError("wino.conv3x3_f43: expected a channels-last float32 CUDA tensor")
+    B, in_c, H, W = x.shape
+    cin = in_c if cin is None else int(cin)
+    L = _lib.lib()
+    if cin > in_c or packed.numel() != L.lidar_wino43_packed_floats(cin, cout) or packed.numel() == 0:
+        raise _lib.LidarHipError("wino.conv3x3_f43: packed filters do not match (Cin, Cout)")
+    if bias is not None and bias.numel() != cout:
+        raise _lib.LidarHipError("wino.conv3x3_f43: bias must hold Cout values")
+    if out is None:
+        out, out_offset = torch.empty((B, cout, H, W), dtype=torch.float32, device=x.device, memory_format=torch.channels_last), 0
+    elif not (out.is_cuda and out.dtype == torch.float32 and out.is_contiguous(memory_format=torch.channels_last)
+              and out.shape[0] == B and tuple(out.shape[2:]) == (H, W) and 0 <= out_offset and out_offset + cout <= out.shape[1]):
+        raise _lib.LidarHipError("wino.conv3x3_f43: output must be channels-last (B, C_out, H, W) with room for the slice")
+    _lib.check(L.lidar_wino43_conv3x3_nhwc(_lib.ptr(x), B, H, W, cin, in_c, _lib.ptr(packed), _lib.ptr(bias), int(bool(relu)), int(cout),
+                                           _lib.ptr(out), out.shape[1], int(out_offset), _lib.stream()), "lidar_wino43_conv3x3_nhwc")
+    return out
+
+
 def conv3x3_grouped_compact(x, packed, group_cin, couts, bias=None, relu=False, tables=None):
     """conv3x3_grouped with only the REAL output channels written: -> (B, sum(couts), H, W) channels-last, group g at channels
     [sum(couts[:g]), + couts[g]).  tables = (grp_cout, grp_ooff) device int32 tensors from a previous call (returned as second value)."""

@@ -159,3 +159,73 @@ def test_wino_grouped_compact_output(dev):
     for k, c in enumerate(couts):
         assert torch.equal(out[:, off:off + c], padded[:, 32 * k:32 * k + c]), k
         off += c
+
+
+# ------------------------------------------------------------------ F(4x4, 3x3): csrc/wino43_conv.hip
+@pytest.mark.parametrize("B,cin,cout,H,W", [
+    (1, 8, 64, 16, 16),        # one tile group pair, two chunks
+    (2, 64, 64, 20, 36),       # partial groups in both directions
+    (1, 64, 64, 32, 16),       # exactly one workgroup of 4 x 4-tile groups
+    (3, 128, 128, 14, 22),     # two channel groups
+    (2, 256, 256, 9, 11),      # four channel groups, odd sizes (bounds inside the last tile row / column)
+    (2, 64, 128, 6, 40),       # 2 x 8-tile groups are chosen
+    (1, 128, 64, 33, 17),
+    (1, 64, 128, 62, 54),      # 8 x 2-tile groups (PointPillar block 3 geometry)
+    (1, 16, 64, 70, 7),
+    (1, 64, 64, 124, 108),     # several blocks per workgroup on one XCD share (persistent walk)
+])
+def test_wino_f43_conv3x3_vs_float64_direct_convolution(dev, B, cin, cout, H, W):
+    """F(4x4, 3x3), points {0, 1, -1, 1/2, -2, inf}: larger transform constants than F(2x2) -> |error| ~ 1e-5 of the output scale;
+    the assert is the north_star tolerance 1e-4, the measured maximum is printed by -s"""
+    g = torch.Generator(device="cpu").manual_seed(1000 * cin + cout + H)
+    x = torch.randn(B, cin, H, W, generator=g)
+    x[:, :, 0, :] += 2.0
+    x[:, :, :, -1] -= 3.0
+    w = torch.randn(cout, cin, 3, 3, generator=g) / np.sqrt(9 * cin)
+    bias = torch.randn(cout, generator=g)
+    xd = x.to(dev).contiguous(memory_format=torch.channels_last)
+    packed = wino.pack_weights43(w.to(dev))
+    for relu, b in ((True, bias), (False, None), (False, bias)):
+        want = _ref(x, w, b, relu)
+        got = wino.conv3x3_f43(xd, packed, cout, None if b is None else b.to(dev), relu)
+        assert got.shape == want.shape and got.is_contiguous(memory_format=torch.channels_last)
+        scale = max(1.0, float(want.abs().max()))
+        err = float((got.double().cpu() - want).abs().max())
+        print(f"f43 {B}x{cin}->{cout} {H}x{W}: max err {err:.2e} (scale {scale:.1f})")
+        assert err <= 1e-4 * scale, (err, scale)
+    assert torch.equal(wino.pack_weights43(w.to(dev).contiguous(memory_format=torch.channels_last)), packed)
+
+
+def test_wino_f43_slice_in_and_out_and_determinism(dev):
+    """reads channels [0, Cin) of a wider input map, writes its slice of a wider output map (neighbours untouched), bit-identical
+    run to run"""
+    g = torch.Generator(device="cpu").manual_seed(6)
+    x = torch.randn(2, 96, 23, 41, generator=g)
+    w = torch.randn(64, 64, 3, 3, generator=g) / 24.0
+    bias = torch.randn(64, generator=g)
+    xd = x.to(dev).contiguous(memory_format=torch.channels_last)
+    packed = wino.pack_weights43(w.to(dev))
+    out = torch.full((2, 160, 23, 41), 7.0, device=dev).contiguous(memory_format=torch.channels_last)
+    wino.conv3x3_f43(xd, packed, 64, bias.to(dev), True, out=out, out_offset=32, cin=64)
+    want = _ref(x[:, :64], w, bias, True)
+    assert float((out[:, 32:96].double().cpu() - want).abs().max()) <= 1e-4 * max(1.0, float(want.abs().max()))
+    assert bool((out[:, :32] == 7.0).all()) and bool((out[:, 96:] == 7.0).all())
+    out2 = torch.full_like(out, 7.0)
+    wino.conv3x3_f43(xd, packed, 64, bias.to(dev), True, out=out2, out_offset=32, cin=64)
+    assert torch.equal(out, out2)
+
+
+def test_wino_f43_matches_f23_on_a_backbone_sized_map(dev):
+    """PointPillar block 2 geometry (128 channels, 124 x 108, 4 frames): both Winograd kernels within 1e-4 of the library's direct
+    fp32 convolution, and of each other"""
+    g = torch.Generator(device="cpu").manual_seed(9)
+    x = torch.relu(torch.randn(4, 128, 124, 108, generator=g)).to(dev).contiguous(memory_format=torch.channels_last)
+    w = (torch.randn(128, 128, 3, 3, generator=g) / np.sqrt(9 * 128)).to(dev)
+    bias = torch.randn(128, generator=g).to(dev)
+    a = wino.conv3x3_f43(x, wino.pack_weights43(w), 128, bias, True)
+    b = wino.conv3x3(x, wino.pack_weights(w), 128, bias, True)
+    ref = torch.relu(F.conv2d(x, w.contiguous(memory_format=torch.channels_last), bias, 1, 1))
+    scale = max(1.0, float(ref.abs().max()))
+    print(f"f43 vs direct {float((a - ref).abs().max()):.2e}, f23 vs direct {float((b - ref).abs().max()):.2e}, scale {scale:.1f}")
+    assert float((a - ref).abs().max()) <= 1e-4 * scale
+    assert float((a - b).abs().max()) <= 1e-4 * scale

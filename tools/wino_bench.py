@@ -34,6 +34,12 @@ for B, C, H, W in shapes:
     with torch.no_grad():
         t_w = ev(lambda: wino.conv3x3(x, packed, C, bias, True))
         if os.environ.get("WINO_BENCH_ONLY"):
+            if wino.supported43(C, C):
+                p43 = wino.pack_weights43(w)
+                t_4 = ev(lambda: wino.conv3x3_f43(x, p43, C, bias, True))
+                e43 = float((wino.conv3x3_f43(x, p43, C, bias, True) - wino.conv3x3(x, packed, C, bias, True)).abs().max())
+                print(f"B{B} C{C} {H}x{W}: F(4x4) {t_4:.3f} ms, MFMA {2.0 * 9 * C * C * B * H * W / 1e9 / 4 / t_4 / 157.3:.3f} of peak, "
+                      f"{t_w / t_4:.2f}x over F(2x2), max |diff| to it {e43:.2e} |", flush=True)
             print(f"B{B} C{C} {H}x{W}: wino {t_w:.3f} ms, MFMA {2.0 * 9 * C * C * B * H * W / 1e9 * 16 / 36 / t_w / 157.3:.3f} of peak |", flush=True)
             continue
         t_m = ev(lambda: bias_act_(F.conv2d(x, wl, None, 1, 1), bias))
