@@ -466,7 +466,7 @@ def main():
         "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": dt / args.steps * 1e3,
         "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
         "config": {"workload": "PointPillar-KITTI bs=16 per GPU, fp32, eval BN folded: HIP voxelize + PFN; dense 2D backbone = first layer from the "
-                               "pillars (sparse implicit GEMM), stride-1 3x3 layers as Winograd F(2x2,3x3) on the fp32 MFMA, strided deblocks as one "
+                               "pillars (sparse implicit GEMM), stride-1 3x3 layers as Winograd F(4x4,3x3) on the fp32 MFMA, strided deblocks as one "
                                "fused MFMA GEMM (all this repo's HIP), the two stride-2 3x3 layers MIOpen, stride-1 deblock + 1x1 heads hipBLASLt; exact "
                                "HIP top-k + decode + batched rotated NMS; cloud_uniform 20k pts/frame, 16k pillars/frame (max_voxels cap), NMS pre 4096 "
                                "/ post 500 / thr 0.01",

@@ -198,12 +198,12 @@ class FoldedBEVBackbone:
                 assert isinstance(conv, nn.Conv2d) and isinstance(bn, nn.BatchNorm2d) and isinstance(mods[i + 2], nn.ReLU)
                 w, b = _fold(conv.weight, bn, 0, conv.bias)
                 # stride-1 3x3 layers (LAYER_NUMS per block, base_bev_backbone.py:40-45; SECOND's first block opens with one too):
-                # Winograd F(2x2, 3x3) on the matrix cores with shift + ReLU in the kernel (csrc/wino_conv.hip)
+                # Winograd on the matrix cores with shift + ReLU in the kernel (csrc/wino43_conv.hip F(4x4, 3x3), csrc/wino_conv.hip F(2x2, 3x3))
                 packed = None
                 if (_WINO[0] and w.is_cuda and tuple(conv.kernel_size) == (3, 3) and tuple(conv.stride) == (1, 1)
                         and tuple(conv.dilation) == (1, 1) and conv.groups == 1 and conv.padding[0] + pad == 1
                         and conv.padding[1] + pad == 1 and wino.supported(w.shape[1], w.shape[0])):
-                    packed = wino.pack_weights(w)
+                    packed = wino.pack_auto(w)        # F(4x4, 3x3) where supported (Cout % 64 == 0), else F(2x2, 3x3)
                 convs.append((w.contiguous(memory_format=torch.channels_last), b, conv.stride, conv.padding[0] + pad, packed))
                 i += 3
             up, bn = de[0], de[1]
@@ -265,7 +265,7 @@ class FoldedBEVBackbone:
                 if first_done and si == 0 and ci == 0:
                     continue
                 if packed is not None and _WINO[0] and x.is_contiguous(memory_format=torch.channels_last):
-                    x = wino.conv3x3(x, packed, w.shape[0], b, True)
+                    x = wino.conv3x3_auto(x, packed, w.shape[0], b, True)
                     continue
                 x = F.conv2d(x, w, None, stride, pad)
                 if not x.is_contiguous(memory_format=torch.channels_last):

@@ -13,6 +13,10 @@ SO = os.path.join(HERE, "liblidar_hip.so")
 HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
 FLAGS = ["--offload-arch=gfx950", "-O3", "-fPIC", "-std=c++17", "-ffp-contract=off", "-fvisibility=hidden",
          "-Wall", "-Wno-unused-function"]
+# per-source extras.  wino43_conv.hip: its 72-slot chunk body must unroll completely (the accumulators are indexed by the slot) and is
+# larger than the default budget of `#pragma unroll` (the loop then stays rolled WITHOUT a diagnostic and the accumulators go to
+# scratch); the m0 clobber of its LDS-DMA assembly is deliberate
+EXTRA_FLAGS = {"wino43_conv.hip": ["-mllvm", "-pragma-unroll-threshold=4000000", "-Wno-inline-asm"]}
 
 
 def sources():
@@ -32,7 +36,7 @@ def build(force=False, verbose=False):
                 and all(os.path.getmtime(o) >= os.path.getmtime(d) for d in [s] + deps[len(srcs):])):
             objs.append(o)
             continue
-        cmd = [HIPCC, *FLAGS, "-c", s, "-o", o]
+        cmd = [HIPCC, *FLAGS, *EXTRA_FLAGS.get(os.path.basename(s), []), "-c", s, "-o", o]
         if verbose:
             print(" ".join(cmd))
         procs.append((s, subprocess.Popen(cmd)))
@@ -70,7 +74,7 @@ def build_variants(force=False, verbose=False):
             outs.append(so)
             continue
         o = os.path.join(HERE, f"{src[:-4]}.{name}.o")
-        cmd = [HIPCC, *FLAGS, *extra, "-c", s, "-o", o]
+        cmd = [HIPCC, *FLAGS, *EXTRA_FLAGS.get(src, []), *extra, "-c", s, "-o", o]
         if verbose:
             print(" ".join(cmd))
         subprocess.check_call(cmd)

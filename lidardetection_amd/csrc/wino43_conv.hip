@@ -299,19 +299,19 @@ __global__ __launch_bounds__(256) void wino_f43_kernel(const Wino43Args a) {
             }                                                                                                                      \
             if (k == 41) vx[1 - (P)][0] = vs_[16 * 64];                                                                            \
             if (k == 45) vx[1 - (P)][1] = vs_[17 * 64];                                                                            \
-            /* input transform of chunk c + 2: column x read at slot x, its first stage at slots 2 x + 2, 2 x + 3 */              \
+            /* input transform of chunk c + 2, spread over the chunk (one wave per SIMD: whatever does not fit into the 28 free    \
+               issue cycles behind an MFMA idles the matrix pipe): one patch read per slot (column-major) in slots 0..29, first      \
+               stage item (x, r) at slot 8 + 2 (3 x + r) (column x is complete at slot 5 x + 4), second stage in slots 44..58 */     \
             if (!(WINO43_PROBE & 4)) {                                                                                             \
-                if (k < 6) {                                                                                                       \
-                    _Pragma("unroll") for (int j = 0; j < 5; ++j) d_[k][j] = raw_[rrow[j] + W43_COL(k)];                           \
-                }                                                                                                                  \
-                if (k >= 3 && k < 21) {                                                                                            \
-                    const int x = (k - 3) / 3, r = (k - 3) % 3;                                                                    \
+                if (k < 30) d_[k / 5][k % 5] = raw_[rrow[k % 5] + W43_COL(k / 5)];                                                 \
+                if (k >= 8 && k < 44 && !(k & 1)) {                                                                                \
+                    const int x = ((k - 8) >> 1) / 3, r = ((k - 8) >> 1) % 3;                                                      \
                     float s = cf[r][0] * d_[x][0];                                                                                 \
                     _Pragma("unroll") for (int j = 1; j < 5; ++j) s = __builtin_fmaf(cf[r][j], d_[x][j], s);                       \
                     w_[r][x] = s;                                                                                                  \
                 }                                                                                                                  \
-                if (k >= 21 && k < 36) {          /* second stage: five slots per row, <= 6 VALU each */                          \
-                    const int r = (k - 21) / 5, part = (k - 21) % 5;                                                               \
+                if (k >= 44 && k < 59) {                                                                                           \
+                    const int r = (k - 44) / 5, part = (k - 44) % 5;                                                               \
                     if (part == 0) { W43_S2_0(w_[r], o_[r]) }                                                                      \
                     if (part == 1) { W43_S2_1(w_[r], o_[r]) }                                                                      \
                     if (part == 2) { W43_S2_2(w_[r], o_[r]) vd_[(r * 3 + 0) * 64] = (f32x2){o_[r][0], o_[r][1]}; }                 \

@@ -199,7 +199,7 @@ class SECONDMultiHeadNuScenes(nn.Module):
                             if c.bias is not None:
                                 b2[32 * g_:32 * g_ + c.weight.shape[0]] = c.bias.detach()
                         pk2 = [wino.pack_weights(w2), b2, mid0, [c.weight.shape[0] for c in second], None]
-                    pk = (wino.pack_weights(ws), wino.pack_weights(w1c), pk2)
+                    pk = (wino.pack_auto(ws), wino.pack_auto(w1c), pk2)
                 cache = (key, cl(ws), bs.contiguous(), cl(w1c), torch.cat(b1, 0).contiguous(), second, pk)
             self.__dict__["_heads_folded"] = cache
         return cache[1:]
@@ -208,8 +208,8 @@ class SECONDMultiHeadNuScenes(nn.Module):
         """same outputs as heads_reference_layout(): shared conv and all first-layer branch convolutions merged and folded"""
         ws, bs, w1, b1, second, pk = self._folded_heads()
         if pk is not None and _WINO[0] and spatial_2d.is_contiguous(memory_format=torch.channels_last):
-            x = wino.conv3x3(spatial_2d, pk[0], ws.shape[0], bs, True)
-            y = wino.conv3x3(x, pk[1], w1.shape[0], b1, True)
+            x = wino.conv3x3_auto(spatial_2d, pk[0], ws.shape[0], bs, True)
+            y = wino.conv3x3_auto(x, pk[1], w1.shape[0], b1, True)
         else:
             x = bias_act_(F.conv2d(spatial_2d, ws, None, padding=1), bs, True)
             y = bias_act_(F.conv2d(x, w1, None, padding=1), b1, True)

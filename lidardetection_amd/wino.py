@@ -1,8 +1,14 @@
 """Host side of csrc/wino_conv.hip: the stride-1 3x3 convolutions of the dense BEV backbone (pcdet/models/backbones_2d/
 base_bev_backbone.py:34-45) as Winograd F(2x2, 3x3) on the fp32 matrix cores, shift + ReLU in the kernel's epilogue."""
+import os
+
 import torch
 
 from . import _lib
+
+# which Winograd kernel the model code gets for a layer both support: 1 (default) = F(4x4, 3x3) (csrc/wino43_conv.hip: fewer MFMA
+# cycles, |error| ~ 1e-5 of the output scale), 0 = F(2x2, 3x3) everywhere (csrc/wino_conv.hip: ~ 2e-6).  A/B switch.
+_F43 = [os.environ.get("LIDAR_WINO_F43", "1") != "0"]
 
 
 def supported(cin, cout):
@@ -84,6 +90,21 @@ def conv3x3_f43(x, packed, cout, bias=None, relu=True, out=None, out_offset=0, c
     _lib.check(L.lidar_wino43_conv3x3_nhwc(_lib.ptr(x), B, H, W, cin, in_c, _lib.ptr(packed), _lib.ptr(bias), int(bool(relu)), int(cout),
                                            _lib.ptr(out), out.shape[1], int(out_offset), _lib.stream()), "lidar_wino43_conv3x3_nhwc")
     return out
+
+
+def pack_auto(w):
+    """-> (kind, packed filters): F(4x4, 3x3) where csrc/wino43_conv.hip takes the layer (and LIDAR_WINO_F43 != 0), else F(2x2, 3x3)"""
+    if _F43[0] and supported43(w.shape[1], w.shape[0]):
+        return ("f43", pack_weights43(w))
+    return ("f23", pack_weights(w))
+
+
+def conv3x3_auto(x, packed, cout, bias=None, relu=True, out=None, out_offset=0):
+    """conv3x3 with the filters of pack_auto"""
+    kind, p = packed
+    if kind == "f43":
+        return conv3x3_f43(x, p, cout, bias, relu, out, out_offset)
+    return conv3x3(x, p, cout, bias, relu, out, out_offset)
 
 
 def conv3x3_grouped_compact(x, packed, group_cin, couts, bias=None, relu=False, tables=None):
