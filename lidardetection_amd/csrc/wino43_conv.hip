@@ -48,11 +48,12 @@ typedef float f32x2 __attribute__((ext_vector_type(2)));
 #define WINO43_PROBE 0                   // transform, bit 3 no epilogue, bit 4 no barrier
 #endif
 
-__device__ float4 g_wino43_zero = {0.f, 0.f, 0.f, 0.f};
+#define W43_OOB 0x80000000u               // a byte offset no map reaches (the launcher keeps maps below 2^31 bytes): the DMA reads zeros
 
 // ------------------------------------------------------------------ filter transform + packing
 // w: (Cout, Cin, 3, 3) contiguous.  float4 index ((c * NB + nb) * 18 + e) * 64 + lane, component (p & 1) * 2 + hf:
-// U_p[cin = 4 c + (lane >> 4)][cout = 32 nb + 16 hf + (lane & 15)], p = 2 e + (component >> 1)
+// U_p[cin = 4 c + (lane >> 4)][cout = 32 nb + 2 (lane & 15) + hf], p = 2 e + (component >> 1)   (a lane's two output channels are
+// neighbours: the epilogue stages them as one 8-byte word)
 __global__ __launch_bounds__(256) void wino43_pack_kernel(const float *__restrict__ w, int Cin, int Cout, float *__restrict__ upk) {
     const int idx = blockIdx.x * 256 + threadIdx.x;
     if (idx >= Cin * Cout) return;
@@ -65,7 +66,7 @@ __global__ __launch_bounds__(256) void wino43_pack_kernel(const float *__restric
     for (int y = 0; y < 6; ++y)
 #pragma unroll
         for (int x = 0; x < 3; ++x) t[y][x] = G[y][0] * (double)g[x] + G[y][1] * (double)g[3 + x] + G[y][2] * (double)g[6 + x];
-    const int c = cin >> 2, kq = cin & 3, nb = cout >> 5, hf = (cout >> 4) & 1, n = cout & 15, NB = Cout >> 5;
+    const int c = cin >> 2, kq = cin & 3, nb = cout >> 5, hf = cout & 1, n = (cout >> 1) & 15, NB = Cout >> 5;
     const int lane = kq * 16 + n;
 #pragma unroll
     for (int y = 0; y < 6; ++y)
@@ -87,8 +88,7 @@ struct Wino43Args {
     int blocks_y, blocks_x, n_groups, n_blocks;       // n_blocks = B * blocks_y * blocks_x * n_groups (n_groups = Cout / 64)
 };
 
-#define W43_STG_PITCH 48                  // floats per staged output pixel (32 channels; 48: the four lane groups of a write land in
-                                          // four different quarters of the 64 banks)
+#define W43_STG_PITCH 36                  // floats per staged output pixel (32 channels + 4: 16-byte aligned rows, spread over banks)
 
 static constexpr int w43_nt(int TY, int TX) { return (2 * TY + 1) * (TX + 1); }              // region tiles (incl. the half tiles)
 static constexpr int w43_rp(int TY, int TX) { return ((16 * w43_nt(TY, TX) + 255) / 256) * 256; }  // region slots: every wave issues the same number of DMAs
@@ -120,7 +120,8 @@ __global__ __launch_bounds__(256) void wino_f43_kernel(const Wino43Args a) {
     const int ty = m / TX, tx = m % TX;
     const int H = a.H, W = a.W;
     const int NB = a.Cout >> 5;
-    const size_t bstride = (size_t)NB * 18 * 64;         // float4 per chunk
+    const unsigned bstride = (unsigned)(NB * 18 * 64);   // float4 per chunk
+    const f32x4 *upk4 = reinterpret_cast<const f32x4 *>(a.upk);
 
     // ---- logical blocks of this workgroup (XCD-aware, as wino_conv.hip: XCD x owns blocks [x nb8, (x + 1) nb8))
     const int nb8 = (a.n_blocks + 7) >> 3;
@@ -129,19 +130,11 @@ __global__ __launch_bounds__(256) void wino_f43_kernel(const Wino43Args a) {
     int blk = xcd * nb8 + slot;
     if (blk >= blk_end) return;
 
-    // ---- this lane's DMA slots: region pixel of slot s = q * 64 + l  (slot = (row-in-tile * 4 + column-in-tile) * NT + tile)
-    int pyx[QW];                          // (row << 16) | column, -1: not a pixel of the region
-#pragma unroll
-    for (int k = 0; k < QW; ++k) {
-        const int q = wv + 4 * k, s = q * 64 + l;
-        const int c0 = s / NT, tidx = s - c0 * NT;
-        const int tyy = tidx / TC, txx = tidx - tyy * TC;
-        const int ry = 4 * tyy + (c0 >> 2), rx = 4 * txx + (c0 & 3);
-        pyx[k] = ((s < 16 * NT) && ry < RH && rx < RW) ? ((ry << 16) | rx) : -1;
-    }
+    // ---- this lane's DMA slots: region pixel of slot s = q * 64 + l  (slot = (row-in-tile * 4 + column-in-tile) * NT + tile), decoded in
+    // make_tile once per block (kept in registers across the main loop it cost spills, and a scratch reload is a vmcnt(0))
     struct Tile {
-        int off[QW];                     // element offset of this lane's DMA source pixels, chunk 0 (< 0: the zero word)
-        const f32x4 *b;                  // this lane's packed filters, chunk 0
+        unsigned off[QW];                // byte offset of this lane's DMA source pixels, chunk 0 (W43_OOB: outside the image -> zeros)
+        unsigned b;                      // float4 index of this lane's packed filters, chunk 0 (a.upk + 32-bit offset: scalar base addressing)
         int bidx, by, bx, nb;
     };
     auto make_tile = [&](int blk_) {
@@ -153,31 +146,45 @@ __global__ __launch_bounds__(256) void wino_f43_kernel(const Wino43Args a) {
         tl.by = blk_ % a.blocks_y;
         tl.bidx = blk_ / a.blocks_y;
         tl.nb = ng * 2 + nw;
-        tl.b = reinterpret_cast<const f32x4 *>(a.upk) + ((size_t)tl.nb * 18) * 64 + l;
+        tl.b = (unsigned)(tl.nb * 18 * 64 + l);
         const int R0 = 8 * TY * tl.by - 1, C0 = 4 * TX * tl.bx - 1;          // image coordinates of region pixel (0, 0)
+        int lq = l;
+        asm volatile("" : "+v"(lq));                      // opaque: the slot decode below must not be hoisted out of the block loop
 #pragma unroll
         for (int k = 0; k < QW; ++k) {
-            const int gy = R0 + (pyx[k] >> 16), gx = C0 + (pyx[k] & 0xffff);
-            const bool ok = pyx[k] >= 0 && gy >= 0 && gy < H && gx >= 0 && gx < W;
-            tl.off[k] = ok ? ((tl.bidx * H + gy) * W + gx) * a.in_C : -1;          // (< 2^31 elements: checked by the launcher)
+            const int sl = (wv + 4 * k) * 64 + lq;
+            const int c0 = sl / NT, tidx = sl - c0 * NT;
+            const int tyy = tidx / TC, txx = tidx - tyy * TC;
+            const int ry = 4 * tyy + (c0 >> 2), rx = 4 * txx + (c0 & 3);
+            const int gy = R0 + ry, gx = C0 + rx;
+            const bool ok = sl < 16 * NT && ry < RH && rx < RW && gy >= 0 && gy < H && gx >= 0 && gx < W;
+            tl.off[k] = ok ? (unsigned)(((tl.bidx * H + gy) * W + gx) * a.in_C) * 4u : W43_OOB;   // (< 2^31 bytes: checked by the launcher)
         }
         return tl;
     };
-    // LDS-DMA as inline assembly: with the builtin in flight hipcc treats the vector-memory counter as unordered and turns every
-    // wait into vmcnt(0) / lgkmcnt(0) — one full memory round trip per chunk.  Hidden from its bookkeeping, its waits for the rolling
-    // filter loads stay exact (17 younger loads allowed; in fact QW more are in flight, so the wait is slightly stricter than
-    // needed, never looser), and the barriers below wait for the DMA explicitly.  ALWAYS issued, QW per wave and chunk (the count is
-    // what "vmcnt(18)" relies on): the chunk of this block, else of the next block, else the zero word.
+    // LDS-DMA as inline assembly, through a buffer descriptor of the input map: (1) with the builtin in flight hipcc treats the
+    // vector-memory counter as unordered and turns every wait into vmcnt(0) / lgkmcnt(0) — one memory round trip per chunk; hidden from
+    // its bookkeeping, its waits for the rolling filter loads stay exact (17 younger loads allowed; in fact QW more are in flight, so
+    // the wait is slightly stricter than needed, never looser) and the barriers below wait for the DMA explicitly; (2) the buffer form
+    // takes a 32-bit byte offset per lane (one add per chunk) and returns ZEROS for an offset beyond the map: that is the zero padding.
+    // ALWAYS issued, QW per wave and chunk (the count is what "vmcnt(18)" relies on).  The DMA runs as a STREAM three chunks ahead of
+    // the MFMAs: after the last chunk of a block it continues with chunk 0 of the workgroup's next block (W43_OOB when there is none).
+    typedef int i32x4 __attribute__((ext_vector_type(4)));
+    i32x4 rsrc;
+    {
+        const unsigned long long base = (unsigned long long)a.in;
+        rsrc[0] = (int)(unsigned)base;
+        rsrc[1] = (int)((unsigned)(base >> 32) & 0xffffu);                       // stride 0: raw buffer
+        rsrc[2] = (int)((unsigned)a.B * (unsigned)H * (unsigned)W * (unsigned)a.in_C * 4u);   // bytes; offsets beyond read as zero
+        rsrc[3] = 0x00020000;
+    }
     const unsigned raw_lds = (unsigned)(size_t)((__attribute__((address_space(3))) char *)s_raw);
-    auto dma = [&](bool in_cur, bool in_nxt, const Tile &tc, const Tile &tn, int c, int buf) {
+    unsigned doff[QW];                    // the stream's next chunk, this lane's pixels
+    auto dma = [&](int buf) {
 #pragma unroll
         for (int k = 0; k < QW; ++k) {
-            const int q = wv + 4 * k;
-            const int off = in_cur ? tc.off[k] : tn.off[k];
-            const int cc = in_cur ? c : c - (a.Cin >> 2);
-            const float *g = (off >= 0 && (in_cur || in_nxt)) ? a.in + off + 4 * cc : (const float *)&g_wino43_zero;
-            const unsigned dst = raw_lds + (unsigned)((buf * RP + q * 64) * 16);
-            asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, off" : : "v"(g), "s"(dst) : "memory", "m0");
+            const unsigned dst = raw_lds + (unsigned)((buf * RP + (wv + 4 * k) * 64) * 16);
+            asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tbuffer_load_dwordx4 %0, %1, 0 offen lds" : : "v"(doff[k]), "s"(rsrc), "s"(dst) : "memory", "m0");
         }
     };
     // ---- input transform, this wave's share: rows xy = 3 nw + r (r = 0..2) of V = B^T d B for tile group mw, lane = (tile m, channel
@@ -244,17 +251,26 @@ __global__ __launch_bounds__(256) void wino_f43_kernel(const Wino43Args a) {
     f32x2 va[16], vx[2][2];               // A operands: pairs 0..15 rolling, pairs 16, 17 one set per chunk parity
     const int NC = a.Cin >> 2;
     Tile cur = make_tile(blk), nxt = cur;
-
-    // ---- pipeline fill (first block only): raw(0..2), V(0), V(1), the operands of chunk 0
-    dma(true, false, cur, cur, 0, 0);
-    dma(true, false, cur, cur, 1, 1);
 #pragma unroll
-    for (int e = 0; e < 18; ++e) bb[e] = cur.b[e * 64];
+    for (int k = 0; k < QW; ++k) doff[k] = cur.off[k];
+    auto dma_advance = [&](bool cross, bool to_next, const Tile &tn) {       // cross: the chunk just fetched was the block's last one
+#pragma unroll
+        for (int k = 0; k < QW; ++k) doff[k] = cross ? (to_next ? tn.off[k] : W43_OOB) : doff[k] + 16u;
+    };
+
+    // ---- pipeline fill (first block only): raw(0..2), V(0), V(1), the operands of chunk 0     (NC >= 4: no block end in here)
+    dma(0);
+    dma_advance(false, false, cur);
+    dma(1);
+    dma_advance(false, false, cur);
+#pragma unroll
+    for (int e = 0; e < 18; ++e) bb[e] = upk4[cur.b + e * 64];
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // (the DMAs are invisible to the compiler's own wait)
     __syncthreads();                                      // raw(0), raw(1) landed
     transform(0, 0);
     __syncthreads();                                      // V(0) visible; raw[0] free
-    dma(2 < NC, false, cur, cur, 2, 0);
+    dma(0);
+    dma_advance(false, false, cur);
     transform(1, 1);
     {
         const f32x2 *vs = s_v + ((size_t)(0 * 2 + mw) * 18) * 64 + l;
@@ -276,8 +292,11 @@ __global__ __launch_bounds__(256) void wino_f43_kernel(const Wino43Args a) {
             if ((c) > 0) asm volatile("s_waitcnt vmcnt(18) lgkmcnt(0)\n\ts_barrier" ::: "memory");                                 \
             else if (!first_block) asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");                                 \
         }                                                                                                                          \
-        if (!(WINO43_PROBE & 1)) dma((c) + 3 < NC, has_next, cur, nxt, (c) + 3, 1 - (P));                                          \
-        const f32x4 *bp_ = ((c) + 1 < NC) ? cur.b + (size_t)((c) + 1) * bstride : (has_next ? nxt.b : cur.b);                      \
+        if (!(WINO43_PROBE & 1)) {                                                                                                 \
+            dma(1 - (P));                              /* stream element c + 3 */                                                  \
+            dma_advance((c) + 4 == NC, has_next, nxt);                                                                             \
+        }                                                                                                                          \
+        const unsigned bp_ = ((c) + 1 < NC) ? cur.b + (unsigned)((c) + 1) * bstride : (has_next ? nxt.b : cur.b);                  \
         const float *raw_ = reinterpret_cast<const float *>(s_raw + (P) * RP);                                                     \
         const f32x2 *vs_ = s_v + ((size_t)((1 - (P)) * 2 + mw) * 18) * 64 + l;                                                     \
         f32x2 *vd_ = s_v + ((size_t)((P) * 2 + mw) * 18 + 9 * nw) * 64 + l;                                                        \
@@ -294,7 +313,7 @@ __global__ __launch_bounds__(256) void wino_f43_kernel(const Wino43Args a) {
             }                                                                                                                      \
             /* operands of the next chunk into the registers this pair has just released */                                       \
             if ((k & 3) == 3) {                                                                                                    \
-                if (!(WINO43_PROBE & 2)) bb[e] = bp_[e * 64];                                                                      \
+                if (!(WINO43_PROBE & 2)) bb[e] = upk4[bp_ + e * 64];                                                               \
                 if (e < 16) va[e < 16 ? e : 0] = vs_[e * 64];                                                                      \
             }                                                                                                                      \
             if (k == 41) vx[1 - (P)][0] = vs_[16 * 64];                                                                            \
@@ -336,66 +355,73 @@ __global__ __launch_bounds__(256) void wino_f43_kernel(const Wino43Args a) {
         }
 #if !(WINO43_PROBE & 8)
         // ---- epilogue: Y = A^T M A per (tile, cout), + shift, ReLU.  Four rounds (element i of the accumulator tiles = tile 4 kq + i):
-        // both cout halves -> this wave's LDS staging tile [pixel-in-tile * 4 + kq][32 channels] -> 16-byte stores (8 lanes = the
+        // both output channels of the lane -> this wave's LDS staging tile [pixel-in-tile * 4 + kq][32 channels] -> 16-byte stores (8 lanes = the
         // 128 contiguous bytes of one pixel's 32 channels)
         {
             // the inline-assembly MFMAs are invisible to the compiler's hazard recogniser: let the last of them retire before the
             // first accumulator read; and drain the DMAs / filter loads of the next block before the stores below are issued, so
             // that the next block's first barrier need not wait on the vector-memory counter (= on these stores)
-            asm volatile("s_nop 15\n\ts_nop 15\n\ts_waitcnt vmcnt(0)" ::: "memory");
+            asm volatile("s_nop 15\n\ts_nop 15" ::: "memory");
+            __builtin_amdgcn_s_waitcnt(0x0F70);            // vmcnt(0) — the builtin, so that the compiler's own bookkeeping sees it too
             int lo = l;                                    // opaque copy: keeps the per-lane store addresses inside the block loop
             asm volatile("" : "+v"(lo));
             const int ch0 = 32 * cur.nb;
             const bool relu = a.relu != 0;
             float *stg = s_stg + (size_t)wv * 64 * W43_STG_PITCH;
-            const float bv[2] = {a.bias ? a.bias[ch0 + (lo & 15)] : 0.f, a.bias ? a.bias[ch0 + 16 + (lo & 15)] : 0.f};
+            // this lane's two output channels are ch0 + 2 (l & 15) + {0, 1} (the packing interleaves the cout halves): every value
+            // below is the PAIR (hf 0, hf 1) — packed fp32 arithmetic (v_pk_*), half the VALU instructions, and one 8-byte staging write
+            const f32x2 bv = a.bias ? *reinterpret_cast<const f32x2 *>(a.bias + ch0 + 2 * (lo & 15)) : (f32x2){0.f, 0.f};
             const int gy0 = 4 * TY * (2 * cur.by + mw), gx0 = 4 * TX * cur.bx;       // first output pixel of this wave's tile group
             float *obase = a.out + (size_t)cur.bidx * H * W * a.out_C + a.out_off + ch0 + 4 * (lo & 7);
+#define W43_PKFMA(a_, b_, c_) __builtin_elementwise_fma((f32x2){a_, a_}, b_, c_)
 #pragma unroll
             for (int i = 0; i < 4; ++i) {
+                f32x2 y[4][4];
 #pragma unroll
-                for (int hf = 0; hf < 2; ++hf) {
-                    float y[4][4];
+                for (int ii = 0; ii < 4; ++ii)
 #pragma unroll
-                    for (int ii = 0; ii < 4; ++ii)
+                    for (int j = 0; j < 4; ++j) y[ii][j] = bv;
 #pragma unroll
-                        for (int j = 0; j < 4; ++j) y[ii][j] = bv[hf];
+                for (int xy = 0; xy < 6; ++xy) {
+                    f32x2 mm[6];
 #pragma unroll
-                    for (int xy = 0; xy < 6; ++xy) {
-                        float mm[6];
-#pragma unroll
-                        for (int x = 0; x < 6; ++x) {
-                            const int p = 6 * xy + x;
-                            if (p < 32) asm volatile("v_accvgpr_read_b32 %0, %1" : "=v"(mm[x]) : "a"(acc[2 * p + hf][i]));
-                            else mm[x] = acc[2 * p + hf][i];
+                    for (int x = 0; x < 6; ++x) {
+                        const int p = 6 * xy + x;
+                        if (p < 32) {
+                            asm volatile("v_accvgpr_read_b32 %0, %1" : "=v"(mm[x][0]) : "a"(acc[2 * p][i]));
+                            asm volatile("v_accvgpr_read_b32 %0, %1" : "=v"(mm[x][1]) : "a"(acc[2 * p + 1][i]));
+                        } else {
+                            mm[x] = (f32x2){acc[2 * p][i], acc[2 * p + 1][i]};
                         }
-                        const float s = mm[1] + mm[2], d = mm[1] - mm[2];
-                        float tt[4];
-                        tt[0] = (mm[0] + s) + (mm[3] + mm[4]);
-                        tt[1] = __builtin_fmaf(0.5f, mm[3], __builtin_fmaf(-2.f, mm[4], d));
-                        tt[2] = __builtin_fmaf(0.25f, mm[3], __builtin_fmaf(4.f, mm[4], s));
-                        tt[3] = __builtin_fmaf(0.125f, mm[3], __builtin_fmaf(-8.f, mm[4], d)) + mm[5];
-                        const float at[6][4] = {{1.f, 0.f, 0.f, 0.f}, {1.f, 1.f, 1.f, 1.f}, {1.f, -1.f, 1.f, -1.f},
-                                                {1.f, 0.5f, 0.25f, 0.125f}, {1.f, -2.f, 4.f, -8.f}, {0.f, 0.f, 0.f, 1.f}};
-#pragma unroll
-                        for (int ii = 0; ii < 4; ++ii) {
-                            const float cfa = at[xy][ii];
-                            if (cfa == 0.f) continue;
-#pragma unroll
-                            for (int j = 0; j < 4; ++j) {
-                                if (cfa == 1.f) y[ii][j] += tt[j];
-                                else if (cfa == -1.f) y[ii][j] -= tt[j];
-                                else y[ii][j] = __builtin_fmaf(cfa, tt[j], y[ii][j]);
-                            }
-                        }
-                        __builtin_amdgcn_sched_barrier(0);
                     }
+                    const f32x2 s = mm[1] + mm[2], d = mm[1] - mm[2];
+                    f32x2 tt[4];
+                    tt[0] = (mm[0] + s) + (mm[3] + mm[4]);
+                    tt[1] = W43_PKFMA(0.5f, mm[3], W43_PKFMA(-2.f, mm[4], d));
+                    tt[2] = W43_PKFMA(0.25f, mm[3], W43_PKFMA(4.f, mm[4], s));
+                    tt[3] = W43_PKFMA(0.125f, mm[3], W43_PKFMA(-8.f, mm[4], d)) + mm[5];
+                    const float at[6][4] = {{1.f, 0.f, 0.f, 0.f}, {1.f, 1.f, 1.f, 1.f}, {1.f, -1.f, 1.f, -1.f},
+                                            {1.f, 0.5f, 0.25f, 0.125f}, {1.f, -2.f, 4.f, -8.f}, {0.f, 0.f, 0.f, 1.f}};
 #pragma unroll
-                    for (int ii = 0; ii < 4; ++ii)
+                    for (int ii = 0; ii < 4; ++ii) {
+                        const float cfa = at[xy][ii];
+                        if (cfa == 0.f) continue;
 #pragma unroll
-                        for (int j = 0; j < 4; ++j)
-                            stg[((ii * 4 + j) * 4 + (lo >> 4)) * W43_STG_PITCH + 16 * hf + (lo & 15)] = relu ? fmaxf(y[ii][j], 0.f) : y[ii][j];
+                        for (int j = 0; j < 4; ++j) {
+                            if (cfa == 1.f) y[ii][j] += tt[j];
+                            else if (cfa == -1.f) y[ii][j] -= tt[j];
+                            else y[ii][j] = W43_PKFMA(cfa, tt[j], y[ii][j]);
+                        }
+                    }
+                    __builtin_amdgcn_sched_barrier(0);
                 }
+#pragma unroll
+                for (int ii = 0; ii < 4; ++ii)
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) {
+                        const f32x2 v = relu ? (f32x2){fmaxf(y[ii][j][0], 0.f), fmaxf(y[ii][j][1], 0.f)} : y[ii][j];
+                        *reinterpret_cast<f32x2 *>(stg + ((ii * 4 + j) * 4 + (lo >> 4)) * W43_STG_PITCH + 2 * (lo & 15)) = v;
+                    }
                 // (only this wave reads its staging tile back: its own LDS operations are ordered, no barrier)
 #pragma unroll
                 for (int k = 0; k < 8; ++k) {
@@ -427,7 +453,8 @@ __global__ __launch_bounds__(256) void wino_f43_kernel(const Wino43Args a) {
 
 // ------------------------------------------------------------------ C ABI
 LIDAR_EXPORT size_t lidar_wino43_packed_floats(int Cin, int Cout) {
-    if (Cin <= 0 || Cout <= 0 || (Cin & 7) || (Cout & 63)) return 0;       // two 4-channel chunks per loop iteration; 64 channels per workgroup
+    if (Cin < 16 || Cout <= 0 || (Cin & 7) || (Cout & 63)) return 0;       // two 4-channel chunks per loop iteration, the input stream runs
+                                                                           // three chunks ahead (>= 4 per block); 64 channels per workgroup
     return (size_t)36 * Cin * Cout;
 }
 
@@ -458,7 +485,7 @@ LIDAR_EXPORT int lidar_wino43_conv3x3_nhwc(const float *in, int B, int H, int W,
         return LIDAR_ERR_ARG;
     if ((reinterpret_cast<uintptr_t>(in) & 15) || (reinterpret_cast<uintptr_t>(packed) & 15) || (in_C & 3)) return LIDAR_ERR_ARG;
     if ((reinterpret_cast<uintptr_t>(out) & 15) || (out_C & 3) || (out_off & 3)) return LIDAR_ERR_ARG;     // 16-byte output stores
-    if ((long long)B * H * W * in_C >= 0x7fffffffll) return LIDAR_ERR_ARG;                                  // 32-bit source offsets
+    if ((long long)B * H * W * in_C * 4 >= 0x7fffffffll) return LIDAR_ERR_ARG;                              // 32-bit byte offsets into the map
     Wino43Args a;
     a.in = in; a.upk = packed; a.bias = bias; a.out = out;
     a.B = B; a.H = H; a.W = W; a.Cin = Cin; a.Cout = Cout; a.in_C = in_C; a.out_C = out_C; a.out_off = out_off; a.relu = relu;
