@@ -45,15 +45,16 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef float f32x2 __attribute__((ext_vector_type(2)));
 
 #ifndef WINO43_PROBE                     // timing probes (WRONG results): bit 0 no DMA in the loop, bit 1 no filter loads, bit 2 no
-#define WINO43_PROBE 0                   // transform, bit 3 no epilogue, bit 4 no barrier
+#define WINO43_PROBE 0                   // transform, bit 3 no epilogue, bit 4 no barrier, bit 5 no transform arithmetic / V writes (reads stay), bit 7 no patch reads
 #endif
 
 #define W43_OOB 0x80000000u               // a byte offset no map reaches (the launcher keeps maps below 2^31 bytes): the DMA reads zeros
 
 // ------------------------------------------------------------------ filter transform + packing
-// w: (Cout, Cin, 3, 3) contiguous.  float4 index ((c * NB + nb) * 18 + e) * 64 + lane, component (p & 1) * 2 + hf:
-// U_p[cin = 4 c + (lane >> 4)][cout = 32 nb + 2 (lane & 15) + hf], p = 2 e + (component >> 1)   (a lane's two output channels are
-// neighbours: the epilogue stages them as one 8-byte word)
+// w: (Cout, Cin, 3, 3) contiguous.  float4 index ((C * NB + nb) * 36 + q) * 64 + lane, component 2 s + hf:
+// U_p[cin = 8 C + 2 (lane >> 4) + s][cout = 32 nb + 2 (lane & 15) + hf], position p = (q + 18 (nb & 1)) % 36 — block nb is consumed by
+// the waves nw = nb & 1 of a workgroup, which walk the positions starting with the 18 whose V they computed themselves (see below).
+// A lane's two input channels (K-steps s = 0, 1) and two output channels (hf) are neighbours in memory.
 __global__ __launch_bounds__(256) void wino43_pack_kernel(const float *__restrict__ w, int Cin, int Cout, float *__restrict__ upk) {
     const int idx = blockIdx.x * 256 + threadIdx.x;
     if (idx >= Cin * Cout) return;
@@ -66,15 +67,15 @@ __global__ __launch_bounds__(256) void wino43_pack_kernel(const float *__restric
     for (int y = 0; y < 6; ++y)
 #pragma unroll
         for (int x = 0; x < 3; ++x) t[y][x] = G[y][0] * (double)g[x] + G[y][1] * (double)g[3 + x] + G[y][2] * (double)g[6 + x];
-    const int c = cin >> 2, kq = cin & 3, nb = cout >> 5, hf = cout & 1, n = (cout >> 1) & 15, NB = Cout >> 5;
+    const int C = cin >> 3, kq = (cin >> 1) & 3, sk = cin & 1, nb = cout >> 5, hf = cout & 1, n = (cout >> 1) & 15, NB = Cout >> 5;
     const int lane = kq * 16 + n;
 #pragma unroll
     for (int y = 0; y < 6; ++y)
 #pragma unroll
         for (int x = 0; x < 6; ++x) {
             const double u = t[y][0] * G[x][0] + t[y][1] * G[x][1] + t[y][2] * G[x][2];
-            const int p = y * 6 + x, e = p >> 1;
-            upk[(((((size_t)c * NB + nb) * 18 + e) * 64 + lane) << 2) + ((p & 1) << 1) + hf] = (float)u;
+            const int p = y * 6 + x, q = (p + 36 - 18 * (nb & 1)) % 36;
+            upk[(((((size_t)C * NB + nb) * 36 + q) * 64 + lane) << 2) + (sk << 1) + hf] = (float)u;
         }
 }
 
@@ -89,30 +90,35 @@ struct Wino43Args {
 };
 
 #define W43_STG_PITCH 36                  // floats per staged output pixel (32 channels + 4: 16-byte aligned rows, spread over banks)
+#define W43_OOB 0x80000000u               // a byte offset no map reaches (the launcher keeps maps below 2^31 bytes): the DMA reads zeros
+#define W43_R 4                           // positions the A operands are read ahead of their MFMAs
 
 static constexpr int w43_nt(int TY, int TX) { return (2 * TY + 1) * (TX + 1); }              // region tiles (incl. the half tiles)
-static constexpr int w43_rp(int TY, int TX) { return ((16 * w43_nt(TY, TX) + 255) / 256) * 256; }  // region slots: every wave issues the same number of DMAs
+static constexpr int w43_rp(int TY, int TX) { return ((32 * w43_nt(TY, TX) + 255) / 256) * 256; }  // DMA lanes (16 bytes) per chunk: every wave issues the same number
 static constexpr size_t w43_lds_bytes(int TY, int TX) {
-    return (size_t)2 * w43_rp(TY, TX) * 16 + (size_t)2 * 2 * 18 * 64 * 8 + (size_t)4 * 64 * W43_STG_PITCH * 4;
+    return (size_t)2 * w43_rp(TY, TX) * 16 + (size_t)2 * 2 * 36 * 64 * 8 + (size_t)4 * 32 * W43_STG_PITCH * 4;
 }
 
 #define W43_MFMA_A(ACC, VA, VB) asm volatile("v_mfma_f32_16x16x4_f32 %0, %1, %2, %0" : "+a"(ACC) : "v"(VA), "v"(VB))
 #define W43_MFMA_V(ACC, VA, VB) asm volatile("v_mfma_f32_16x16x4_f32 %0, %1, %2, %0" : "+v"(ACC) : "v"(VA), "v"(VB))
 #define W43_MFMA_A0(ACC, VA, VB) asm volatile("v_mfma_f32_16x16x4_f32 %0, %1, %2, 0" : "=a"(ACC) : "v"(VA), "v"(VB))
 #define W43_MFMA_V0(ACC, VA, VB) asm volatile("v_mfma_f32_16x16x4_f32 %0, %1, %2, 0" : "=v"(ACC) : "v"(VA), "v"(VB))
+#define W43_PK(c_) ((f32x2){c_, c_})
+#define W43_FMA(a_, b_, c_) __builtin_elementwise_fma(a_, b_, c_)
 
 template <int TY, int TX>
 __global__ __launch_bounds__(256) void wino_f43_kernel(const Wino43Args a) {
     static_assert(TY * TX == 16, "a wave owns 16 tiles");
     constexpr int TR = 2 * TY + 1, TC = TX + 1, NT = TR * TC;   // region tile rows / columns (the last of each: 2 pixels of halo)
     constexpr int RH = 8 * TY + 2, RW = 4 * TX + 2;             // region pixels
-    constexpr int RP = w43_rp(TY, TX);
-    constexpr int NQ = RP / 64;                                 // DMA wave-instructions per chunk and workgroup
-    constexpr int QW = NQ / 4;                                  // ... per wave (RP is a multiple of 256)
+    constexpr int RP = w43_rp(TY, TX);                          // 16-byte DMA lanes per chunk (two per pixel: 8 channels)
+    constexpr int QW = RP / 256;                                // DMA wave-instructions per wave and chunk
+    constexpr int VB = 2 * 36 * 64;                             // f32x2 per V buffer
+    constexpr int R = W43_R;
     extern __shared__ float4 s_mem4[];
-    float4 *s_raw = s_mem4;                                                   // [2][RP]: [slot][4 channels of the chunk]
-    f32x2 *s_v = reinterpret_cast<f32x2 *>(s_mem4 + 2 * RP);                  // [2][2 tile groups][18 pairs][64 lanes]
-    float *s_stg = reinterpret_cast<float *>(s_v + 2 * 2 * 18 * 64);          // [4 waves][64 pixels][W43_STG_PITCH]
+    float4 *s_raw = s_mem4;                                                   // [2][RP]: [pixel slot][8 channels of the chunk]
+    f32x2 *s_v = reinterpret_cast<f32x2 *>(s_mem4 + 2 * RP);                  // [2][2 tile groups][36 positions][64 lanes]{K-step 0, 1}
+    float *s_stg = reinterpret_cast<float *>(s_v + 2 * VB);                   // [4 waves][32 pixels][W43_STG_PITCH]
 
     const int t = threadIdx.x, l = t & 63, wv = __builtin_amdgcn_readfirstlane(t >> 6);
     const int mw = wv >> 1, nw = wv & 1;
@@ -120,7 +126,7 @@ __global__ __launch_bounds__(256) void wino_f43_kernel(const Wino43Args a) {
     const int ty = m / TX, tx = m % TX;
     const int H = a.H, W = a.W;
     const int NB = a.Cout >> 5;
-    const unsigned bstride = (unsigned)(NB * 18 * 64);   // float4 per chunk
+    const int bstride = NB * 36 * 64;                    // float4 per chunk
     const f32x4 *upk4 = reinterpret_cast<const f32x4 *>(a.upk);
 
     // ---- logical blocks of this workgroup (XCD-aware, as wino_conv.hip: XCD x owns blocks [x nb8, (x + 1) nb8))
@@ -130,11 +136,12 @@ __global__ __launch_bounds__(256) void wino_f43_kernel(const Wino43Args a) {
     int blk = xcd * nb8 + slot;
     if (blk >= blk_end) return;
 
-    // ---- this lane's DMA slots: region pixel of slot s = q * 64 + l  (slot = (row-in-tile * 4 + column-in-tile) * NT + tile), decoded in
-    // make_tile once per block (kept in registers across the main loop it cost spills, and a scratch reload is a vmcnt(0))
+    // ---- this lane's DMA lanes: lane sl = q * 64 + l of the chunk image holds the 16-byte half (sl & 1) of region pixel slot sl >> 1
+    // (slot = (row-in-tile * 4 + column-in-tile) * NT + tile), decoded in make_tile once per block (kept in registers across the
+    // main loop it cost spills, and a scratch reload is a vmcnt(0))
     struct Tile {
-        unsigned off[QW];                // byte offset of this lane's DMA source pixels, chunk 0 (W43_OOB: outside the image -> zeros)
-        unsigned b;                      // float4 index of this lane's packed filters, chunk 0 (a.upk + 32-bit offset: scalar base addressing)
+        unsigned off[QW];                // byte offset of this lane's DMA sources, chunk 0 (W43_OOB: outside the image -> zeros)
+        int b;                           // float4 index of the wave's packed filters, chunk 0 (wave-uniform: scalar address arithmetic)
         int bidx, by, bx, nb;
     };
     auto make_tile = [&](int blk_) {
@@ -146,19 +153,20 @@ __global__ __launch_bounds__(256) void wino_f43_kernel(const Wino43Args a) {
         tl.by = blk_ % a.blocks_y;
         tl.bidx = blk_ / a.blocks_y;
         tl.nb = ng * 2 + nw;
-        tl.b = (unsigned)(tl.nb * 18 * 64 + l);
+        tl.b = tl.nb * 36 * 64;
         const int R0 = 8 * TY * tl.by - 1, C0 = 4 * TX * tl.bx - 1;          // image coordinates of region pixel (0, 0)
         int lq = l;
         asm volatile("" : "+v"(lq));                      // opaque: the slot decode below must not be hoisted out of the block loop
 #pragma unroll
         for (int k = 0; k < QW; ++k) {
             const int sl = (wv + 4 * k) * 64 + lq;
-            const int c0 = sl / NT, tidx = sl - c0 * NT;
+            const int ps = sl >> 1;
+            const int c0 = ps / NT, tidx = ps - c0 * NT;
             const int tyy = tidx / TC, txx = tidx - tyy * TC;
             const int ry = 4 * tyy + (c0 >> 2), rx = 4 * txx + (c0 & 3);
             const int gy = R0 + ry, gx = C0 + rx;
-            const bool ok = sl < 16 * NT && ry < RH && rx < RW && gy >= 0 && gy < H && gx >= 0 && gx < W;
-            tl.off[k] = ok ? (unsigned)(((tl.bidx * H + gy) * W + gx) * a.in_C) * 4u : W43_OOB;   // (< 2^31 bytes: checked by the launcher)
+            const bool ok = ps < 16 * NT && ry < RH && rx < RW && gy >= 0 && gy < H && gx >= 0 && gx < W;
+            tl.off[k] = ok ? (unsigned)(((tl.bidx * H + gy) * W + gx) * a.in_C) * 4u + 16u * (unsigned)(sl & 1) : W43_OOB;
         }
         return tl;
     };
@@ -167,7 +175,7 @@ __global__ __launch_bounds__(256) void wino_f43_kernel(const Wino43Args a) {
     // its bookkeeping, its waits for the rolling filter loads stay exact (17 younger loads allowed; in fact QW more are in flight, so
     // the wait is slightly stricter than needed, never looser) and the barriers below wait for the DMA explicitly; (2) the buffer form
     // takes a 32-bit byte offset per lane (one add per chunk) and returns ZEROS for an offset beyond the map: that is the zero padding.
-    // ALWAYS issued, QW per wave and chunk (the count is what "vmcnt(18)" relies on).  The DMA runs as a STREAM three chunks ahead of
+    // ALWAYS issued, QW per wave and chunk (the count is what "vmcnt(36)" relies on).  The DMA runs as a STREAM two chunks ahead of
     // the MFMAs: after the last chunk of a block it continues with chunk 0 of the workgroup's next block (W43_OOB when there is none).
     typedef int i32x4 __attribute__((ext_vector_type(4)));
     i32x4 rsrc;
@@ -179,7 +187,7 @@ __global__ __launch_bounds__(256) void wino_f43_kernel(const Wino43Args a) {
         rsrc[3] = 0x00020000;
     }
     const unsigned raw_lds = (unsigned)(size_t)((__attribute__((address_space(3))) char *)s_raw);
-    unsigned doff[QW];                    // the stream's next chunk, this lane's pixels
+    unsigned doff[QW];                    // the stream's next chunk, this lane's sources
     auto dma = [&](int buf) {
 #pragma unroll
         for (int k = 0; k < QW; ++k) {
@@ -187,16 +195,19 @@ __global__ __launch_bounds__(256) void wino_f43_kernel(const Wino43Args a) {
             asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tbuffer_load_dwordx4 %0, %1, 0 offen lds" : : "v"(doff[k]), "s"(rsrc), "s"(dst) : "memory", "m0");
         }
     };
-    // ---- input transform, this wave's share: rows xy = 3 nw + r (r = 0..2) of V = B^T d B for tile group mw, lane = (tile m, channel
-    // kq) as in the A operand.  Row xy of B^T d is a combination of the five raw rows nw .. nw + 4 (wave-uniform coefficients, the
-    // same instructions for both waves); the second stage is the full B^T per row.
-    // float index of region pixel (dy, dx) of this lane's patch: ((dy & 3) * 4 + (dx & 3)) * NT * 4 + ((dy >> 2) * TC + (dx >> 2)) * 4 + base
-    const int rbase = ((mw * TY + ty) * TC + tx) * 4 + kq;
+
+    // ---- input transform, this wave's share: rows xy = 3 nw + r (r = 0..2) of V = B^T d B for tile group mw.  Lane = (tile m, channel
+    // PAIR kq): channels 8 C + 2 kq + {0, 1} are the lane's A operands of the chunk's two K-steps, sit in one 8-byte word of the region
+    // image and go through the transform as one packed-fp32 value (v_pk_*: half the VALU instructions of a scalar transform).  Row xy
+    // of B^T d is a combination of the five raw rows nw .. nw + 4 (wave-uniform coefficients, the same instructions for both waves);
+    // the second stage is the full B^T per row.  The wave's 18 positions p = 18 nw + 6 r + x land at V[.][mw][p][lane].
+    // float index of region pixel (dy, dx) of this lane's patch: (((dy & 3) * 4 + (dx & 3)) * NT + (dy >> 2) * TC + (dx >> 2)) * 8 + base
+    const int rbase = ((mw * TY + ty) * TC + tx) * 8 + 2 * kq;
     int rrow[5];
 #pragma unroll
     for (int j = 0; j < 5; ++j) {
         const int dy = nw + j;
-        rrow[j] = rbase + ((dy & 3) * 4 * NT + (dy >> 2) * TC) * 4;
+        rrow[j] = rbase + ((dy & 3) * 4 * NT + (dy >> 2) * TC) * 8;
     }
     float cf[3][5];
     {
@@ -207,140 +218,233 @@ __global__ __launch_bounds__(256) void wino_f43_kernel(const Wino43Args a) {
 #pragma unroll
             for (int j = 0; j < 5; ++j) cf[r][j] = nw ? c1[r][j] : c0[r][j];
     }
-#define W43_COL(x) ((((x) & 3) * NT + ((x) >> 2)) * 4)                    /* float offset of patch column x */
-    // second stage: o = B^T w for one row (6 -> 6)
-#define W43_S2_0(w_, o_) o_[0] = __builtin_fmaf(2.f, w_[0] + w_[4], __builtin_fmaf(-3.f, w_[1] - w_[3], -4.f * w_[2]));
-#define W43_S2_1(w_, o_) o_[1] = __builtin_fmaf(-2.f, w_[1], w_[2]) + __builtin_fmaf(5.f, w_[3], 2.f * w_[4]);
-#define W43_S2_2(w_, o_) o_[2] = __builtin_fmaf(-2.f, w_[1] + w_[4], __builtin_fmaf(5.f, w_[2], -w_[3]));
+#define W43_COL(x) ((((x) & 3) * NT + ((x) >> 2)) * 8)                    /* float offset of patch column x */
+    // second stage: o = B^T w for one row (6 -> 6), packed
+#define W43_S2_0(w_, o_) o_[0] = W43_FMA(W43_PK(2.f), w_[0] + w_[4], W43_FMA(W43_PK(-3.f), w_[1] - w_[3], W43_PK(-4.f) * w_[2]));
+#define W43_S2_1(w_, o_) o_[1] = W43_FMA(W43_PK(-2.f), w_[1], w_[2]) + W43_FMA(W43_PK(5.f), w_[3], W43_PK(2.f) * w_[4]);
+#define W43_S2_2(w_, o_) o_[2] = W43_FMA(W43_PK(-2.f), w_[1] + w_[4], W43_FMA(W43_PK(5.f), w_[2], -w_[3]));
 #define W43_S2_34(w_, o_)                                                                                                          \
     {                                                                                                                              \
-        const float a_ = w_[1] - w_[3], b_ = w_[2] - w_[4];                                                                        \
-        o_[3] = __builtin_fmaf(2.f, a_, b_);                                                                                       \
-        o_[4] = __builtin_fmaf(-2.f, b_, a_);                                                                                      \
+        const f32x2 a_ = w_[1] - w_[3], b_ = w_[2] - w_[4];                                                                        \
+        o_[3] = W43_FMA(W43_PK(2.f), a_, b_);                                                                                      \
+        o_[4] = W43_FMA(W43_PK(-2.f), b_, a_);                                                                                     \
     }
-#define W43_S2_5(w_, o_) o_[5] = __builtin_fmaf(2.f, w_[1] + w_[5], __builtin_fmaf(-3.f, w_[2] - w_[4], -4.f * w_[3]));
-#define W43_STAGE2(w_, o_) { W43_S2_0(w_, o_) W43_S2_1(w_, o_) W43_S2_2(w_, o_) W43_S2_34(w_, o_) W43_S2_5(w_, o_) }
+#define W43_S2_5(w_, o_) o_[5] = W43_FMA(W43_PK(2.f), w_[1] + w_[5], W43_FMA(W43_PK(-3.f), w_[2] - w_[4], W43_PK(-4.f) * w_[3]));
+    f32x2 *const v_own = s_v + (size_t)(mw * 36 + 18 * nw) * 64 + l;           // + buffer * VB: the positions this wave computes (q = 0..17)
+    const f32x2 *const v_prt = s_v + (size_t)(mw * 36 + 18 * (1 - nw)) * 64 + l;  // ... its partner's (q = 18..35)
     auto transform = [&](int rbuf, int vbuf) {            // (pipeline fill only: the loop below carries its own interleaved copy)
         const float *raw = reinterpret_cast<const float *>(s_raw + rbuf * RP);
-        f32x2 *vd = s_v + ((size_t)(vbuf * 2 + mw) * 18 + 9 * nw) * 64 + l;
-        float w_[3][6];
+        f32x2 *vd = v_own + vbuf * VB;
+        f32x2 w_[3][6];
 #pragma unroll
         for (int x = 0; x < 6; ++x) {
-            float d[5];
+            f32x2 d[5];
 #pragma unroll
-            for (int j = 0; j < 5; ++j) d[j] = raw[rrow[j] + W43_COL(x)];
+            for (int j = 0; j < 5; ++j) d[j] = *reinterpret_cast<const f32x2 *>(raw + rrow[j] + W43_COL(x));
 #pragma unroll
             for (int r = 0; r < 3; ++r) {
-                float s = cf[r][0] * d[0];
+                f32x2 sacc = W43_PK(cf[r][0]) * d[0];
 #pragma unroll
-                for (int j = 1; j < 5; ++j) s = __builtin_fmaf(cf[r][j], d[j], s);
-                w_[r][x] = s;
+                for (int j = 1; j < 5; ++j) sacc = W43_FMA(W43_PK(cf[r][j]), d[j], sacc);
+                w_[r][x] = sacc;
             }
         }
 #pragma unroll
         for (int r = 0; r < 3; ++r) {
-            float o[6];
-            W43_STAGE2(w_[r], o)
+            f32x2 o[6];
+            W43_S2_0(w_[r], o) W43_S2_1(w_[r], o) W43_S2_2(w_[r], o) W43_S2_34(w_[r], o) W43_S2_5(w_[r], o)
 #pragma unroll
-            for (int jj = 0; jj < 3; ++jj) vd[(r * 3 + jj) * 64] = (f32x2){o[2 * jj], o[2 * jj + 1]};
+            for (int x = 0; x < 6; ++x) vd[(r * 6 + x) * 64] = o[x];
         }
     };
 
-    f32x4 acc[72];                        // acc[2 p + hf]: position p, cout half hf; element i: tile 4 kq + i of the group, cout (l & 15)
-    f32x4 bb[18];                         // filters of the current chunk (rolling)
-    f32x2 va[16], vx[2][2];               // A operands: pairs 0..15 rolling, pairs 16, 17 one set per chunk parity
-    const int NC = a.Cin >> 2;
+    f32x4 acc[72];                        // acc[2 q + hf]: the wave's q-th position, output channel 2 (l & 15) + hf; element i: tile 4 kq + i
+    f32x4 bb[18];                         // filters, a rolling window of 18 positions: {K-step 0: hf 0, 1; K-step 1: hf 0, 1}
+    f32x2 va[R];                          // A operands {K-step 0, K-step 1}, a ring R positions ahead of the MFMAs
+    const int NC = a.Cin >> 3;            // chunks of 8 channels
     Tile cur = make_tile(blk), nxt = cur;
 #pragma unroll
     for (int k = 0; k < QW; ++k) doff[k] = cur.off[k];
     auto dma_advance = [&](bool cross, bool to_next, const Tile &tn) {       // cross: the chunk just fetched was the block's last one
 #pragma unroll
-        for (int k = 0; k < QW; ++k) doff[k] = cross ? (to_next ? tn.off[k] : W43_OOB) : doff[k] + 16u;
+        for (int k = 0; k < QW; ++k) doff[k] = cross ? (to_next ? tn.off[k] : W43_OOB) : doff[k] + 32u;
     };
 
-    // ---- pipeline fill (first block only): raw(0..2), V(0), V(1), the operands of chunk 0     (NC >= 4: no block end in here)
+    // ---- pipeline fill (first block only): raw(0), raw(1), V(0), the filters of positions 0..17 and the first R A operands of chunk 0
     dma(0);
-    dma_advance(false, false, cur);
+    dma_advance(false, false, cur);                       // (NC >= 4: no block end in here)
     dma(1);
     dma_advance(false, false, cur);
 #pragma unroll
-    for (int e = 0; e < 18; ++e) bb[e] = upk4[cur.b + e * 64];
+    for (int e = 0; e < 18; ++e) bb[e] = (upk4 + cur.b + e * 64)[l];
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // (the DMAs are invisible to the compiler's own wait)
     __syncthreads();                                      // raw(0), raw(1) landed
     transform(0, 0);
     __syncthreads();                                      // V(0) visible; raw[0] free
-    dma(0);
-    dma_advance(false, false, cur);
-    transform(1, 1);
-    {
-        const f32x2 *vs = s_v + ((size_t)(0 * 2 + mw) * 18) * 64 + l;
 #pragma unroll
-        for (int e = 0; e < 16; ++e) va[e] = vs[e * 64];
-        vx[0][0] = vs[16 * 64];
-        vx[0][1] = vs[17 * 64];
-    }
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __syncthreads();                                      // V(1) visible, raw(2) landed; raw[1] free
+    for (int e = 0; e < R; ++e) va[e] = v_own[e * 64];
 
-    // chunk c (parity P = c & 1, NC even): DMA raw(c + 3) -> raw[!P]; operands of c + 1 (A from V[!P], filters from global) into the
-    // registers the MFMAs have just read; transform raw(c + 2) in raw[P] -> V[P].  Past the end of the block, "c + k" means chunk
-    // c + k - NC of the NEXT block (same parities).  FIRST: the block's first chunk starts the accumulators from a zero C operand.
-    // Slot k = 0..71 <-> MFMA (pair e = k >> 2, position p = 2 e + ((k >> 1) & 1), half k & 1).
-#define W43_CHUNK(c, P, FIRST)                                                                                                     \
+    // chunk C of 8 channels (parity P = C & 1, NC even), 144 slots: slot k <-> MFMA (position q = k >> 2, K-step (k >> 1) & 1, output
+    // channel k & 1).  Alongside: DMA raw(C + 2) -> raw[P]; transform raw(C + 1) in raw[!P] -> V[!P]; after a position's four MFMAs its
+    // filter registers take position q + 18 (of this chunk, then of chunk C + 1) and its A ring slot takes position q + R — of V[P],
+    // then (q + R >= 36) the first positions of chunk C + 1 in V[!P]: those are the wave's OWN rows, written by itself earlier in this
+    // chunk, so they need no barrier.  Past the end of the block, "C + 1" / "C + 2" mean chunks 0 / 1 of the NEXT block.
+#define W43_CHUNK(C, P, FIRST)                                                                                                     \
     {                                                                                                                              \
         if (!(WINO43_PROBE & 16)) {                                                                                                \
-            if ((c) > 0) asm volatile("s_waitcnt vmcnt(18) lgkmcnt(0)\n\ts_barrier" ::: "memory");                                 \
+            if ((C) > 0) asm volatile("s_waitcnt vmcnt(36) lgkmcnt(0)\n\ts_barrier" ::: "memory");                                 \
             else if (!first_block) asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");                                 \
         }                                                                                                                          \
         if (!(WINO43_PROBE & 1)) {                                                                                                 \
-            dma(1 - (P));                              /* stream element c + 3 */                                                  \
-            dma_advance((c) + 4 == NC, has_next, nxt);                                                                             \
+            dma(P);                                    /* stream element C + 2 */                                                  \
+            dma_advance((C) + 3 == NC, has_next, nxt);                                                                             \
         }                                                                                                                          \
-        const unsigned bp_ = ((c) + 1 < NC) ? cur.b + (unsigned)((c) + 1) * bstride : (has_next ? nxt.b : cur.b);                  \
-        const float *raw_ = reinterpret_cast<const float *>(s_raw + (P) * RP);                                                     \
-        const f32x2 *vs_ = s_v + ((size_t)((1 - (P)) * 2 + mw) * 18) * 64 + l;                                                     \
-        f32x2 *vd_ = s_v + ((size_t)((P) * 2 + mw) * 18 + 9 * nw) * 64 + l;                                                        \
-        float d_[6][5], w_[3][6], o_[3][6];                                                                                        \
+        /* filter addresses = wave-uniform base (scalar registers, advanced by scalar adds: free) + lane * 16: no VALU */         \
+        const f32x4 *bc_ = upk4 + (cur.b + (C) * bstride);                                                                         \
+        const f32x4 *bn_ = upk4 + (((C) + 1 < NC) ? cur.b + ((C) + 1) * bstride : (has_next ? nxt.b : cur.b));                     \
+        const float *raw_ = reinterpret_cast<const float *>(s_raw + (1 - (P)) * RP);                                               \
+        const f32x2 *vo_ = v_own + (P) * VB, *vp_ = v_prt + (P) * VB;                                                              \
+        f32x2 *vd_ = v_own + (1 - (P)) * VB;                                                                                       \
+        f32x2 d_[6][5], w_[3][6];                                                                                                  \
         __builtin_amdgcn_sched_barrier(0);                                                                                         \
-        _Pragma("unroll") for (int k = 0; k < 72; ++k) {                                                                           \
-            const int e = k >> 2, p = 2 * e + ((k >> 1) & 1), hf = k & 1;                                                          \
-            const float av_ = e < 16 ? va[e < 16 ? e : 0][p & 1] : vx[P][e - 16 < 0 ? 0 : e - 16][p & 1];                          \
-            const float bv_ = bb[e][((p & 1) << 1) + hf];                                                                          \
-            if (FIRST) {                                                                                                           \
-                if (p < 32) W43_MFMA_A0(acc[2 * p + hf], av_, bv_); else W43_MFMA_V0(acc[2 * p + hf], av_, bv_);                   \
+        _Pragma("unroll") for (int k = 0; k < 144; ++k) {                                                                          \
+            const int q = k >> 2, sk = (k >> 1) & 1, hf = k & 1;                                                                   \
+            const float av_ = va[q % R][sk];                                                                                       \
+            const float bv_ = bb[q % 18][(sk << 1) + hf];                                                                          \
+            if (FIRST && sk == 0) {                                                                                                \
+                if (q < 32) W43_MFMA_A0(acc[2 * q + hf], av_, bv_); else W43_MFMA_V0(acc[2 * q + hf], av_, bv_);                   \
             } else {                                                                                                               \
-                if (p < 32) W43_MFMA_A(acc[2 * p + hf], av_, bv_); else W43_MFMA_V(acc[2 * p + hf], av_, bv_);                     \
+                if (q < 32) W43_MFMA_A(acc[2 * q + hf], av_, bv_); else W43_MFMA_V(acc[2 * q + hf], av_, bv_);                     \
             }                                                                                                                      \
-            /* operands of the next chunk into the registers this pair has just released */                                       \
             if ((k & 3) == 3) {                                                                                                    \
-                if (!(WINO43_PROBE & 2)) bb[e] = upk4[bp_ + e * 64];                                                               \
-                if (e < 16) va[e < 16 ? e : 0] = vs_[e * 64];                                                                      \
+                if (!(WINO43_PROBE & 2)) bb[q % 18] = q < 18 ? (bc_ + (q + 18) * 64)[l] : (bn_ + (q - 18 < 0 ? 0 : q - 18) * 64)[l];      \
+                const int qa = q + R;                                                                                              \
+                va[q % R] = qa < 18 ? vo_[(qa < 18 ? qa : 0) * 64] : (qa < 36 ? vp_[(qa >= 18 && qa < 36 ? qa - 18 : 0) * 64]       \
+                                                                               : vd_[(qa >= 36 ? qa - 36 : 0) * 64]);              \
             }                                                                                                                      \
-            if (k == 41) vx[1 - (P)][0] = vs_[16 * 64];                                                                            \
-            if (k == 45) vx[1 - (P)][1] = vs_[17 * 64];                                                                            \
-            /* input transform of chunk c + 2, spread over the chunk (one wave per SIMD: whatever does not fit into the 28 free    \
-               issue cycles behind an MFMA idles the matrix pipe): one patch read per slot (column-major) in slots 0..29, first      \
-               stage item (x, r) at slot 8 + 2 (3 x + r) (column x is complete at slot 5 x + 4), second stage in slots 44..58 */     \
+            /* input transform of chunk C + 1.  VALU instructions do NOT overlap the MFMAs of their SIMD (tools/ubench/mfma_issue.hip:   \
+               one v_fma behind every MFMA costs 12.7 cycles, the same instructions in a burst 4.9 each), LDS reads do (up to two per    \
+               MFMA and wave).  So: the 30 patch reads one per slot, and the arithmetic in TWO bursts — first stage of columns 0..2      \
+               at slot 20 (their reads: slots 0..14), first stage of columns 3..5 (reads: slots 20..34) + the whole second stage with    \
+               its 18 V writes at slot 40; the own-row A reads of the next chunk start at slot 4 (36 - R) + 3 */                          \
             if (!(WINO43_PROBE & 4)) {                                                                                             \
-                if (k < 30) d_[k / 5][k % 5] = raw_[rrow[k % 5] + W43_COL(k / 5)];                                                 \
-                if (k >= 8 && k < 44 && !(k & 1)) {                                                                                \
-                    const int x = ((k - 8) >> 1) / 3, r = ((k - 8) >> 1) % 3;                                                      \
-                    float s = cf[r][0] * d_[x][0];                                                                                 \
-                    _Pragma("unroll") for (int j = 1; j < 5; ++j) s = __builtin_fmaf(cf[r][j], d_[x][j], s);                       \
-                    w_[r][x] = s;                                                                                                  \
+                if (k < 15 || (k >= 20 && k < 35)) {                                                                               \
+                    const int rk = k < 15 ? k : k - 5;                                                                             \
+                    if (WINO43_PROBE & 128) d_[rk / 5][rk % 5] = va[0];                                                            \
+                    else d_[rk / 5][rk % 5] = *reinterpret_cast<const f32x2 *>(raw_ + rrow[rk % 5] + W43_COL(rk / 5));             \
                 }                                                                                                                  \
-                if (k >= 44 && k < 59) {                                                                                           \
-                    const int r = (k - 44) / 5, part = (k - 44) % 5;                                                               \
-                    if (part == 0) { W43_S2_0(w_[r], o_[r]) }                                                                      \
-                    if (part == 1) { W43_S2_1(w_[r], o_[r]) }                                                                      \
-                    if (part == 2) { W43_S2_2(w_[r], o_[r]) vd_[(r * 3 + 0) * 64] = (f32x2){o_[r][0], o_[r][1]}; }                 \
-                    if (part == 3) { W43_S2_34(w_[r], o_[r]) vd_[(r * 3 + 1) * 64] = (f32x2){o_[r][2], o_[r][3]}; }                \
-                    if (part == 4) { W43_S2_5(w_[r], o_[r]) vd_[(r * 3 + 2) * 64] = (f32x2){o_[r][4], o_[r][5]}; }                 \
+                if ((k == 20 || k == 40) && (WINO43_PROBE & 32)) {     /* keep the reads alive */                                  \
+                    _Pragma("unroll") for (int x = (k == 20 ? 0 : 3); x < (k == 20 ? 3 : 6); ++x)                                  \
+                        _Pragma("unroll") for (int j = 0; j < 5; ++j) asm volatile("" : : "v"(d_[x][j]));                          \
+                }                                                                                                                  \
+                if ((k == 20 || k == 40) && !(WINO43_PROBE & 32)) {                                                                \
+                    _Pragma("unroll") for (int x = (k == 20 ? 0 : 3); x < (k == 20 ? 3 : 6); ++x)                                  \
+                        _Pragma("unroll") for (int r = 0; r < 3; ++r) {                                                            \
+                            f32x2 s_ = W43_PK(cf[r][0]) * d_[x][0];                                                                \
+                            _Pragma("unroll") for (int j = 1; j < 5; ++j) s_ = W43_FMA(W43_PK(cf[r][j]), d_[x][j], s_);            \
+                            w_[r][x] = s_;                                                                                         \
+                        }                                                                                                          \
+                }                                                                                                                  \
+                if (k == 40 && !(WINO43_PROBE & 32)) {                                                                             \
+                    _Pragma("unroll") for (int r = 0; r < 3; ++r) {                                                                \
+                        f32x2 o_[6];                                                                                               \
+                        W43_S2_0(w_[r], o_) W43_S2_1(w_[r], o_) W43_S2_2(w_[r], o_) W43_S2_34(w_[r], o_) W43_S2_5(w_[r], o_)       \
+                        _Pragma("unroll") for (int x = 0; x < 6; ++x) vd_[(r * 6 + x) * 64] = o_[x];                               \
+                    }                                                                                                              \
                 }                                                                                                                  \
             }                                                                                                                      \
             __builtin_amdgcn_sched_barrier(0);                                                                                     \
         }                                                                                                                          \
     }
+
+    // ---- epilogue: Y = A^T M A per (tile, cout), + shift, ReLU.  Four rounds (element i of the accumulator tiles = tile 4 kq + i) of two
+    // half rounds (output rows 0, 1 / 2, 3 of the tile): this wave's LDS staging tile [32 pixels][32 channels] -> 16-byte stores (8 lanes =
+    // the 128 contiguous bytes of one pixel's 32 channels).  The accumulators are stored in the wave's position order: stored row qr
+    // holds transform row xy = (qr + 3 nw) % 6 — one copy of the code per nw (compile-time coefficients; a wave-uniform branch picks).
+    //  * the inline-assembly MFMAs are invisible to the compiler's hazard recogniser: two s_nop 15 let the last of them retire before
+    //    the first accumulator read;
+    //  * `lo`: an opaque copy of the lane id keeps the per-lane store addresses inside the block loop;
+    //  * this lane's two output channels are ch0 + 2 (l & 15) + {0, 1}: every value is the PAIR (hf 0, hf 1) — packed fp32 arithmetic
+    //    and one 8-byte staging write; only this wave reads its staging tile back (its own LDS operations are ordered, no barrier);
+    //  * the DMAs / filter loads of the next block (issued during the last chunk) are drained right before the first store, so that
+    //    the next block's first barrier need not wait on the vector-memory counter (= on these stores); through the builtin, so that
+    //    the compiler's own bookkeeping sees it too.
+#define W43_EPILOGUE(NWV)                                                                                                          \
+        {                                                                                                                          \
+            asm volatile("s_nop 15\n\ts_nop 15" ::: "memory");                                                                     \
+            int lo = l;                                                                                                            \
+            asm volatile("" : "+v"(lo));                                                                                           \
+            const int ch0 = 32 * cur.nb;                                                                                           \
+            const bool relu = a.relu != 0;                                                                                         \
+            float *stg = s_stg + (size_t)wv * 32 * W43_STG_PITCH;                                                                  \
+            const f32x2 bv = a.bias ? *reinterpret_cast<const f32x2 *>(a.bias + ch0 + 2 * (lo & 15)) : (f32x2){0.f, 0.f};          \
+            const int gy0 = 4 * TY * (2 * cur.by + mw), gx0 = 4 * TX * cur.bx;                                                     \
+            float *obase = a.out + (size_t)cur.bidx * H * W * a.out_C + a.out_off + ch0 + 4 * (lo & 7);                            \
+            const float at[6][4] = {{1.f, 0.f, 0.f, 0.f}, {1.f, 1.f, 1.f, 1.f}, {1.f, -1.f, 1.f, -1.f},                            \
+                                    {1.f, 0.5f, 0.25f, 0.125f}, {1.f, -2.f, 4.f, -8.f}, {0.f, 0.f, 0.f, 1.f}};                     \
+_Pragma("unroll")                                                                                                                  \
+            for (int i = 0; i < 4; ++i) {                                                                                          \
+                f32x2 y[4][4];                                                                                                     \
+_Pragma("unroll")                                                                                                                  \
+                for (int ii = 0; ii < 4; ++ii)                                                                                     \
+_Pragma("unroll")                                                                                                                  \
+                    for (int j = 0; j < 4; ++j) y[ii][j] = bv;                                                                     \
+_Pragma("unroll")                                                                                                                  \
+                for (int qr = 0; qr < 6; ++qr) {                                                                                   \
+                    f32x2 mm[6];                                                                                                   \
+_Pragma("unroll")                                                                                                                  \
+                    for (int x = 0; x < 6; ++x) {                                                                                  \
+                        const int q = 6 * qr + x;                                                                                  \
+                        if (q < 32) {                                                                                              \
+                            asm volatile("v_accvgpr_read_b32 %0, %1" : "=v"(mm[x][0]) : "a"(acc[2 * q][i]));                       \
+                            asm volatile("v_accvgpr_read_b32 %0, %1" : "=v"(mm[x][1]) : "a"(acc[2 * q + 1][i]));                   \
+                        } else {                                                                                                   \
+                            mm[x] = (f32x2){acc[2 * q][i], acc[2 * q + 1][i]};                                                     \
+                        }                                                                                                          \
+                    }                                                                                                              \
+                    const f32x2 s = mm[1] + mm[2], d = mm[1] - mm[2];                                                              \
+                    f32x2 tt[4];                                                                                                   \
+                    tt[0] = (mm[0] + s) + (mm[3] + mm[4]);                                                                         \
+                    tt[1] = W43_FMA(W43_PK(0.5f), mm[3], W43_FMA(W43_PK(-2.f), mm[4], d));                                         \
+                    tt[2] = W43_FMA(W43_PK(0.25f), mm[3], W43_FMA(W43_PK(4.f), mm[4], s));                                         \
+                    tt[3] = W43_FMA(W43_PK(0.125f), mm[3], W43_FMA(W43_PK(-8.f), mm[4], d)) + mm[5];                               \
+_Pragma("unroll")                                                                                                                  \
+                    for (int ii = 0; ii < 4; ++ii) {                                                                               \
+                        const float c_own = at[qr][ii], c_oth = at[(qr + 3) % 6][ii];                                              \
+                        if ((NWV ? c_oth : c_own) == 0.f) continue;                                                                \
+                        const float cfa = NWV ? c_oth : c_own;                                                                     \
+_Pragma("unroll")                                                                                                                  \
+                        for (int j = 0; j < 4; ++j) {                                                                              \
+                            if (cfa == 1.f) y[ii][j] += tt[j];                                                                     \
+                            else if (cfa == -1.f) y[ii][j] -= tt[j];                                                               \
+                            else y[ii][j] = W43_FMA(W43_PK(cfa), tt[j], y[ii][j]);                                                 \
+                        }                                                                                                          \
+                    }                                                                                                              \
+                    __builtin_amdgcn_sched_barrier(0);                                                                             \
+                }                                                                                                                  \
+_Pragma("unroll")                                                                                                                  \
+                for (int hh = 0; hh < 2; ++hh) {                                                                                   \
+_Pragma("unroll")                                                                                                                  \
+                    for (int ii = 0; ii < 2; ++ii)                                                                                 \
+_Pragma("unroll")                                                                                                                  \
+                        for (int j = 0; j < 4; ++j) {                                                                              \
+                            const f32x2 yv = y[2 * hh + ii][j];                                                                    \
+                            const f32x2 v = relu ? (f32x2){fmaxf(yv[0], 0.f), fmaxf(yv[1], 0.f)} : yv;                             \
+                            *reinterpret_cast<f32x2 *>(stg + ((ii * 4 + j) * 4 + (lo >> 4)) * W43_STG_PITCH + 2 * (lo & 15)) = v;  \
+                        }                                                                                                          \
+                    if (i == 0 && hh == 0) __builtin_amdgcn_s_waitcnt(0x0F70);                                                     \
+_Pragma("unroll")                                                                                                                  \
+                    for (int k = 0; k < 4; ++k) {                                                                                  \
+                        const int qp = k * 8 + (lo >> 3);                                                                          \
+                        const int mt = 4 * (qp & 3) + i;                                                                           \
+                        const int oy = gy0 + 4 * (mt / TX) + 2 * hh + (qp >> 4), ox = gx0 + 4 * (mt % TX) + ((qp >> 2) & 3);       \
+                        const float4 v = *reinterpret_cast<const float4 *>(stg + qp * W43_STG_PITCH + 4 * (lo & 7));               \
+                        if (oy < H && ox < W) *reinterpret_cast<float4 *>(obase + ((size_t)oy * W + ox) * a.out_C) = v;            \
+                    }                                                                                                              \
+                    __builtin_amdgcn_sched_barrier(0);                                                                             \
+                }                                                                                                                  \
+            }                                                                                                                      \
+        }                                                                                                                          \
 
     bool first_block = true;
     for (;;) {
@@ -354,91 +458,12 @@ __global__ __launch_bounds__(256) void wino_f43_kernel(const Wino43Args a) {
             W43_CHUNK(c + 1, 1, false)
         }
 #if !(WINO43_PROBE & 8)
-        // ---- epilogue: Y = A^T M A per (tile, cout), + shift, ReLU.  Four rounds (element i of the accumulator tiles = tile 4 kq + i):
-        // both output channels of the lane -> this wave's LDS staging tile [pixel-in-tile * 4 + kq][32 channels] -> 16-byte stores (8 lanes = the
-        // 128 contiguous bytes of one pixel's 32 channels)
-        {
-            // the inline-assembly MFMAs are invisible to the compiler's hazard recogniser: let the last of them retire before the
-            // first accumulator read; and drain the DMAs / filter loads of the next block before the stores below are issued, so
-            // that the next block's first barrier need not wait on the vector-memory counter (= on these stores)
-            asm volatile("s_nop 15\n\ts_nop 15" ::: "memory");
-            __builtin_amdgcn_s_waitcnt(0x0F70);            // vmcnt(0) — the builtin, so that the compiler's own bookkeeping sees it too
-            int lo = l;                                    // opaque copy: keeps the per-lane store addresses inside the block loop
-            asm volatile("" : "+v"(lo));
-            const int ch0 = 32 * cur.nb;
-            const bool relu = a.relu != 0;
-            float *stg = s_stg + (size_t)wv * 64 * W43_STG_PITCH;
-            // this lane's two output channels are ch0 + 2 (l & 15) + {0, 1} (the packing interleaves the cout halves): every value
-            // below is the PAIR (hf 0, hf 1) — packed fp32 arithmetic (v_pk_*), half the VALU instructions, and one 8-byte staging write
-            const f32x2 bv = a.bias ? *reinterpret_cast<const f32x2 *>(a.bias + ch0 + 2 * (lo & 15)) : (f32x2){0.f, 0.f};
-            const int gy0 = 4 * TY * (2 * cur.by + mw), gx0 = 4 * TX * cur.bx;       // first output pixel of this wave's tile group
-            float *obase = a.out + (size_t)cur.bidx * H * W * a.out_C + a.out_off + ch0 + 4 * (lo & 7);
-#define W43_PKFMA(a_, b_, c_) __builtin_elementwise_fma((f32x2){a_, a_}, b_, c_)
-#pragma unroll
-            for (int i = 0; i < 4; ++i) {
-                f32x2 y[4][4];
-#pragma unroll
-                for (int ii = 0; ii < 4; ++ii)
-#pragma unroll
-                    for (int j = 0; j < 4; ++j) y[ii][j] = bv;
-#pragma unroll
-                for (int xy = 0; xy < 6; ++xy) {
-                    f32x2 mm[6];
-#pragma unroll
-                    for (int x = 0; x < 6; ++x) {
-                        const int p = 6 * xy + x;
-                        if (p < 32) {
-                            asm volatile("v_accvgpr_read_b32 %0, %1" : "=v"(mm[x][0]) : "a"(acc[2 * p][i]));
-                            asm volatile("v_accvgpr_read_b32 %0, %1" : "=v"(mm[x][1]) : "a"(acc[2 * p + 1][i]));
-                        } else {
-                            mm[x] = (f32x2){acc[2 * p][i], acc[2 * p + 1][i]};
-                        }
-                    }
-                    const f32x2 s = mm[1] + mm[2], d = mm[1] - mm[2];
-                    f32x2 tt[4];
-                    tt[0] = (mm[0] + s) + (mm[3] + mm[4]);
-                    tt[1] = W43_PKFMA(0.5f, mm[3], W43_PKFMA(-2.f, mm[4], d));
-                    tt[2] = W43_PKFMA(0.25f, mm[3], W43_PKFMA(4.f, mm[4], s));
-                    tt[3] = W43_PKFMA(0.125f, mm[3], W43_PKFMA(-8.f, mm[4], d)) + mm[5];
-                    const float at[6][4] = {{1.f, 0.f, 0.f, 0.f}, {1.f, 1.f, 1.f, 1.f}, {1.f, -1.f, 1.f, -1.f},
-                                            {1.f, 0.5f, 0.25f, 0.125f}, {1.f, -2.f, 4.f, -8.f}, {0.f, 0.f, 0.f, 1.f}};
-#pragma unroll
-                    for (int ii = 0; ii < 4; ++ii) {
-                        const float cfa = at[xy][ii];
-                        if (cfa == 0.f) continue;
-#pragma unroll
-                        for (int j = 0; j < 4; ++j) {
-                            if (cfa == 1.f) y[ii][j] += tt[j];
-                            else if (cfa == -1.f) y[ii][j] -= tt[j];
-                            else y[ii][j] = W43_PKFMA(cfa, tt[j], y[ii][j]);
-                        }
-                    }
-                    __builtin_amdgcn_sched_barrier(0);
-                }
-#pragma unroll
-                for (int ii = 0; ii < 4; ++ii)
-#pragma unroll
-                    for (int j = 0; j < 4; ++j) {
-                        const f32x2 v = relu ? (f32x2){fmaxf(y[ii][j][0], 0.f), fmaxf(y[ii][j][1], 0.f)} : y[ii][j];
-                        *reinterpret_cast<f32x2 *>(stg + ((ii * 4 + j) * 4 + (lo >> 4)) * W43_STG_PITCH + 2 * (lo & 15)) = v;
-                    }
-                // (only this wave reads its staging tile back: its own LDS operations are ordered, no barrier)
-#pragma unroll
-                for (int k = 0; k < 8; ++k) {
-                    const int q = k * 8 + (lo >> 3);      // staged pixel: pixel-in-tile q >> 2, lane group q & 3
-                    const int mt = 4 * (q & 3) + i;       // tile of the group
-                    const int oy = gy0 + 4 * (mt / TX) + (q >> 4), ox = gx0 + 4 * (mt % TX) + ((q >> 2) & 3);
-                    const float4 v = *reinterpret_cast<const float4 *>(stg + q * W43_STG_PITCH + 4 * (lo & 7));
-                    if (oy < H && ox < W) *reinterpret_cast<float4 *>(obase + ((size_t)oy * W + ox) * a.out_C) = v;
-                    if ((k & 3) == 3) __builtin_amdgcn_sched_barrier(0);
-                }
-            }
-        }
+        if (nw == 0) W43_EPILOGUE(0) else W43_EPILOGUE(1)
 #else
         {
             float sum = 0.f;
 #pragma unroll
-            for (int p = 32; p < 36; ++p) sum += acc[2 * p][0] + acc[2 * p + 1][1];
+            for (int q = 32; q < 36; ++q) sum += acc[2 * q][0] + acc[2 * q + 1][1];
             if (sum == 12345.678f) a.out[0] = sum;
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         }
@@ -449,12 +474,13 @@ __global__ __launch_bounds__(256) void wino_f43_kernel(const Wino43Args a) {
         first_block = false;
     }
 #undef W43_CHUNK
+#undef W43_EPILOGUE
 }
 
 // ------------------------------------------------------------------ C ABI
 LIDAR_EXPORT size_t lidar_wino43_packed_floats(int Cin, int Cout) {
-    if (Cin < 16 || Cout <= 0 || (Cin & 7) || (Cout & 63)) return 0;       // two 4-channel chunks per loop iteration, the input stream runs
-                                                                           // three chunks ahead (>= 4 per block); 64 channels per workgroup
+    if (Cin < 32 || Cout <= 0 || (Cin & 15) || (Cout & 63)) return 0;      // two 8-channel chunks per loop iteration, the input stream runs
+                                                                           // two chunks ahead (>= 4 per block); 64 channels per workgroup
     return (size_t)36 * Cin * Cout;
 }
 

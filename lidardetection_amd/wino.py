@@ -52,7 +52,7 @@ def conv3x3(x, packed, cout, bias=None, relu=True, out=None, out_offset=0):
 
 
 def supported43(cin, cout):
-    """the F(4x4, 3x3) kernel (csrc/wino43_conv.hip) takes this layer: Cin % 8 == 0, Cout % 64 == 0"""
+    """the F(4x4, 3x3) kernel (csrc/wino43_conv.hip) takes this layer: Cin % 16 == 0, Cin >= 32, Cout % 64 == 0"""
     return bool(_lib.lib().lidar_wino43_supported(int(cin), int(cout)))
 
 
@@ -60,7 +60,7 @@ def pack_weights43(w):
     """w (Cout, Cin, 3, 3) fp32 -> the packed F(4x4, 3x3) filters (36 Cin Cout floats; the filter transform runs in fp64)"""
     _lib.require_cuda(w.contiguous())
     if w.dim() != 4 or tuple(w.shape[2:]) != (3, 3) or w.dtype != torch.float32 or not supported43(w.shape[1], w.shape[0]):
-        raise _lib.LidarHipError(f"wino.pack_weights43: expected a float32 (Cout % 64 == 0, Cin % 8 == 0, 3, 3) weight, got {tuple(w.shape)}")
+        raise _lib.LidarHipError(f"wino.pack_weights43: expected a float32 (Cout % 64 == 0, Cin % 16 == 0, 3, 3) weight, got {tuple(w.shape)}")
     wc = w.detach().contiguous()
     if wc.stride() != (wc.shape[1] * 9, 9, 3, 1):
         wc = wc.clone(memory_format=torch.contiguous_format)

@@ -163,7 +163,7 @@ def test_wino_grouped_compact_output(dev):
 
 # ------------------------------------------------------------------ F(4x4, 3x3): csrc/wino43_conv.hip
 @pytest.mark.parametrize("B,cin,cout,H,W", [
-    (1, 16, 64, 16, 16),       # one tile group pair, four chunks (the fewest the kernel takes)
+    (1, 32, 64, 16, 16),       # one tile group pair, four chunks of 8 channels (the fewest the kernel takes)
     (2, 64, 64, 20, 36),       # partial groups in both directions
     (1, 64, 64, 32, 16),       # exactly one workgroup of 4 x 4-tile groups
     (3, 128, 128, 14, 22),     # two channel groups
@@ -171,7 +171,7 @@ def test_wino_grouped_compact_output(dev):
     (2, 64, 128, 6, 40),       # 2 x 8-tile groups are chosen
     (1, 128, 64, 33, 17),
     (1, 64, 128, 62, 54),      # 8 x 2-tile groups (PointPillar block 3 geometry)
-    (2, 16, 64, 70, 7),        # four chunks per block, several blocks per workgroup: the input stream crosses blocks mid-pipeline
+    (2, 32, 64, 70, 7),        # four chunks per block, several blocks per workgroup: the input stream crosses blocks mid-pipeline
     (1, 64, 64, 124, 108),     # several blocks per workgroup on one XCD share (persistent walk)
 ])
 def test_wino_f43_conv3x3_vs_float64_direct_convolution(dev, B, cin, cout, H, W):
