@@ -22,22 +22,23 @@
 // register class spelled out: given the choice, hipcc parks the overflow in VGPRs and copies it through AGPRs around every use).  In
 // the accumulator layout all 36 positions of one (tile, cout) sit in the same lane at the same element index, so the output
 // transform is lane-local.  One wave per SIMD, 512 registers.  Workgroup = 4 waves = 2 tile groups (stacked in y) x 2 blocks of 32
-// output channels; Cout / 64 channel groups are separate logical blocks.
-//   A operand (16 tiles x 4 channels of the chunk): lane (m = lane & 15, kq = lane >> 4) supplies tile m, channel 4c + kq.  The
-//              input transform of a tile group is computed once per workgroup: its two waves take transform rows xy 0..2 and 3..5
-//              (raw pixels from the LDS image of the region -> B^T d -> (B^T d) B) and leave V in LDS in A-operand lane order, two
-//              positions per 8-byte word.
+// output channels; Cout / 64 channel groups are separate logical blocks.  A chunk is 8 input channels = two K-steps = 144 MFMAs.
+//   A operand: lane (m = lane & 15, kq = lane >> 4) supplies tile m, channels 8 C + 2 kq + s in K-step s.  The input transform of a
+//              tile group is computed once per workgroup: its two waves take transform rows xy 0..2 and 3..5; a lane owns (tile,
+//              channel PAIR): one 8-byte word of the region image -> B^T d B in packed fp32 (v_pk_*) -> V in LDS, the pair being
+//              the A operands of the two K-steps.  Read back just in time through a 4-position register ring.
 //   B operand: transformed filters packed once per weight update in the order the lanes consume them —
-//              [chunk][cout / 32][position pair e][lane][(p & 1) * 2 + cout half]: one contiguous 1 KB wave load per pair.
-//   LDS image of the region ((8 TY + 2) x (4 TX + 2) pixels x 4 channels): LDS-DMA (global_load_lds_dwordx4), pixels stored TILE-MAJOR
-//              ([row in tile][column in tile][tile]) so that the 16 tiles x 4 channels a wave reads per patch position spread over the
-//              banks (pixel-major: 4-way conflicts).  Zero padding = out-of-image lanes read a zero word.
-// Pipeline per chunk c of 4 channels (72 MFMAs = 2 304 matrix-pipe cycles per wave), the v3 scheme of wino_conv.hip: MFMAs(c) |
-// operands of c + 1 | transform of c + 2 | DMA of c + 3, one barrier per chunk, persistent workgroups that never drain the pipeline
-// across tile blocks, issue order written out slot by slot.  Differences: the operand registers ROLL (a pair's registers are reloaded
-// for the next chunk right after its four MFMAs issue: one register set instead of two; the last two pairs keep two sets so that no
-// LDS read is young when the barrier waits for lgkmcnt(0)), and the barrier waits for the DMA only — s_waitcnt vmcnt(18) leaves the 18
-// filter loads of the next chunk in flight (loads return in order, they were issued after the DMA).
+//              [chunk][cout / 32][position in the wave's order][lane][2 s + cout parity]: one contiguous 1 KB wave load per position,
+//              a rolling window of 18 positions in registers, addresses on a scalar base.
+//   LDS image of the region ((8 TY + 2) x (4 TX + 2) pixels x 8 channels): LDS-DMA (buffer_load_dwordx4 ... lds), pixels stored
+//              TILE-MAJOR ([row in tile][column in tile][tile]) so that the 16 tiles a wave reads per patch position spread over the
+//              banks.  Zero padding = byte offsets beyond the map read zeros (buffer bounds).
+// Pipeline per chunk C: MFMAs(C) | filters of C / C + 1 | transform of C + 1 | DMA of C + 2, one barrier per chunk, persistent
+// workgroups that never drain the pipeline across tile blocks.  The barrier waits for the DMA only — s_waitcnt vmcnt(36) leaves the
+// 36 filter loads issued behind it in flight (loads return in order).
+// Issue model (tools/ubench/mfma_issue.hip): on this part VALU instructions do NOT overlap the MFMAs of their SIMD (4.3 cycles each
+// + 8.5 per MFMA -> VALU switch), LDS reads and vector-memory loads do.  Hence: arithmetic in few large bursts, addresses on the scalar
+// unit, LDS reads one per MFMA slot, and as few VALU instructions as possible (channel pairs, packed fp32).
 #include "common.h"
 #include <stdlib.h>
 
