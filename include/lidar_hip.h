@@ -390,7 +390,7 @@ int lidar_dense_gemm_import_choices(const int *in7, int n);
  * every BaseBEVBackbone block (pcdet/models/backbones_2d/base_bev_backbone.py:34-45) — as Winograd F(2x2, 3x3) on the fp32 matrix
  * cores (csrc/wino_conv.hip): 2.25x fewer MFMA cycles than the direct form, |error| ~ 1e-6 of the output scale.
  * lidar_wino_pack_weights: w (Cout, Cin, 3, 3) contiguous (BatchNorm scale already folded in) -> `packed`, lidar_wino_packed_floats
- * (Cin, Cout) floats (0: shape not supported — Cin % 8 == 0 and Cout % 32 == 0 are); once per weight update.
+ * (Cin, Cout) floats (0: shape not supported — Cin % 8 == 0, Cin >= 16 and Cout % 32 == 0 are); once per weight update.
  * lidar_wino_conv3x3_nhwc: out[b][y][x][out_off + co] = act(conv(in, w)[b][y][x][co] + bias[co]), `in` (B, H, W, Cin), `out`
  * (B, H, W, out_C) — out_off / out_C as in lidar_bias_act_nhwc (a slice of the concatenated map); bias may be null. */
 size_t lidar_wino_packed_floats(int Cin, int Cout);

@@ -40,6 +40,7 @@ def bias_act_(x, bias, relu=True, out=None, out_offset=0):
 
 
 _LT_GEMM = [os.environ.get("LIDAR_BEV_LT_GEMM", "1") != "0"]      # the fused stride-1 deblock (csrc/dense_gemm.hip); A/B switch
+_SPLIT_MIN = [int(os.environ.get("LIDAR_BEV_SPLIT_MIN", "8"))]    # fewest frames per part-batch
 _SPLIT = [int(os.environ.get("LIDAR_BEV_SPLIT", "2"))]            # part-batches / streams of FoldedBEVBackbone.merged (1 = off)
 _WINO = [os.environ.get("LIDAR_BEV_WINO", "1") != "0"]            # stride-1 3x3 layers on csrc/wino_conv.hip (0: MIOpen + epilogue pass)
 _DECONV = [os.environ.get("LIDAR_BEV_DECONV", "1") != "0"]        # stride > 1 deblocks on csrc/deconv_gemm.hip (0: library GEMM + pixel-shuffle pass)
@@ -318,7 +319,7 @@ class FoldedBEVBackbone:
             else:
                 canvas = canvas.dense()
         B = canvas.shape[0]
-        if 1 < _SPLIT[0] <= 2 and canvas.is_cuda and B % _SPLIT[0] == 0 and B // _SPLIT[0] >= 8:     # (4-frame parts lose: PV-RCNN bs 8 16.0 -> 17.5 ms)
+        if 1 < _SPLIT[0] <= 2 and canvas.is_cuda and B % _SPLIT[0] == 0 and B // _SPLIT[0] >= _SPLIT_MIN[0]:   # (4-frame parts lost in r03: PV-RCNN bs 8 16.0 -> 17.5 ms)
             return self._merged_split(canvas, _SPLIT[0], first_done)
         cat = self.features(canvas, first_done=first_done)
         B, C, H, W = cat.shape

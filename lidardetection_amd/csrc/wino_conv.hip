@@ -679,7 +679,8 @@ __global__ __launch_bounds__(512) void wino_f23x2_kernel(const WinoArgs a) {
 
 // ------------------------------------------------------------------ C ABI
 LIDAR_EXPORT size_t lidar_wino_packed_floats(int Cin, int Cout) {
-    if (Cin <= 0 || Cout <= 0 || (Cin & 7) || (Cout & 31)) return 0;       // two 4-channel chunks per loop iteration
+    if (Cin < 16 || Cout <= 0 || (Cin & 7) || (Cout & 31)) return 0;       // two 4-channel chunks per loop iteration; the input DMA runs three
+                                                                           // chunks ahead, across tile blocks: a block must hold at least four
     return (size_t)16 * Cin * Cout;
 }
 

@@ -19,7 +19,7 @@ def pack_weights(w):
     """w (Cout, Cin, 3, 3) fp32 (BatchNorm scale folded in) -> the packed transformed filters the kernel reads (16 Cin Cout floats)"""
     _lib.require_cuda(w.contiguous())
     if w.dim() != 4 or tuple(w.shape[2:]) != (3, 3) or w.dtype != torch.float32 or not supported(w.shape[1], w.shape[0]):
-        raise _lib.LidarHipError(f"wino.pack_weights: expected a float32 (Cout % 32 == 0, Cin % 8 == 0, 3, 3) weight, got {tuple(w.shape)}")
+        raise _lib.LidarHipError(f"wino.pack_weights: expected a float32 (Cout % 32 == 0, Cin % 8 == 0, Cin >= 16, 3, 3) weight, got {tuple(w.shape)}")
     wc = w.detach().contiguous()                      # plain (Cout, Cin, 3, 3) order whatever the memory format of `w`
     if wc.stride() != (wc.shape[1] * 9, 9, 3, 1):
         wc = wc.clone(memory_format=torch.contiguous_format)
@@ -93,17 +93,23 @@ def conv3x3_f43(x, packed, cout, bias=None, relu=True, out=None, out_offset=0, c
 
 
 def pack_auto(w):
-    """-> (kind, packed filters): F(4x4, 3x3) where csrc/wino43_conv.hip takes the layer (and LIDAR_WINO_F43 != 0), else F(2x2, 3x3)"""
+    """-> [kind, packed filters, weight]: F(4x4, 3x3) where csrc/wino43_conv.hip takes the layer (and LIDAR_WINO_F43 != 0), else
+    F(2x2, 3x3).  The weight rides along: a map too large for the F(4x4) kernel's 32-bit byte offsets (>= 2 GiB) is served by F(2x2),
+    packed on first need."""
     if _F43[0] and supported43(w.shape[1], w.shape[0]):
-        return ("f43", pack_weights43(w))
-    return ("f23", pack_weights(w))
+        return ["f43", pack_weights43(w), w.detach()]
+    return ["f23", pack_weights(w), None]
 
 
 def conv3x3_auto(x, packed, cout, bias=None, relu=True, out=None, out_offset=0):
     """conv3x3 with the filters of pack_auto"""
-    kind, p = packed
+    kind, p = packed[0], packed[1]
     if kind == "f43":
-        return conv3x3_f43(x, p, cout, bias, relu, out, out_offset)
+        if x.numel() * 4 < 2 ** 31 - 1:
+            return conv3x3_f43(x, p, cout, bias, relu, out, out_offset)
+        if len(packed) < 4:                            # oversize map: F(2x2) filters, packed once
+            packed.append(pack_weights(packed[2]))
+        p = packed[3]
     return conv3x3(x, p, cout, bias, relu, out, out_offset)
 
 

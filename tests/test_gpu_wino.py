@@ -24,12 +24,12 @@ def _ref(x, w, bias, relu):
     (1, 64, 64, 16, 16),       # exactly one workgroup
     (3, 128, 128, 14, 22),     # 1 x 4 waves
     (2, 256, 256, 9, 11),      # two channel groups per spatial block, odd sizes (bounds in the last tile row / column)
-    (1, 8, 32, 7, 5),          # smallest supported channel counts: 4 x 1 waves, two chunks
+    (1, 16, 32, 7, 5),         # smallest supported channel counts: 4 x 1 waves, four chunks
     (2, 64, 128, 6, 40),       # Cin != Cout
     (1, 128, 64, 33, 17),
     (1, 64, 128, 62, 54),      # tall wave tiles (8 x 4 tiles) are chosen: 28 workgroups instead of 32 (PointPillar block 3 geometry)
     (1, 64, 64, 32, 8),        # tall, 2 x 2 waves
-    (1, 8, 32, 64, 8),         # tall, 4 x 1 waves
+    (2, 16, 32, 64, 8),        # tall, 4 x 1 waves
 ])
 def test_wino_conv3x3_vs_float64_direct_convolution(dev, B, cin, cout, H, W):
     g = torch.Generator(device="cpu").manual_seed(1000 * cin + cout + H)
@@ -80,7 +80,9 @@ def test_wino_conv3x3_is_deterministic_and_matches_miopen(dev):
 
 
 def test_wino_boundary_rejects_unsupported_shapes(dev):
-    assert not wino.supported(4, 32) and not wino.supported(64, 48) and wino.supported(8, 32)
+    assert not wino.supported(4, 32) and not wino.supported(64, 48) and wino.supported(16, 32)
+    assert not wino.supported(8, 32)                     # fewer than four chunks per block: the cross-block input pipeline needs them
+    assert wino.supported43(32, 64) and not wino.supported43(16, 64) and not wino.supported43(64, 32) and not wino.supported43(40, 64)
     with pytest.raises(_lib.LidarHipError):
         wino.pack_weights(torch.zeros(48, 64, 3, 3, device=dev))
     x = torch.zeros(1, 64, 8, 8, device=dev).contiguous(memory_format=torch.channels_last)
