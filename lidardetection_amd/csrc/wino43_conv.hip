@@ -128,7 +128,6 @@ __global__ __launch_bounds__(256) void wino_f43_kernel(const Wino43Args a) {
     const int H = a.H, W = a.W;
     const int NB = a.Cout >> 5;
     const int bstride = NB * 36 * 64;                    // float4 per chunk
-    const f32x4 *upk4 = reinterpret_cast<const f32x4 *>(a.upk);
 
     // ---- logical blocks of this workgroup (XCD-aware, as wino_conv.hip: XCD x owns blocks [x nb8, (x + 1) nb8))
     const int nb8 = (a.n_blocks + 7) >> 3;
@@ -187,6 +186,13 @@ __global__ __launch_bounds__(256) void wino_f43_kernel(const Wino43Args a) {
         rsrc[2] = (int)((unsigned)a.B * (unsigned)H * (unsigned)W * (unsigned)a.in_C * 4u);   // bytes; offsets beyond read as zero
         rsrc[3] = 0x00020000;
     }
+    // the packed filters through a second descriptor: wave-uniform offset in a scalar register, lane * 16 in one vector register,
+    // 32-bit addressing (half the address traffic of a 64-bit global load, and no VALU)
+    const __amdgpu_buffer_rsrc_t frsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(a.upk), (short)0, (int)(36u * (unsigned)a.Cin * (unsigned)a.Cout * 4u), 0x00020000);
+    const int l16 = l * 16;
+    auto ldf = [&](int f4_index) {                        // float4 number f4_index (wave-uniform) + lane
+        return __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(frsrc, l16, f4_index * 16, 0));
+    };
     const unsigned raw_lds = (unsigned)(size_t)((__attribute__((address_space(3))) char *)s_raw);
     unsigned doff[QW];                    // the stream's next chunk, this lane's sources
     auto dma = [&](int buf) {
@@ -277,7 +283,7 @@ __global__ __launch_bounds__(256) void wino_f43_kernel(const Wino43Args a) {
     dma(1);
     dma_advance(false, false, cur);
 #pragma unroll
-    for (int e = 0; e < 18; ++e) bb[e] = (upk4 + cur.b + e * 64)[l];
+    for (int e = 0; e < 18; ++e) bb[e] = ldf(cur.b + e * 64);
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // (the DMAs are invisible to the compiler's own wait)
     __syncthreads();                                      // raw(0), raw(1) landed
     transform(0, 0);
@@ -301,8 +307,8 @@ __global__ __launch_bounds__(256) void wino_f43_kernel(const Wino43Args a) {
             dma_advance((C) + 3 == NC, has_next, nxt);                                                                             \
         }                                                                                                                          \
         /* filter addresses = wave-uniform base (scalar registers, advanced by scalar adds: free) + lane * 16: no VALU */         \
-        const f32x4 *bc_ = upk4 + (cur.b + (C) * bstride);                                                                         \
-        const f32x4 *bn_ = upk4 + (((C) + 1 < NC) ? cur.b + ((C) + 1) * bstride : (has_next ? nxt.b : cur.b));                     \
+        const int bc_ = cur.b + (C) * bstride;                                                                                     \
+        const int bn_ = ((C) + 1 < NC) ? cur.b + ((C) + 1) * bstride : (has_next ? nxt.b : cur.b);                                 \
         const float *raw_ = reinterpret_cast<const float *>(s_raw + (1 - (P)) * RP);                                               \
         const f32x2 *vo_ = v_own + (P) * VB, *vp_ = v_prt + (P) * VB;                                                              \
         f32x2 *vd_ = v_own + (1 - (P)) * VB;                                                                                       \
@@ -318,7 +324,7 @@ __global__ __launch_bounds__(256) void wino_f43_kernel(const Wino43Args a) {
                 if (q < 32) W43_MFMA_A(acc[2 * q + hf], av_, bv_); else W43_MFMA_V(acc[2 * q + hf], av_, bv_);                     \
             }                                                                                                                      \
             if ((k & 3) == 3) {                                                                                                    \
-                if (!(WINO43_PROBE & 2)) bb[q % 18] = q < 18 ? (bc_ + (q + 18) * 64)[l] : (bn_ + (q - 18 < 0 ? 0 : q - 18) * 64)[l];      \
+                if (!(WINO43_PROBE & 2)) bb[q % 18] = q < 18 ? ldf(bc_ + (q + 18) * 64) : ldf(bn_ + (q - 18 < 0 ? 0 : q - 18) * 64);      \
                 const int qa = q + R;                                                                                              \
                 va[q % R] = qa < 18 ? vo_[(qa < 18 ? qa : 0) * 64] : (qa < 36 ? vp_[(qa >= 18 && qa < 36 ? qa - 18 : 0) * 64]       \
                                                                                : vd_[(qa >= 36 ? qa - 36 : 0) * 64]);              \
