@@ -413,7 +413,7 @@ int lidar_wino_conv3x3_grouped_compact_nhwc(const float *in, int B, int H, int W
 /* The same stride-1 3x3 layers as Winograd F(4x4, 3x3) (csrc/wino43_conv.hip): 4x fewer MFMA cycles than the direct form (F(2x2):
  * 2.25x), interpolation points {0, 1, -1, 1/2, -2, inf}, filter transform in fp64; |error| ~ 1e-5 of the output scale (asserted at
  * 1e-4 against the fp64 convolution).  Supported: Cin % 16 == 0, Cin >= 32, Cout % 64 == 0 (lidar_wino43_packed_floats = 36 Cin Cout,
- * 0 = unsupported).  `in` is (B, H, W, in_C) and the layer reads channels [0, Cin); the map stays below 2^31 bytes.  Replaces the same reference
+ * 0 = unsupported).  `in` is (B, H, W, in_C) and the layer reads channels [0, Cin); the input and output maps stay below 2^31 bytes each.  Replaces the same reference
  * layers as lidar_wino_conv3x3_nhwc (pcdet/models/backbones_2d/base_bev_backbone.py:34-45). */
 size_t lidar_wino43_packed_floats(int Cin, int Cout);
 int lidar_wino43_supported(int Cin, int Cout);

@@ -46,7 +46,7 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef float f32x2 __attribute__((ext_vector_type(2)));
 
 #ifndef WINO43_PROBE                     // timing probes (WRONG results): bit 0 no DMA in the loop, bit 1 no filter loads, bit 2 no
-#define WINO43_PROBE 0                   // transform, bit 3 no epilogue, bit 4 no barrier, bit 5 no transform arithmetic / V writes (reads stay), bit 7 no patch reads
+#define WINO43_PROBE 0                   // transform, bit 3 no epilogue, bit 4 no barrier, bit 5 no transform arithmetic / V writes (reads stay), bit 7 no patch reads, bit 8 no global stores, bit 9 no load drain before the stores
 #endif
 
 #define W43_OOB 0x80000000u               // a byte offset no map reaches (the launcher keeps maps below 2^31 bytes): the DMA reads zeros
@@ -92,6 +92,10 @@ struct Wino43Args {
 
 #define W43_STG_PITCH 36                  // floats per staged output pixel (32 channels + 4: 16-byte aligned rows, spread over banks)
 #define W43_OOB 0x80000000u               // a byte offset no map reaches (the launcher keeps maps below 2^31 bytes): the DMA reads zeros
+#ifndef W43_STORE_AUX
+#define W43_STORE_AUX 2                 // cache policy bits of the output stores: nt (streaming) — the 33 MB all workgroups write in the same few
+                                        // microseconds otherwise evict the filters from L2; 0 = default policy (A/B: 64 ch 0.237 vs 0.221 ms)
+#endif
 #define W43_R 4                           // positions the A operands are read ahead of their MFMAs
 
 static constexpr int w43_nt(int TY, int TX) { return (2 * TY + 1) * (TX + 1); }              // region tiles (incl. the half tiles)
@@ -189,6 +193,8 @@ __global__ __launch_bounds__(256) void wino_f43_kernel(const Wino43Args a) {
     // the packed filters through a second descriptor: wave-uniform offset in a scalar register, lane * 16 in one vector register,
     // 32-bit addressing (half the address traffic of a 64-bit global load, and no VALU)
     const __amdgpu_buffer_rsrc_t frsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(a.upk), (short)0, (int)(36u * (unsigned)a.Cin * (unsigned)a.Cout * 4u), 0x00020000);
+    typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+    const __amdgpu_buffer_rsrc_t orsrc = __builtin_amdgcn_make_buffer_rsrc(a.out, (short)0, (int)((unsigned)a.B * (unsigned)H * (unsigned)W * (unsigned)a.out_C * 4u), 0x00020000);
     const int l16 = l * 16;
     auto ldf = [&](int f4_index) {                        // float4 number f4_index (wave-uniform) + lane
         return __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(frsrc, l16, f4_index * 16, 0));
@@ -284,7 +290,8 @@ __global__ __launch_bounds__(256) void wino_f43_kernel(const Wino43Args a) {
     dma_advance(false, false, cur);
 #pragma unroll
     for (int e = 0; e < 18; ++e) bb[e] = ldf(cur.b + e * 64);
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // (the DMAs are invisible to the compiler's own wait)
+    __builtin_amdgcn_s_waitcnt(0x0F70);                   // vmcnt(0): the DMAs are invisible to the compiler's own wait; the builtin, so that its
+    asm volatile("" ::: "memory");                        // bookkeeping knows the filters have landed (else chunk 0 waits for the previous block's stores)
     __syncthreads();                                      // raw(0), raw(1) landed
     transform(0, 0);
     __syncthreads();                                      // V(0) visible; raw[0] free
@@ -384,9 +391,21 @@ __global__ __launch_bounds__(256) void wino_f43_kernel(const Wino43Args a) {
             const int ch0 = 32 * cur.nb;                                                                                           \
             const bool relu = a.relu != 0;                                                                                         \
             float *stg = s_stg + (size_t)wv * 32 * W43_STG_PITCH;                                                                  \
-            const f32x2 bv = a.bias ? *reinterpret_cast<const f32x2 *>(a.bias + ch0 + 2 * (lo & 15)) : (f32x2){0.f, 0.f};          \
+            const f32x2 bv = bias2;                                                                                                \
             const int gy0 = 4 * TY * (2 * cur.by + mw), gx0 = 4 * TX * cur.bx;                                                     \
-            float *obase = a.out + (size_t)cur.bidx * H * W * a.out_C + a.out_off + ch0 + 4 * (lo & 7);                            \
+            /* output addressing through a buffer descriptor: per round i a 32-bit byte offset per lane (tile of the lane's staged    \
+               pixel), the (row, column) step of each store as a scalar offset, pixels outside the map get an offset beyond the      \
+               descriptor's size and are dropped by the hardware; blocks inside the map skip the test (wave-uniform) */              \
+            const bool inside = gy0 + 4 * TY <= H && gx0 + 4 * TX <= W;                                                            \
+            int lane_ry[4], lane_cx[4];                                                                                            \
+            unsigned lane_off[4];                                                                                                  \
+_Pragma("unroll")                                                                                                                  \
+            for (int i = 0; i < 4; ++i) {                                                                                          \
+                const int mt = 4 * ((lo >> 3) & 3) + i;                                                                            \
+                lane_ry[i] = gy0 + 4 * (mt / TX);                                                                                  \
+                lane_cx[i] = gx0 + 4 * (mt % TX) + (lo >> 5);                                                                      \
+                lane_off[i] = (unsigned)(((cur.bidx * H + lane_ry[i]) * W + lane_cx[i]) * a.out_C + a.out_off + ch0 + 4 * (lo & 7)) * 4u; \
+            }                                                                                                                      \
             const float at[6][4] = {{1.f, 0.f, 0.f, 0.f}, {1.f, 1.f, 1.f, 1.f}, {1.f, -1.f, 1.f, -1.f},                            \
                                     {1.f, 0.5f, 0.25f, 0.125f}, {1.f, -2.f, 4.f, -8.f}, {0.f, 0.f, 0.f, 1.f}};                     \
 _Pragma("unroll")                                                                                                                  \
@@ -439,14 +458,17 @@ _Pragma("unroll")                                                               
                             const f32x2 v = relu ? (f32x2){fmaxf(yv[0], 0.f), fmaxf(yv[1], 0.f)} : yv;                             \
                             *reinterpret_cast<f32x2 *>(stg + ((ii * 4 + j) * 4 + (lo >> 4)) * W43_STG_PITCH + 2 * (lo & 15)) = v;  \
                         }                                                                                                          \
-                    if (i == 0 && hh == 0) __builtin_amdgcn_s_waitcnt(0x0F70);                                                     \
+                    if (i == 0 && hh == 0 && !(WINO43_PROBE & 512)) __builtin_amdgcn_s_waitcnt(0x0F70);                                                     \
+                    float4 sv_[4];                                                                                                 \
+_Pragma("unroll")                                                                                                                  \
+                    for (int k = 0; k < 4; ++k) sv_[k] = *reinterpret_cast<const float4 *>(stg + (k * 8 + (lo >> 3)) * W43_STG_PITCH + 4 * (lo & 7)); \
 _Pragma("unroll")                                                                                                                  \
                     for (int k = 0; k < 4; ++k) {                                                                                  \
-                        const int qp = k * 8 + (lo >> 3);                                                                          \
-                        const int mt = 4 * (qp & 3) + i;                                                                           \
-                        const int oy = gy0 + 4 * (mt / TX) + 2 * hh + (qp >> 4), ox = gx0 + 4 * (mt % TX) + ((qp >> 2) & 3);       \
-                        const float4 v = *reinterpret_cast<const float4 *>(stg + qp * W43_STG_PITCH + 4 * (lo & 7));               \
-                        if (oy < H && ox < W) *reinterpret_cast<float4 *>(obase + ((size_t)oy * W + ox) * a.out_C) = v;            \
+                        const int dyk = 2 * hh + (k >> 1), dxk = 2 * (k & 1);                                                      \
+                        unsigned vo_ = lane_off[i];                                                                                \
+                        if (!inside) vo_ = (lane_ry[i] + dyk < H && lane_cx[i] + dxk < W) ? vo_ : W43_OOB;                        \
+                        if (!(WINO43_PROBE & 256))                                                                                 \
+                            __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, sv_[k]), orsrc, (int)vo_, (dyk * W + dxk) * a.out_C * 4, W43_STORE_AUX); \
                     }                                                                                                              \
                     __builtin_amdgcn_sched_barrier(0);                                                                             \
                 }                                                                                                                  \
@@ -458,6 +480,13 @@ _Pragma("unroll")                                                               
         const int blk_next = blk + nslots;
         const bool has_next = blk_next < blk_end;
         if (has_next) nxt = make_tile(blk_next);
+        // this block's shift values, fetched now: by the epilogue they have long arrived (fetched there, the wait for them was a wait
+        // for every filter load and DMA of the next block issued just before)
+        const f32x2 bias2 = a.bias ? *reinterpret_cast<const f32x2 *>(a.bias + 32 * cur.nb + 2 * (l & 15)) : (f32x2){0.f, 0.f};
+        // a no-op for the hardware (the epilogue drained every load before its 32 stores; + the shift load above = 33 operations in
+        // flight at most), but hipcc's wait bookkeeping loses the epilogue's vmcnt(0) across the loop's back edge and would make chunk 0
+        // wait for the filter registers with "vmcnt(17)" = for the previous block's STORES; this tells it what is known
+        __builtin_amdgcn_s_waitcnt(0x8F71);                // vmcnt(33)
         W43_CHUNK(0, 0, true)
         W43_CHUNK(1, 1, false)
         for (int c = 2; c < NC; c += 2) {
@@ -519,6 +548,7 @@ LIDAR_EXPORT int lidar_wino43_conv3x3_nhwc(const float *in, int B, int H, int W,
     if ((reinterpret_cast<uintptr_t>(in) & 15) || (reinterpret_cast<uintptr_t>(packed) & 15) || (in_C & 3)) return LIDAR_ERR_ARG;
     if ((reinterpret_cast<uintptr_t>(out) & 15) || (out_C & 3) || (out_off & 3)) return LIDAR_ERR_ARG;     // 16-byte output stores
     if ((long long)B * H * W * in_C * 4 >= 0x7fffffffll) return LIDAR_ERR_ARG;                              // 32-bit byte offsets into the map
+    if ((long long)B * H * W * out_C * 4 >= 0x7fffffffll) return LIDAR_ERR_ARG;                             // ... and into the output map (W43_OOB + a store's scalar step must not wrap)
     Wino43Args a;
     a.in = in; a.upk = packed; a.bias = bias; a.out = out;
     a.B = B; a.H = H; a.W = W; a.Cin = Cin; a.Cout = Cout; a.in_C = in_C; a.out_C = out_C; a.out_off = out_off; a.relu = relu;

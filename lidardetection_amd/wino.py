@@ -105,7 +105,7 @@ def conv3x3_auto(x, packed, cout, bias=None, relu=True, out=None, out_offset=0):
     """conv3x3 with the filters of pack_auto"""
     kind, p = packed[0], packed[1]
     if kind == "f43":
-        if x.numel() * 4 < 2 ** 31 - 1:
+        if x.numel() * 4 < 2 ** 31 - 1 and (out is None or out.numel() * 4 < 2 ** 31 - 1):
             return conv3x3_f43(x, p, cout, bias, relu, out, out_offset)
         if len(packed) < 4:                            # oversize map: F(2x2) filters, packed once
             packed.append(pack_weights(packed[2]))

@@ -5,7 +5,7 @@ R = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 C = os.path.join(R, "lidardetection_amd", "csrc")
 F = "--offload-arch=gfx950 -O3 -fPIC -std=c++17 -ffp-contract=off -fvisibility=hidden -Wall -Wno-unused-function -Wno-inline-asm -mllvm -pragma-unroll-threshold=4000000".split()
 objs = [os.path.join(C, o) for o in os.listdir(C) if o.endswith(".o") and o != "wino43_conv.o" and ".vxl_nowait." not in o]
-names = {1: "no input DMA", 2: "no filter loads", 4: "no patch reads/transform", 8: "no epilogue", 16: "no barrier", 32: "no transform arithmetic + V writes", 128: "no patch reads"}
+names = {1: "no input DMA", 2: "no filter loads", 4: "no patch reads/transform", 8: "no epilogue", 16: "no barrier", 32: "no transform arithmetic + V writes", 128: "no patch reads", 256: "no global stores", 512: "no load drain before the stores"}
 for tok in sys.argv[1].split():                 # "bits" or "bits:EXTRA_DEFINE=val" (e.g. 0:WINO_SCHED=0 for an A/B of two schedules on one box)
     v, extra = (tok.split(":", 1) + [""])[:2]
     v = int(v)
