@@ -57,16 +57,21 @@ VARIANTS = {
     # deadline exit (s_slow -> vxl_bin_streaming): the branch an ordinary run reaches only beside a stalled neighbour
     "vxl_nowait": ("voxelize.hip", ["-DVXL_WAIT_TICKS=0"]),
 }
+# timing A/B libraries (tools only, built on request: build_variants(names=[...]))
+AB_VARIANTS = {
+    "w43_aux0": ("wino43_conv.hip", ["-DW43_STORE_AUX=0"]),        # F(4x4) Winograd with default-policy output stores instead of nt
+}
 
 
 def variant_path(name):
     return os.path.join(HERE, f"liblidar_hip_{name}.so")
 
 
-def build_variants(force=False, verbose=False):
+def build_variants(force=False, verbose=False, names=None):
     build(force=False, verbose=verbose)
     outs = []
-    for name, (src, extra) in VARIANTS.items():
+    todo = VARIANTS if names is None else {n: {**VARIANTS, **AB_VARIANTS}[n] for n in names}
+    for name, (src, extra) in todo.items():
         so = variant_path(name)
         s = os.path.join(HERE, src)
         deps = [s] + glob.glob(os.path.join(HERE, "*.h")) + [os.path.abspath(__file__), SO]

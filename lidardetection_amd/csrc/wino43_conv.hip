@@ -92,10 +92,9 @@ struct Wino43Args {
 
 #define W43_STG_PITCH 36                  // floats per staged output pixel (32 channels + 4: 16-byte aligned rows, spread over banks)
 #define W43_OOB 0x80000000u               // a byte offset no map reaches (the launcher keeps maps below 2^31 bytes): the DMA reads zeros
-#ifndef W43_STORE_AUX
-#define W43_STORE_AUX 2                 // cache policy bits of the output stores: nt (streaming) — the 33 MB all workgroups write in the same few
-                                        // microseconds otherwise evict the filters from L2; 0 = default policy (A/B: 64 ch 0.237 vs 0.221 ms)
-#endif
+#ifndef W43_STORE_AUX                   // cache policy bits of the output stores.  2 = nt (streaming): alone, a 64-channel layer gains 7 %
+#define W43_STORE_AUX 0                 // (0.237 -> 0.221 ms: the 33 MB all workgroups write within microseconds stop evicting the filters
+#endif                                  // from L2); inside the model the NEXT layer then misses them: 3 180 vs 3 203 frames/s, same box -> 0
 #define W43_R 4                           // positions the A operands are read ahead of their MFMAs
 
 static constexpr int w43_nt(int TY, int TX) { return (2 * TY + 1) * (TX + 1); }              // region tiles (incl. the half tiles)
