@@ -216,7 +216,7 @@ class FoldedBEVBackbone:
                     w_kn = w.permute(0, 2, 3, 1).reshape(w.shape[0], -1).contiguous()
                     upc = ("gemm", w_kn, b, up.stride[0])
                     if (_DECONV[0] and w.is_cuda and up.stride[0] > 1 and deconv_supported(w_kn.shape[0], up.stride[0], b.numel())):
-                        upc = ("deconv_mfma", deconv_pack(w_kn), b, up.stride[0])           # csrc/deconv_gemm.hip
+                        upc = ("deconv_mfma", (deconv_pack(w_kn), w_kn), b, up.stride[0])   # csrc/deconv_gemm.hip (+ the plain weight: maps of 2 GiB and more take the two-step path)
                 else:
                     upc = ("deconv", w.contiguous(memory_format=torch.channels_last), b, up.stride)
             else:   # stride < 1 in the reference config: a strided Conv2d (base_bev_backbone.py:60-69)
@@ -276,6 +276,11 @@ class FoldedBEVBackbone:
             y = None
             if kind == "deconv_mfma":
                 oh, ow = h * ustride, w * ustride
+                if B * oh * ow * sum(self.up_channels) * 4 >= 2 ** 31 - 1:       # the fused kernel stores with 32-bit byte offsets
+                    kind, uw = "gemm", uw[1]
+                    y = rows_gemm(x.permute(0, 2, 3, 1).reshape(B * h * w, -1), uw)
+                else:
+                    uw = uw[0]
             elif kind == "gemm":
                 oh, ow = h * ustride, w * ustride
                 if not (ustride == 1 and _LT_GEMM[0]):

@@ -59,7 +59,8 @@ VARIANTS = {
 }
 # timing A/B libraries (tools only, built on request: build_variants(names=[...]))
 AB_VARIANTS = {
-    "w43_aux0": ("wino43_conv.hip", ["-DW43_STORE_AUX=0"]),        # F(4x4) Winograd with default-policy output stores instead of nt
+    "w43_aux0": ("wino43_conv.hip", ["-DW43_STORE_AUX=0"]),
+    "dc_nowait": ("deconv_gemm.hip", ["-DDC_PROBE=1"]),            # WRONG results: the deblock GEMM's barrier does not wait for its DMA        # F(4x4) Winograd with default-policy output stores instead of nt
 }
 
 

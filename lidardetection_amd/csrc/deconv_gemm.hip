@@ -16,9 +16,13 @@
 // 16-byte lane-linear loads; the A operand is one 8-byte LDS load per lane and chunk.  Per chunk and wave: 32 MFMAs against 9 LDS
 // reads and 1 DMA instruction (the Winograd kernel: 8 global loads + 14 LDS operations + the transform arithmetic).
 #include "common.h"
+#ifndef DC_PROBE                         // timing probe (WRONG results): bit 0 = the chunk barrier does not wait for the DMA
+#define DC_PROBE 0
+#endif
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
 typedef float f32x2 __attribute__((ext_vector_type(2)));
 
 __device__ float4 g_dc_zero = {0.f, 0.f, 0.f, 0.f};
@@ -41,6 +45,7 @@ struct DcArgs {
     float *out;              // (B, s h, s w, out_C), channels [out_off, out_off + C_up)
     int P, K, N, h, w, s, C_up, out_C, out_off, relu;
     int n_pblocks, n_groups, n_blocks;       // pixel blocks of 128, column groups of 512, n_blocks = n_pblocks * n_groups
+    unsigned out_bytes;                      // size of the output map (< 2^31: 32-bit store offsets)
 };
 
 #define DC_STG_PITCH 132                 // floats per staged pixel: 128 channels + 4 (16-byte aligned rows, shifted banks)
@@ -57,6 +62,7 @@ __global__ __launch_bounds__(256) void dc_gemm_kernel(const DcArgs a) {
     const size_t bstride = (size_t)a.n_groups * 8 * 64;  // float4 per chunk
 
     const int nb8 = (a.n_blocks + 7) >> 3;
+    const __amdgpu_buffer_rsrc_t orsrc = __builtin_amdgcn_make_buffer_rsrc(a.out, (short)0, (int)a.out_bytes, 0x00020000);
     const int xcd = (int)(blockIdx.x & 7), slot = (int)(blockIdx.x >> 3), nslots = (int)(gridDim.x >> 3);
     const int blk_end = min((xcd + 1) * nb8, a.n_blocks);
     int blk = xcd * nb8 + slot;
@@ -113,7 +119,7 @@ __global__ __launch_bounds__(256) void dc_gemm_kernel(const DcArgs a) {
     // n >> 1, component 2 (n & 1) + s.  FIRST: the block's first chunk starts the accumulators from a zero C operand.
 #define DC_CHUNK(c, P, FIRST, AC, BC, AN, BN)                                                                                      \
     {                                                                                                                              \
-        if ((c) > 0) __syncthreads();                                                                                              \
+        if ((c) > 0) { if (DC_PROBE & 1) { __builtin_amdgcn_s_waitcnt(0xC07F); __builtin_amdgcn_s_barrier(); } else __syncthreads(); } \
         else if (!first_block) {                                                                                                   \
             __builtin_amdgcn_s_waitcnt(0xC07F);                                                                                    \
             __builtin_amdgcn_s_barrier();                                                                                          \
@@ -158,6 +164,27 @@ __global__ __launch_bounds__(256) void dc_gemm_kernel(const DcArgs a) {
             const bool relu = a.relu != 0;
             float *stg = s_stg + (size_t)wv * 32 * DC_STG_PITCH;
             const int hw = a.h * a.w, OW = a.s * a.w;
+            // output addressing through a buffer descriptor: the byte offset of each of this lane's 16 staged pixels (rows lo >> 5,
+            // + 2, ...) is computed ONCE per block — one division pair, then steps with carries; per pixel and round that was two
+            // integer divisions, ~50 VALU instructions each, a fifth of the 128-channel deblock — and the (ky, kx, channel) part of a
+            // round is a scalar offset.  Pixels past the end get an offset beyond the descriptor's size: the store is dropped.
+            unsigned pix[16];
+            {
+                const int p = cur.p0 + 32 * wv + (lo >> 5);
+                int bb = p / hw;
+                const int rem = p - bb * hw;
+                int y = rem / a.w, x = rem - y * a.w;
+#pragma unroll
+                for (int k = 0; k < 16; ++k) {
+                    pix[k] = (p + 2 * k < a.P) ? (unsigned)(((bb * a.s * a.h + a.s * y) * OW + a.s * x) * a.out_C + a.out_off + 4 * (lo & 31)) * 4u : 0x80000000u;
+#pragma unroll
+                    for (int st = 0; st < 2; ++st) {      // two pixels on
+                        x += 1;
+                        if (x >= a.w) { x = 0; y += 1; }
+                        if (y >= a.h) { y = 0; bb += 1; }
+                    }
+                }
+            }
 #pragma unroll
             for (int rnd = 0; rnd < 4; ++rnd) {
                 const int col0 = 512 * cur.g + 128 * rnd;                     // first column of the round
@@ -177,22 +204,15 @@ __global__ __launch_bounds__(256) void dc_gemm_kernel(const DcArgs a) {
                     }
                     __builtin_amdgcn_sched_barrier(0);
                 }
+                const int soff = ((ky * OW + kx) * a.out_C + c0) * 4;          // wave-uniform
 #pragma unroll
                 for (int k4 = 0; k4 < 16; k4 += 4) {      // four staged rows at a time: the LDS reads first, then the stores (a read right
                     f32x4 sv[4];                          // before its store exposes the LDS latency sixteen times per round)
 #pragma unroll
                     for (int k = 0; k < 4; ++k) sv[k] = *reinterpret_cast<const f32x4 *>(stg + (2 * (k4 + k) + (lo >> 5)) * DC_STG_PITCH + 4 * (lo & 31));
 #pragma unroll
-                    for (int k = 0; k < 4; ++k) {
-                        const int row = 2 * (k4 + k) + (lo >> 5);
-                        const int p = cur.p0 + 32 * wv + row;
-                        if (p < a.P) {
-                            const int bb = p / hw, rem = p - bb * hw;
-                            const int y = rem / a.w, x = rem - y * a.w;
-                            float *o = a.out + (((size_t)bb * a.s * a.h + (size_t)a.s * y + ky) * OW + (size_t)a.s * x + kx) * a.out_C + a.out_off + c0 + 4 * (lo & 31);
-                            *reinterpret_cast<f32x4 *>(o) = sv[k];       // (streaming / nt stores measured: no gain here, 3171 vs 3198 frames/s)
-                        }
-                    }
+                    for (int k = 0; k < 4; ++k)
+                        __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, sv[k]), orsrc, (int)pix[k4 + k], soff, 0);
                     __builtin_amdgcn_sched_barrier(0);
                 }
             }
@@ -238,11 +258,12 @@ LIDAR_EXPORT int lidar_deconv_gemm_nhwc(const float *in, int B, int h, int w, in
     if (!in || !packed || !out || B <= 0 || h <= 0 || w <= 0 || !lidar_deconv_supported(K, s, C_up) || out_off < 0 || out_off + C_up > out_C)
         return LIDAR_ERR_ARG;
     if ((reinterpret_cast<uintptr_t>(in) & 15) || (reinterpret_cast<uintptr_t>(packed) & 15) || (reinterpret_cast<uintptr_t>(out) & 15) ||
-        (out_C & 3) || (out_off & 3) || (long long)B * h * w > 0x7fffffffll)
+        (out_C & 3) || (out_off & 3) || (long long)B * h * w > 0x7fffffffll || (long long)B * h * w * s * s * out_C * 4 >= 0x7fffffffll)
         return LIDAR_ERR_ARG;
     DcArgs a;
     a.in = in; a.pk = packed; a.bias = bias; a.out = out;
     a.P = B * h * w; a.K = K; a.N = s * s * C_up; a.h = h; a.w = w; a.s = s; a.C_up = C_up; a.out_C = out_C; a.out_off = out_off; a.relu = relu;
+    a.out_bytes = (unsigned)((long long)B * h * w * s * s * out_C * 4);
     a.n_pblocks = divup(a.P, 128);
     a.n_groups = a.N / 512;
     const long long nblk = (long long)a.n_pblocks * a.n_groups;
