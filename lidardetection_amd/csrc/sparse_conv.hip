@@ -19,6 +19,9 @@
 // 4 waves = 128 output rows; per offset the gathered rows (32 x Cin per wave) and W[k] (Cin x Cout, shared by
 // the workgroup) are staged in LDS; offsets with no neighbour in a wave's tile are skipped.
 #include "common.h"
+#ifndef SC_PROBE                         // timing probes of sc_implicit_gemm_rega_kernel (WRONG results): bit 0 no row gathers, bit 1 no weight
+#define SC_PROBE 0                       // fetch / LDS store, bit 2 no stage barrier
+#endif
 #include <stdlib.h>
 
 #define SC_EMPTY 0xFFFFFFFFFFFFFFFFull
@@ -607,9 +610,11 @@ __global__ __launch_bounds__(256) void sc_implicit_gemm_pipe_kernel(const float 
 // The MFMA's A operand wants lane (row r = lane & 31, half a = lane >> 5) to supply channel (step, a) of row r.  The
 // pipe kernel above gathers rows with coalescing lanes, transposes them through LDS (four ds_write_b32 per float4 at an odd
 // pitch) and reads them back one float per MFMA step, two barriers per offset.  Any fixed assignment of channels to
-// (step, half) gives the same products summed in a fixed order, so here half a of row r simply OWNS channels
-// [a * Cin/2, (a + 1) * Cin/2): lane (r, a) loads those Cin/2 floats of its gathered row straight into registers (contiguous
-// 128 B per lane at Cin = 64) and feeds them to the MFMAs — no LDS for A, no transpose, no cross-lane shuffles of the table
+// (step, half) gives the same products summed in a fixed order, so here half a of row r simply OWNS the 16-byte pieces a, a + 2,
+// a + 4, ... of the row (r04; r03: the contiguous half [a * Cin/2, (a + 1) * Cin/2) — then one gather instruction touched every
+// 64-byte sector of a row with a single 16-byte piece and each sector was requested by four different instructions; interleaved, the
+// two halves of a row read neighbouring pieces in the same instruction and a sector is requested twice): lane (r, a) loads those
+// Cin/2 floats of its gathered row straight into registers and feeds them to the MFMAs — no LDS for A, no transpose, no cross-lane shuffles of the table
 // entries.  Only W[k] goes through LDS, double-buffered: the pieces of W[k+1] and the gathered rows of offset k+1 are in flight
 // while the MFMAs of offset k run, and ONE barrier per offset separates a buffer's last reader from its next writer.
 // Per output row the channels are accumulated in a different (but fixed) order than in the pipe kernel: results differ from
@@ -659,7 +664,7 @@ __global__ __launch_bounds__(256) void sc_implicit_gemm_rega_kernel(const float 
         for (int q = 0; q < NW; ++q) {
             const int e = q * 256 + t, ci = e / CW4, q4 = e - ci * CW4;
             wr[q] = make_float4(0.f, 0.f, 0.f, 0.f);
-            if (e < Cin * CW4 && q4 < Co4) wr[q] = reinterpret_cast<const float4 *>(Wt + ((size_t)k * CinT + h * Cin + ci) * Cout)[q4];
+            if (e < Cin * CW4 && q4 < Co4 && !(SC_PROBE & 2)) wr[q] = reinterpret_cast<const float4 *>(Wt + ((size_t)k * CinT + h * Cin + ci) * Cout)[q4];
         }
     };
     auto store_w = [&](int buf) {
@@ -667,15 +672,15 @@ __global__ __launch_bounds__(256) void sc_implicit_gemm_rega_kernel(const float 
 #pragma unroll
         for (int q = 0; q < NW; ++q) {
             const int e = q * 256 + t;
-            if (e < Cin * CW4) dst[e] = wr[q];
+            if (e < Cin * CW4 && !(SC_PROBE & 2)) dst[e] = wr[q];
         }
     };
     auto fetch_a = [&](float4 (&g)[NG], int h, int src, bool any) {
-        const float4 *rowp = reinterpret_cast<const float4 *>(in + (size_t)max(src, 0) * CinT + h * Cin + ak * HALF);
+        const float4 *rowp = reinterpret_cast<const float4 *>(in + (size_t)max(src, 0) * CinT + h * Cin) + ak;    // pieces ak, ak + 2, ...: see the ownership note
 #pragma unroll
         for (int u = 0; u < NG; ++u) {
             g[u] = make_float4(0.f, 0.f, 0.f, 0.f);
-            if (any && src >= 0) g[u] = rowp[u];
+            if (any && src >= 0 && !(SC_PROBE & 1)) g[u] = rowp[2 * u];
         }
     };
     int k = next_k(-1), h = 0, buf = 0;
@@ -692,7 +697,7 @@ __global__ __launch_bounds__(256) void sc_implicit_gemm_rega_kernel(const float 
     for (; k < K;) {
         int kn = k, hn = h + 1;                           // the stage after this one
         if (hn == SL) { kn = next_k(k); hn = 0; }
-        __syncthreads();                                  // W of this stage is visible; the other buffer's readers are done
+        if (!(SC_PROBE & 4)) __syncthreads();             // W of this stage is visible; the other buffer's readers are done
         int src_next = src_cur;
         bool any_next = false;
         if (kn < K) {                                     // in flight while the MFMAs below run
@@ -705,7 +710,7 @@ __global__ __launch_bounds__(256) void sc_implicit_gemm_rega_kernel(const float 
             fetch_a(gn, hn, src_next, any_next);
         }
         if (any) {
-            const float *Wb = s_mem + (size_t)buf * Cin * CW + (size_t)ak * HALF * CW + ar;
+            const float *Wb = s_mem + (size_t)buf * Cin * CW + (size_t)ak * 4 * CW + ar;
 #pragma unroll
             for (int u = 0; u < NG; ++u) {
                 const float av[4] = {ga[u].x, ga[u].y, ga[u].z, ga[u].w};
@@ -713,7 +718,7 @@ __global__ __launch_bounds__(256) void sc_implicit_gemm_rega_kernel(const float 
                 for (int j = 0; j < 4; ++j) {
 #pragma unroll
                     for (int q = 0; q < NT; ++q)
-                        acc[q] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[j], Wb[(u * 4 + j) * CW + q * 32], acc[q], 0, 0, 0);
+                        acc[q] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[j], Wb[(u * 8 + j) * CW + q * 32], acc[q], 0, 0, 0);
                 }
             }
         }
@@ -769,7 +774,7 @@ __global__ __launch_bounds__(256) void sc_implicit_gemm_rega_kernel(const float 
 // W[k+1] into registers (wr[NW]), stored it to LDS behind the MFMAs (store_w) and read it back ONE FLOAT PER MFMA (64 ds_read_b32
 // per 64->64 stage, each with its own wait).  Here the folded weights are packed ONCE PER WEIGHT UPDATE (lidar_spconv_pack_weights)
 // in exactly the order the lanes consume them —
-//     P[k][h][u][q][lane = ak * 32 + ar][j] = W[k][h * Cin + ak * HALF + 4 u + j][32 q + ar]      (float4 over j; 0 past Cout)
+//     P[k][h][u][q][lane = ak * 32 + ar][j] = W[k][h * Cin + 4 (2 u + ak) + j][32 q + ar]      (float4 over j; 0 past Cout)
 // — so that (a) a stage is a straight copy and goes global -> LDS by LDS-DMA (global_load_lds_dwordx4: no registers, no store
 // phase; NG * NT wave-instructions of 1 KB per stage), and (b) a lane reads the B operands of FOUR consecutive MFMA steps with
 // one conflict-free ds_read_b128 (lane-linear image).  One barrier per stage as before (it also drains the DMA: vmcnt(0)).
@@ -824,11 +829,11 @@ __global__ __launch_bounds__(256) void sc_implicit_gemm_pk_kernel(const float *_
         }
     };
     auto fetch_a = [&](float4 (&g)[NG], int h, int src, bool any) {
-        const float4 *rowp = reinterpret_cast<const float4 *>(in + (size_t)max(src, 0) * CinT + h * Cin + ak * HALF);
+        const float4 *rowp = reinterpret_cast<const float4 *>(in + (size_t)max(src, 0) * CinT + h * Cin) + ak;    // pieces ak, ak + 2, ...: see the ownership note
 #pragma unroll
         for (int u = 0; u < NG; ++u) {
             g[u] = make_float4(0.f, 0.f, 0.f, 0.f);
-            if (any && src >= 0) g[u] = rowp[u];
+            if (any && src >= 0) g[u] = rowp[2 * u];
         }
     };
     int k = next_k(-1), h = 0, buf = 0;
@@ -935,7 +940,7 @@ __global__ __launch_bounds__(256) void sc_pack_weights_kernel(const float *__res
     float v[4] = {0.f, 0.f, 0.f, 0.f};
     if (col < Cout) {
 #pragma unroll
-        for (int j = 0; j < 4; ++j) v[j] = W[((size_t)k * CinT + h * Cin + ak * HALF + 4 * u + j) * Cout + col];
+        for (int j = 0; j < 4; ++j) v[j] = W[((size_t)k * CinT + h * Cin + (2 * u + ak) * 4 + j) * Cout + col];
     }
     P[e] = make_float4(v[0], v[1], v[2], v[3]);
 }
@@ -1002,11 +1007,11 @@ __global__ __launch_bounds__(256, 2) void sc_implicit_gemm_wave_kernel(const flo
         }
     };
     auto fetch_a = [&](float4 (&g)[NG], int h, int src, bool any) {
-        const float4 *rowp = reinterpret_cast<const float4 *>(in + (size_t)max(src, 0) * CinT + h * Cin + ak * HALF);
+        const float4 *rowp = reinterpret_cast<const float4 *>(in + (size_t)max(src, 0) * CinT + h * Cin) + ak;    // pieces ak, ak + 2, ...: see the ownership note
 #pragma unroll
         for (int u = 0; u < NG; ++u) {
             g[u] = make_float4(0.f, 0.f, 0.f, 0.f);
-            if (any && src >= 0) g[u] = rowp[u];
+            if (any && src >= 0) g[u] = rowp[2 * u];
         }
     };
     int k = next_k(-1), h = 0;
@@ -1035,7 +1040,7 @@ __global__ __launch_bounds__(256, 2) void sc_implicit_gemm_wave_kernel(const flo
             fetch_a(gn, hn, src_next, any_next);
         }
         if (any) {
-            const float *Wb = Wl + (size_t)ak * HALF * CW + ar;
+            const float *Wb = Wl + (size_t)ak * 4 * CW + ar;
 #pragma unroll
             for (int u = 0; u < NG; ++u) {
                 const float av[4] = {ga[u].x, ga[u].y, ga[u].z, ga[u].w};
@@ -1043,7 +1048,7 @@ __global__ __launch_bounds__(256, 2) void sc_implicit_gemm_wave_kernel(const flo
                 for (int j = 0; j < 4; ++j) {
 #pragma unroll
                     for (int q = 0; q < NT; ++q)
-                        acc[q] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[j], Wb[(u * 4 + j) * CW + q * 32], acc[q], 0, 0, 0);
+                        acc[q] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[j], Wb[(u * 8 + j) * CW + q * 32], acc[q], 0, 0, 0);
                 }
             }
         }
