@@ -18,6 +18,9 @@
 //   vx_rows   : writes every padded voxel row exactly once with 16-B/lane stores (zeros included),
 //               coords + counts, and restores the workspace (hash table, lists) to its clean state
 #include "common.h"
+#ifndef VXL_FILL_NT                      // A/B: 1 = the zero fill as streaming (nt) stores
+#define VXL_FILL_NT 0
+#endif
 #include <hip/hip_ext.h>
 #include <stdlib.h>
 #include <type_traits>
@@ -603,12 +606,20 @@ __device__ __forceinline__ void vxl_chain_insert(int *cell0, int stride_ints, in
 
 __device__ __forceinline__ void vxl_fill_chunks(float4 *__restrict__ dst, long long c0, long long cstep, long long cend,
                                                 long long lim_f4, int t) {
-    const float4 z = make_float4(0.f, 0.f, 0.f, 0.f);
+    typedef float vxf4 __attribute__((ext_vector_type(4)));
+    const vxf4 z = {0.f, 0.f, 0.f, 0.f};
+    vxf4 *d = reinterpret_cast<vxf4 *>(dst);
     for (long long c = c0; c < cend; c += cstep) {
         const long long b = c * VXL_FILL_F4_PER_WG + t;
 #pragma unroll
         for (int k = 0; k < 4; ++k)
-            if (b + k * 1024 < lim_f4) dst[b + k * 1024] = z;
+            if (b + k * 1024 < lim_f4) {
+#if VXL_FILL_NT
+                __builtin_nontemporal_store(z, d + b + k * 1024);
+#else
+                d[b + k * 1024] = z;
+#endif
+            }
     }
 }
 
