@@ -61,6 +61,8 @@ VARIANTS = {
 AB_VARIANTS = {
     "w43_aux0": ("wino43_conv.hip", ["-DW43_STORE_AUX=0"]),
     "vxl_fill_nt": ("voxelize.hip", ["-DVXL_FILL_NT=1"]),          # the voxeliser's zero fill as streaming stores
+    "vxl_share12": ("voxelize.hip", ["-DVXL_FILL_SHARE16=12"]), "vxl_share10": ("voxelize.hip", ["-DVXL_FILL_SHARE16=10"]),
+    "vxl_share8": ("voxelize.hip", ["-DVXL_FILL_SHARE16=8"]),      # part of the zero fill moved into the emit launch
     "dc_nowait": ("deconv_gemm.hip", ["-DDC_PROBE=1"]),
     "sc_p1": ("sparse_conv.hip", ["-DSC_PROBE=1"]), "sc_p2": ("sparse_conv.hip", ["-DSC_PROBE=2"]), "sc_p4": ("sparse_conv.hip", ["-DSC_PROBE=4"]),
     "sc_p7": ("sparse_conv.hip", ["-DSC_PROBE=7"]),                # WRONG results: ablations of the sparse implicit GEMM            # WRONG results: the deblock GEMM's barrier does not wait for its DMA        # F(4x4) Winograd with default-policy output stores instead of nt

@@ -18,6 +18,9 @@
 //   vx_rows   : writes every padded voxel row exactly once with 16-B/lane stores (zeros included),
 //               coords + counts, and restores the workspace (hash table, lists) to its clean state
 #include "common.h"
+#ifndef VXL_FILL_SHARE16                 // sixteenths of the predicted rows the first launch's fill roles clear; the emit launch clears the rest
+#define VXL_FILL_SHARE16 16
+#endif
 #ifndef VXL_FILL_NT                      // A/B: 1 = the zero fill as streaming (nt) stores
 #define VXL_FILL_NT 0
 #endif
@@ -604,6 +607,12 @@ __device__ __forceinline__ void vxl_chain_insert(int *cell0, int stride_ints, in
     }
 }
 
+// rows of a compact buffer the first launch clears: a share of the prediction (the rest is cleared by the emit launch, whose first-point
+// threads know which rows exist); "everything" stays everything
+__device__ __forceinline__ long long vxl_fill_share(long long rows) {
+    return (rows >= 0x7fffffffll || VXL_FILL_SHARE16 >= 16) ? rows : rows * VXL_FILL_SHARE16 / 16;
+}
+
 __device__ __forceinline__ void vxl_fill_chunks(float4 *__restrict__ dst, long long c0, long long cstep, long long cend,
                                                 long long lim_f4, int t) {
     typedef float vxf4 __attribute__((ext_vector_type(4)));
@@ -792,7 +801,7 @@ __global__ __launch_bounds__(1024, 8) void vxl_keybin_kernel(const float *__rest
                           w.resident[1] == (long long)reinterpret_cast<uintptr_t>(prev_counts) &&
                           w.resident[3] == (long long)p.P * p.C;
     // ---- fill geometry (all roles): chunks of 64 KiB; the last help16/16 of them belong to the bin roles
-    const long long lim_rows = (p.compact && !resident) ? (long long)w.fillst[0] : 0x7fffffffll;
+    const long long lim_rows = (p.compact && !resident) ? vxl_fill_share((long long)w.fillst[0]) : 0x7fffffffll;
     const long long lim_f4 = (lim_rows >= 0x7fffffffll) ? total_f4 : min(total_f4, (lim_rows * p.P * p.C + 3) / 4);
     const long long nchunks = (lim_f4 + VXL_FILL_F4_PER_WG - 1) / VXL_FILL_F4_PER_WG;
     const long long nhelp = nchunks * help16 / 16, nmain = nchunks - nhelp;
@@ -1015,7 +1024,7 @@ __global__ __launch_bounds__(1024, 8) void vxl_keybin_kernel(const float *__rest
             for (int k = 0; k < 32; ++k) tot += s_tc[k];
             w.bvox[f * VXL_GMAX + g] = tot;                    // read by the emit launch
             // rows the fill roles of THIS call leave zero (the emit launch reads it): everything in resident mode
-            if (id == 0) w.fillst[1] = resident ? 0x7fffffff : w.fillst[0];
+            if (id == 0) w.fillst[1] = resident ? 0x7fffffff : (int)vxl_fill_share((long long)w.fillst[0]);
         }
     }
     VXL_STAMP(7);
@@ -1129,8 +1138,6 @@ __global__ __launch_bounds__(1024, 8) void vxl_emit_kernel(const float *__restri
             out4[0] = me;
             if (cnt >= 2) out4[1] = pre1;
             if (cnt >= 3) out4[2] = pre2;
-            if ((long long)row >= cleared_rows)            // beyond what the fill role cleared: this thread owns the row's zeros
-                for (int sl = cnt; sl < p.P; ++sl) out4[sl] = make_float4(0.f, 0.f, 0.f, 0.f);
             x0 = me.x; y0 = me.y; z0 = me.z;
         } else {
             const float *q = points + ((size_t)start + i) * p.C;
@@ -1145,6 +1152,24 @@ __global__ __launch_bounds__(1024, 8) void vxl_emit_kernel(const float *__restri
         vx_cell(p, x0, y0, z0, key);
         reinterpret_cast<int4 *>(coords)[row] = make_int4(f, (int)(key / (nx * ny)), (int)((key / nx) % ny), (int)(key % nx));
         num_points[row] = cnt;
+    }
+    if (C4) {
+        // rows beyond what the fill roles cleared: their zeros (slots cnt .. P - 1) are written here, the WAVE working through its
+        // lanes' rows two at a time — 32 lanes x 16 B per row and pass, whole 512-byte runs (one thread per row wrote 16 B per
+        // instruction at a 512 B stride)
+        unsigned long long need = __ballot(first && (long long)row >= cleared_rows);      // wave-uniform
+        while (need) {
+            const int la = __builtin_ctzll(need);
+            need &= need - 1ull;
+            int lb = la;
+            if (need) { lb = __builtin_ctzll(need); need &= need - 1ull; }
+            const int src = (l < 32) ? la : lb;
+            const size_t rr = (size_t)__shfl((long long)row, src, 64);
+            const int cc = __shfl(cnt, src, 64);
+            float4 *o = reinterpret_cast<float4 *>(voxels) + rr * p.P;
+            if (l < 32 || lb != la)
+                for (int sl = cc + (l & 31); sl < p.P; sl += 32) o[sl] = make_float4(0.f, 0.f, 0.f, 0.f);
+        }
     }
     VXL_ESTAMP(3);
     // ---- the further slots of the multi-point voxels (from slot 3 when C == 4: 1 and 2 were prefetched; else from slot 1),
