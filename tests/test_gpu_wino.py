@@ -231,3 +231,26 @@ def test_wino_f43_matches_f23_on_a_backbone_sized_map(dev):
     print(f"f43 vs direct {float((a - ref).abs().max()):.2e}, f23 vs direct {float((b - ref).abs().max()):.2e}, scale {scale:.1f}")
     assert float((a - ref).abs().max()) <= 1e-4 * scale
     assert float((a - b).abs().max()) <= 1e-4 * scale
+
+
+def test_wino_f43_random_small_shapes(dev):
+    """24 seeded random shapes (maps from 1 x 1 up, channel counts from the smallest supported) against the fp64 convolution, through a
+    wider input map and into a slice of a wider output map: the zero padding by buffer bounds, the bounds-dropped stores of partial
+    tiles, the cross-block input stream with few chunks per block"""
+    r = np.random.default_rng(4343)
+    for case in range(24):
+        B, H, W = int(r.integers(1, 4)), int(r.integers(1, 41)), int(r.integers(1, 41))
+        cin, cout = int(r.choice([32, 48, 64, 96])), int(r.choice([64, 128]))
+        in_c, out_c, off = cin + 4 * int(r.integers(0, 3)), cout + 32, 4 * int(r.integers(0, 9))
+        g = torch.Generator(device="cpu").manual_seed(100 + case)
+        x = torch.randn(B, in_c, H, W, generator=g)
+        w = torch.randn(cout, cin, 3, 3, generator=g) / np.sqrt(9 * cin)
+        bias = torch.randn(cout, generator=g)
+        out = torch.full((B, out_c, H, W), -5.0, device=dev).contiguous(memory_format=torch.channels_last)
+        wino.conv3x3_f43(x.to(dev).contiguous(memory_format=torch.channels_last), wino.pack_weights43(w.to(dev)), cout, bias.to(dev), bool(case & 1),
+                         out=out, out_offset=off, cin=cin)
+        want = _ref(x[:, :cin], w, bias, bool(case & 1))
+        got = out[:, off:off + cout].double().cpu()
+        scale = max(1.0, float(want.abs().max()))
+        assert float((got - want).abs().max()) <= 1e-4 * scale, (case, B, H, W, cin, cout)
+        assert bool((out[:, :off] == -5.0).all()) and bool((out[:, off + cout:] == -5.0).all()), case
