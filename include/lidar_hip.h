@@ -425,7 +425,7 @@ int lidar_wino43_conv3x3_nhwc(const float *in, int B, int H, int W, int Cin, int
  * + ReLU + the write into the layer's channel slice of the concatenated map (base_bev_backbone.py:103) as ONE fp32-MFMA kernel
  * (csrc/deconv_gemm.hip): out[b][s y + ky][s x + kx][out_off + c] = act(sum_k in[b][y][x][k] W[k][(ky, kx, c)] + bias[c]).
  * W: (K, s * s * C_up) row-major, columns ordered (ky, kx, c); packed once per weight update (lidar_deconv_pack_weights,
- * lidar_deconv_packed_floats floats; 0 = unsupported: K % 8 == 0, C_up % 128 == 0 and s * s * C_up % 512 == 0 are supported). */
+ * lidar_deconv_packed_floats floats; 0 = unsupported: K % 8 == 0, K >= 16, C_up % 128 == 0 and s * s * C_up % 512 == 0 are supported). */
 size_t lidar_deconv_packed_floats(int K, int N);
 int lidar_deconv_supported(int K, int s, int C_up);
 int lidar_deconv_pack_weights(const float *W, int K, int N, float *packed, void *stream);

@@ -11,10 +11,10 @@
 //
 // Same machinery as csrc/wino_conv.hip (one wave per SIMD, 256 accumulator registers = a 32-pixel x 512-column tile per wave,
 // LDS-DMA ring, one barrier per 4-channel chunk, issue order written out MFMA by MFMA, persistent over tile blocks) without the
-// transforms: the four waves of a workgroup take four consecutive 32-pixel row blocks and SHARE the B operand — a chunk's 4 x 512
-// weights (8 KB, packed once per weight update in lane order) are DMA'd to LDS once per workgroup and read by every wave as eight
-// 16-byte lane-linear loads; the A operand is one 8-byte LDS load per lane and chunk.  Per chunk and wave: 32 MFMAs against 9 LDS
-// reads and 1 DMA instruction (the Winograd kernel: 8 global loads + 14 LDS operations + the transform arithmetic).
+// transforms: the four waves of a workgroup take four consecutive 32-pixel row blocks and use the same B operand — a chunk's 4 x 512
+// weights (8 KB, packed once per weight update in lane order): eight 16-byte buffer loads per wave straight into the next chunk's
+// registers (end of r04; before: DMA'd to LDS once per workgroup and read back); the A operand is one 8-byte LDS load per lane and
+// chunk from the LDS-DMA image of the block's pixels.  Per chunk and wave: 32 MFMAs against 8 buffer loads, 1 LDS read, <= 1 DMA.
 #include "common.h"
 #ifndef DC_PROBE                         // timing probe (WRONG results): bit 0 = the chunk barrier does not wait for the DMA
 #define DC_PROBE 0
@@ -25,7 +25,7 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
 typedef float f32x2 __attribute__((ext_vector_type(2)));
 
-__device__ float4 g_dc_zero = {0.f, 0.f, 0.f, 0.f};
+#define DC_OOB 0x80000000u                // a byte offset no input map reaches (the launcher keeps it below 2^31 bytes): the DMA reads zeros
 
 // W (K, N) row-major, columns ordered (ky, kx, c).
 // packed[((((c * NG + g) * 8 + e) * 64 + lane) * 4 + (t & 1) * 2 + s] = W[4 c + 2 (lane >> 5) + s][512 g + 32 (2 e + (t & 1)) + (lane & 31)]
@@ -49,17 +49,16 @@ struct DcArgs {
 };
 
 #define DC_STG_PITCH 132                 // floats per staged pixel: 128 channels + 4 (16-byte aligned rows, shifted banks)
-static constexpr size_t dc_lds_bytes() { return (size_t)2 * (128 * 16 + 8 * 64 * 16) + (size_t)4 * 32 * DC_STG_PITCH * 4; }
+static constexpr size_t dc_lds_bytes() { return (size_t)2 * 128 * 16 + (size_t)4 * 32 * DC_STG_PITCH * 4; }
 
 __global__ __launch_bounds__(256) void dc_gemm_kernel(const DcArgs a) {
     extern __shared__ float4 s_mem4[];
     float4 *s_a = s_mem4;                                 // [2][128]: A images, [pixel of the block][4 channels of the chunk]
-    f32x4 *s_b = reinterpret_cast<f32x4 *>(s_mem4 + 2 * 128);      // [2][8][64]: B images, lane order
-    float *s_stg = reinterpret_cast<float *>(s_b + 2 * 8 * 64);    // [4 waves][32 pixels][DC_STG_PITCH]
+    float *s_stg = reinterpret_cast<float *>(s_mem4 + 2 * 128);    // [4 waves][32 pixels][DC_STG_PITCH]
     const int t = threadIdx.x, l = t & 63, wv = __builtin_amdgcn_readfirstlane(t >> 6);
     const int i = l & 31, h = l >> 5;
     const int K = a.K, NC = K >> 2;
-    const size_t bstride = (size_t)a.n_groups * 8 * 64;  // float4 per chunk
+    const int bstride = a.n_groups * 8 * 64;             // float4 per chunk
 
     const int nb8 = (a.n_blocks + 7) >> 3;
     const __amdgpu_buffer_rsrc_t orsrc = __builtin_amdgcn_make_buffer_rsrc(a.out, (short)0, (int)a.out_bytes, 0x00020000);
@@ -69,9 +68,8 @@ __global__ __launch_bounds__(256) void dc_gemm_kernel(const DcArgs a) {
     if (blk >= blk_end) return;
 
     struct Tile {
-        const float *asrc;               // this lane's A DMA source (waves 0 / 1: pixels 64 wv + l of the block), chunk 0
-        bool aok;
-        const f32x4 *bsrc;               // this lane's B DMA sources: pieces 2 wv and 2 wv + 1 of the group, chunk 0
+        unsigned aoff;                   // byte offset of this lane's A DMA source (waves 0 / 1: pixels 64 wv + l of the block), chunk 0; DC_OOB: no pixel
+        int b;                           // float4 index of the group's packed weights, chunk 0 (wave-uniform)
         int p0, g;
     };
     auto make_tile = [&](int blk_) {
@@ -80,54 +78,68 @@ __global__ __launch_bounds__(256) void dc_gemm_kernel(const DcArgs a) {
         const int pb = blk_ / a.n_groups;
         tl.p0 = pb * 128;
         const int p = tl.p0 + 64 * (wv & 1) + l;
-        tl.aok = p < a.P;
-        tl.asrc = tl.aok ? a.in + (size_t)p * K : (const float *)&g_dc_zero;
-        tl.bsrc = reinterpret_cast<const f32x4 *>(a.pk) + ((size_t)tl.g * 8 + 2 * wv) * 64 + l;
+        tl.aoff = p < a.P ? (unsigned)p * (unsigned)K * 4u : DC_OOB;
+        tl.b = tl.g * 8 * 64;
         return tl;
     };
-    auto dma = [&](const Tile &tl, int c, int buf) {      // chunk c of tile tl -> ring slot buf
+    // r04 (end): the issue model of csrc/wino43_conv.hip applied.  B — the same 8 KB for every wave — is no longer DMA'd to LDS and read
+    // back (2 DMA instructions per wave at ~80 issue cycles each + 8 LDS reads) but loaded straight into the next chunk's registers
+    // through a buffer descriptor (scalar offset + lane * 16: ~7 issue cycles each, no VALU); A alone goes through LDS, DMA'd by waves
+    // 0 / 1 as inline assembly through a descriptor of the input map (32-bit running offset, pixels past the end read zeros) so that
+    // hipcc's wait bookkeeping stays exact, and the chunk barrier waits "vmcnt(8)": for the DMA, not for the 8 loads behind it.
+    typedef int i32x4 __attribute__((ext_vector_type(4)));
+    i32x4 arsrc;
+    {
+        const unsigned long long base = (unsigned long long)a.in;
+        arsrc[0] = (int)(unsigned)base;
+        arsrc[1] = (int)((unsigned)(base >> 32) & 0xffffu);
+        arsrc[2] = (int)((unsigned)a.P * (unsigned)K * 4u);
+        arsrc[3] = 0x00020000;
+    }
+    const __amdgpu_buffer_rsrc_t brsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(a.pk), (short)0, (int)((unsigned)K * (unsigned)a.N * 4u), 0x00020000);
+    const int l16 = l * 16;
+    auto ldb = [&](int f4_index) { return __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(brsrc, l16, f4_index * 16, 0)); };
+    const unsigned a_lds = (unsigned)(size_t)((__attribute__((address_space(3))) char *)s_a);
+    unsigned doff = 0;                    // the A stream's next chunk (waves 0 / 1)
+    auto dma = [&](int buf) {
         if (wv < 2) {
-            const float *g = tl.aok ? tl.asrc + 4 * c : tl.asrc;
-            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)g,
-                                             (__attribute__((address_space(3))) void *)(s_a + buf * 128 + 64 * wv), 16, 0, 0);
+            const unsigned dst = a_lds + (unsigned)((buf * 128 + 64 * wv) * 16);
+            asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tbuffer_load_dwordx4 %0, %1, 0 offen lds" : : "v"(doff), "s"(arsrc), "s"(dst) : "memory", "m0");
         }
-        const f32x4 *bp = tl.bsrc + (size_t)c * bstride;
-#pragma unroll
-        for (int e = 0; e < 2; ++e)
-            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(bp + e * 64),
-                                             (__attribute__((address_space(3))) void *)(s_b + (buf * 8 + 2 * wv + e) * 64), 16, 0, 0);
     };
-    auto load_ab = [&](int buf, f32x2 &av, f32x4 (&bb)[8]) {
-        av = reinterpret_cast<const f32x2 *>(s_a + buf * 128 + 32 * wv + i)[h];
-#pragma unroll
-        for (int e = 0; e < 8; ++e) bb[e] = s_b[(buf * 8 + e) * 64 + l];
-    };
+    auto load_a = [&](int buf, f32x2 &av) { av = reinterpret_cast<const f32x2 *>(s_a + buf * 128 + 32 * wv + i)[h]; };
 
     f32x16 acc[16];
     f32x2 a0, a1;
     f32x4 b0[8], b1[8];
     Tile cur = make_tile(blk), nxt = cur;
-    dma(cur, 0, 0);
-    dma(cur, 1, 1);
+    doff = cur.aoff;
+    dma(0);
+    doff += 16u;
+    dma(1);
+    doff += 16u;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) b0[e] = ldb(cur.b + e * 64);
+    __builtin_amdgcn_s_waitcnt(0x0F70);                   // vmcnt(0): the DMAs are invisible to the compiler's own wait
+    asm volatile("" ::: "memory");
     __syncthreads();                                      // chunks 0, 1 landed
-    load_ab(0, a0, b0);
+    load_a(0, a0);
     __syncthreads();                                      // every wave has read image 0: chunk 0's DMA of chunk 2 may overwrite it
 
-    // chunk c (parity P = c & 1, NC even): the operands of chunk c + 1 are read from image !P into the other register set, the DMA of
-    // chunk c + 2 goes to image P (chunk c's data there was read during chunk c - 1; every wave has passed this chunk's barrier since).
-    // Past the end of the block "c + k" is chunk c + k - NC of the NEXT block (same parities).  Column tile n, K-step s: B piece
-    // n >> 1, component 2 (n & 1) + s.  FIRST: the block's first chunk starts the accumulators from a zero C operand.
+    // chunk c (parity P = c & 1, NC even): A of chunk c + 1 is read from image !P and B of chunk c + 1 loaded from memory into the
+    // other register set, the DMA of chunk c + 2 goes to image P (chunk c's data there was read during chunk c - 1; every wave has
+    // passed this chunk's barrier since).  Past the end of the block "c + k" is chunk c + k - NC of the NEXT block (same parities).
+    // Column tile n, K-step s: B piece n >> 1, component 2 (n & 1) + s.  FIRST: the block's first chunk starts from a zero C operand.
 #define DC_CHUNK(c, P, FIRST, AC, BC, AN, BN)                                                                                      \
     {                                                                                                                              \
-        if ((c) > 0) { if (DC_PROBE & 1) { __builtin_amdgcn_s_waitcnt(0xC07F); __builtin_amdgcn_s_barrier(); } else __syncthreads(); } \
-        else if (!first_block) {                                                                                                   \
-            __builtin_amdgcn_s_waitcnt(0xC07F);                                                                                    \
-            __builtin_amdgcn_s_barrier();                                                                                          \
-        }                                                                                                                          \
-        if ((c) + 2 < NC) dma(cur, (c) + 2, (P));                                                                                  \
-        else if (has_next) dma(nxt, (c) + 2 - NC, (P));                                                                            \
+        if ((c) > 0) {                                                                                                             \
+            if (DC_PROBE & 1) asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");                                      \
+            else asm volatile("s_waitcnt vmcnt(8) lgkmcnt(0)\n\ts_barrier" ::: "memory");                                          \
+        } else if (!first_block) asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");                                   \
+        dma(P);                                        /* A stream element c + 2 */                                                \
+        doff = ((c) + 3 == NC) ? (has_next ? nxt.aoff : DC_OOB) : doff + 16u;                                                      \
+        const int bn_ = ((c) + 1 < NC) ? cur.b + ((c) + 1) * bstride : (has_next ? nxt.b : cur.b);                                 \
         const f32x2 *as_ = reinterpret_cast<const f32x2 *>(s_a + (1 - (P)) * 128 + 32 * wv + i) + h;                               \
-        const f32x4 *bs_ = s_b + ((1 - (P)) * 8) * 64 + l;                                                                         \
         __builtin_amdgcn_sched_barrier(0);                                                                                         \
         _Pragma("unroll") for (int k = 0; k < 32; ++k) {                                                                           \
             const float bop_ = BC[(k & 15) >> 1][((k & 1) << 1) + (k >> 4)];                                                       \
@@ -138,8 +150,8 @@ __global__ __launch_bounds__(256) void dc_gemm_kernel(const DcArgs a) {
             } else {                                                                                                               \
                 acc[k & 15] = __builtin_amdgcn_mfma_f32_32x32x2f32(AC[k >> 4], bop_, acc[k & 15], 0, 0, 0);                        \
             }                                                                                                                      \
+            if (k < 8) BN[k] = ldb(bn_ + k * 64);                                                                                  \
             if (k == 2) AN = as_[0];                                                                                               \
-            if (k >= 4 && k < 20 && !(k & 1)) BN[(k - 4) >> 1] = bs_[((k - 4) >> 1) * 64];                                         \
             __builtin_amdgcn_sched_barrier(0);                                                                                     \
         }                                                                                                                          \
     }
@@ -227,7 +239,8 @@ __global__ __launch_bounds__(256) void dc_gemm_kernel(const DcArgs a) {
 
 // ------------------------------------------------------------------ C ABI
 LIDAR_EXPORT size_t lidar_deconv_packed_floats(int K, int N) {
-    if (K <= 0 || N <= 0 || (K & 7) || (N & 511)) return 0;            // two 4-channel chunks per loop iteration, 512-column groups
+    if (K < 16 || N <= 0 || (K & 7) || (N & 511)) return 0;            // two 4-channel chunks per loop iteration (the A stream runs two chunks
+                                                                       // ahead, across blocks: at least four per block), 512-column groups
     return (size_t)K * N;
 }
 
@@ -258,7 +271,8 @@ LIDAR_EXPORT int lidar_deconv_gemm_nhwc(const float *in, int B, int h, int w, in
     if (!in || !packed || !out || B <= 0 || h <= 0 || w <= 0 || !lidar_deconv_supported(K, s, C_up) || out_off < 0 || out_off + C_up > out_C)
         return LIDAR_ERR_ARG;
     if ((reinterpret_cast<uintptr_t>(in) & 15) || (reinterpret_cast<uintptr_t>(packed) & 15) || (reinterpret_cast<uintptr_t>(out) & 15) ||
-        (out_C & 3) || (out_off & 3) || (long long)B * h * w > 0x7fffffffll || (long long)B * h * w * s * s * out_C * 4 >= 0x7fffffffll)
+        (out_C & 3) || (out_off & 3) || (long long)B * h * w > 0x7fffffffll || (long long)B * h * w * s * s * out_C * 4 >= 0x7fffffffll ||
+        (long long)B * h * w * K * 4 >= 0x7fffffffll || (long long)K * s * s * C_up * 4 >= 0x7fffffffll)      // 32-bit byte offsets: output, input, weights
         return LIDAR_ERR_ARG;
     DcArgs a;
     a.in = in; a.pk = packed; a.bias = bias; a.out = out;

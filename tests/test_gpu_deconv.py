@@ -18,7 +18,7 @@ pytestmark = pytest.mark.gpu
     (1, 256, 9, 11, 4, 128, 384, 256),      # PointPillar deblock 3: four column groups
     (1, 256, 10, 12, 2, 256, 512, 256),     # SECOND / multi-head deblock 2: 256 up-channels (two 128-channel rounds per (ky, kx))
     (3, 64, 5, 7, 2, 128, 128, 0),          # K = 64 (16 chunks), fewer pixels than one block
-    (1, 8, 16, 16, 2, 128, 132, 4),         # smallest K, 256 pixels = two blocks exactly, odd slice offset
+    (1, 16, 16, 16, 2, 128, 132, 4),         # smallest K, 256 pixels = two blocks exactly, odd slice offset
 ])
 def test_deconv_gemm_vs_float64_conv_transpose(dev, B, K, h, w, s, c_up, c_out, off):
     g = torch.Generator(device="cpu").manual_seed(K + 7 * s + c_up + h)
