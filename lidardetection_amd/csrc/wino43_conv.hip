@@ -92,10 +92,18 @@ struct Wino43Args {
 
 #define W43_STG_PITCH 36                  // floats per staged output pixel (32 channels + 4: 16-byte aligned rows, spread over banks)
 #define W43_OOB 0x80000000u               // a byte offset no map reaches (the launcher keeps maps below 2^31 bytes): the DMA reads zeros
+#ifndef W43_B1                          // slots of the two transform bursts (A/B: tools/wino43_probe.py "0:W43_B1=24,W43_B2=48")
+#define W43_B1 20
+#endif
+#ifndef W43_B2
+#define W43_B2 40
+#endif
 #ifndef W43_STORE_AUX                   // cache policy bits of the output stores.  2 = nt (streaming): alone, a 64-channel layer gains 7 %
 #define W43_STORE_AUX 0                 // (0.237 -> 0.221 ms: the 33 MB all workgroups write within microseconds stop evicting the filters
 #endif                                  // from L2); inside the model the NEXT layer then misses them: 3 180 vs 3 203 frames/s, same box -> 0
-#define W43_R 4                           // positions the A operands are read ahead of their MFMAs
+#ifndef W43_R
+#define W43_R 4                           // positions the A operands are read ahead of their MFMAs (divides 36)
+#endif
 
 static constexpr int w43_nt(int TY, int TX) { return (2 * TY + 1) * (TX + 1); }              // region tiles (incl. the half tiles)
 static constexpr int w43_rp(int TY, int TX) { return ((32 * w43_nt(TY, TX) + 255) / 256) * 256; }  // DMA lanes (16 bytes) per chunk: every wave issues the same number
@@ -341,24 +349,24 @@ __global__ __launch_bounds__(256) void wino_f43_kernel(const Wino43Args a) {
                at slot 20 (their reads: slots 0..14), first stage of columns 3..5 (reads: slots 20..34) + the whole second stage with    \
                its 18 V writes at slot 40; the own-row A reads of the next chunk start at slot 4 (36 - R) + 3 */                          \
             if (!(WINO43_PROBE & 4)) {                                                                                             \
-                if (k < 15 || (k >= 20 && k < 35)) {                                                                               \
-                    const int rk = k < 15 ? k : k - 5;                                                                             \
+                if (k < 15 || (k >= W43_B1 && k < W43_B1 + 15)) {                                                                               \
+                    const int rk = k < 15 ? k : k - W43_B1 + 15;                                                                             \
                     if (WINO43_PROBE & 128) d_[rk / 5][rk % 5] = va[0];                                                            \
                     else d_[rk / 5][rk % 5] = *reinterpret_cast<const f32x2 *>(raw_ + rrow[rk % 5] + W43_COL(rk / 5));             \
                 }                                                                                                                  \
-                if ((k == 20 || k == 40) && (WINO43_PROBE & 32)) {     /* keep the reads alive */                                  \
-                    _Pragma("unroll") for (int x = (k == 20 ? 0 : 3); x < (k == 20 ? 3 : 6); ++x)                                  \
+                if ((k == W43_B1 || k == W43_B2) && (WINO43_PROBE & 32)) {     /* keep the reads alive */                                  \
+                    _Pragma("unroll") for (int x = (k == W43_B1 ? 0 : 3); x < (k == W43_B1 ? 3 : 6); ++x)                                  \
                         _Pragma("unroll") for (int j = 0; j < 5; ++j) asm volatile("" : : "v"(d_[x][j]));                          \
                 }                                                                                                                  \
-                if ((k == 20 || k == 40) && !(WINO43_PROBE & 32)) {                                                                \
-                    _Pragma("unroll") for (int x = (k == 20 ? 0 : 3); x < (k == 20 ? 3 : 6); ++x)                                  \
+                if ((k == W43_B1 || k == W43_B2) && !(WINO43_PROBE & 32)) {                                                                \
+                    _Pragma("unroll") for (int x = (k == W43_B1 ? 0 : 3); x < (k == W43_B1 ? 3 : 6); ++x)                                  \
                         _Pragma("unroll") for (int r = 0; r < 3; ++r) {                                                            \
                             f32x2 s_ = W43_PK(cf[r][0]) * d_[x][0];                                                                \
                             _Pragma("unroll") for (int j = 1; j < 5; ++j) s_ = W43_FMA(W43_PK(cf[r][j]), d_[x][j], s_);            \
                             w_[r][x] = s_;                                                                                         \
                         }                                                                                                          \
                 }                                                                                                                  \
-                if (k == 40 && !(WINO43_PROBE & 32)) {                                                                             \
+                if (k == W43_B2 && !(WINO43_PROBE & 32)) {                                                                             \
                     _Pragma("unroll") for (int r = 0; r < 3; ++r) {                                                                \
                         f32x2 o_[6];                                                                                               \
                         W43_S2_0(w_[r], o_) W43_S2_1(w_[r], o_) W43_S2_2(w_[r], o_) W43_S2_34(w_[r], o_) W43_S2_5(w_[r], o_)       \

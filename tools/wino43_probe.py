@@ -9,8 +9,8 @@ names = {1: "no input DMA", 2: "no filter loads", 4: "no patch reads/transform",
 for tok in sys.argv[1].split():                 # "bits" or "bits:EXTRA_DEFINE=val" (e.g. 0:WINO_SCHED=0 for an A/B of two schedules on one box)
     v, extra = (tok.split(":", 1) + [""])[:2]
     v = int(v)
-    so = f"/tmp/liblidar_wino43_probe_{tok.replace(':', '_').replace('=', '_')}.so"
-    subprocess.check_call(["/opt/rocm/bin/hipcc", *F, f"-DWINO43_PROBE={v}", *([f"-D{extra}"] if extra else []), "-c", os.path.join(C, "wino43_conv.hip"),
+    so = f"/tmp/liblidar_wino43_probe_{tok.replace(':', '_').replace('=', '_').replace(',', '_')}.so"
+    subprocess.check_call(["/opt/rocm/bin/hipcc", *F, f"-DWINO43_PROBE={v}", *([f"-D{x}" for x in extra.split(",")] if extra else []), "-c", os.path.join(C, "wino43_conv.hip"),
                            "-o", f"/tmp/wino43_probe_{v}.o"])
     subprocess.check_call(["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-shared", "-fPIC", "-o", so, *objs, f"/tmp/wino43_probe_{v}.o"])
     r = subprocess.run([sys.executable, os.path.join(R, "tools", "wino_bench.py"), *sys.argv[2:]], env=dict(os.environ, LIDAR_HIP_SO=so, WINO_BENCH_ONLY="1"),
