@@ -46,7 +46,7 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef float f32x2 __attribute__((ext_vector_type(2)));
 
 #ifndef WINO43_PROBE                     // timing probes (WRONG results): bit 0 no DMA in the loop, bit 1 no filter loads, bit 2 no
-#define WINO43_PROBE 0                   // transform, bit 3 no epilogue, bit 4 no barrier, bit 5 no transform arithmetic / V writes (reads stay), bit 7 no patch reads, bit 8 no global stores, bit 9 no load drain before the stores
+#define WINO43_PROBE 0                   // transform, bit 3 no epilogue, bit 4 no barrier, bit 5 no transform arithmetic / V writes (reads stay), bit 7 no patch reads, bit 8 no global stores, bit 9 no load drain before the stores, bit 10 odd workgroups start late
 #endif
 
 #define W43_OOB 0x80000000u               // a byte offset no map reaches (the launcher keeps maps below 2^31 bytes): the DMA reads zeros
@@ -282,6 +282,9 @@ __global__ __launch_bounds__(256) void wino_f43_kernel(const Wino43Args a) {
     f32x4 bb[18];                         // filters, a rolling window of 18 positions: {K-step 0: hf 0, 1; K-step 1: hf 0, 1}
     f32x2 va[R];                          // A operands {K-step 0, K-step 1}, a ring R positions ahead of the MFMAs
     const int NC = a.Cin >> 3;            // chunks of 8 channels
+    if ((WINO43_PROBE & 1024) && (slot & 1)) {            // probe: every other workgroup starts ~16 us late (de-synchronised epilogues)
+        for (int z = 0; z < 4; ++z) asm volatile("s_sleep 127");
+    }
     Tile cur = make_tile(blk), nxt = cur;
 #pragma unroll
     for (int k = 0; k < QW; ++k) doff[k] = cur.off[k];
