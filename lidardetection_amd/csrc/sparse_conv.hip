@@ -769,6 +769,205 @@ __global__ __launch_bounds__(256) void sc_implicit_gemm_rega_kernel(const float 
     }
 }
 
+// Two row tiles per wave (r04, Cin <= 64): the register-A kernel with every wave owning 64 rows — row r and row r + 32 per lane pair.
+// A B operand read from LDS feeds two MFMAs, a staged W[k] serves 256 rows and the stage barrier comes once per 2 x NT x Cin / 2
+// MFMAs per wave: the 64 -> 64 layers ran at 0.37 of the peak against 0.61 for the 128 -> 128 layers, whose stages carry twice the MFMAs
+// for the same staging and barrier (profiles/r04/spconv_gemm_ablation.log: barrier 8 %, staging 4 %).  One workgroup per CU at these
+// register counts (the second set of gathered rows), so nothing hides behind another workgroup — and that is what it costs: 45 TF where
+// the one-tile kernel reaches 68 on the 64 -> 64 layers (2.89 vs 1.99 ms on the SECOND stack).  Correct (bit-identical, under test via
+// LIDAR_SPCONV_RT2=1), off by default; kept as the measured answer to "more MFMAs per barrier".
+// Row tile rt of a wave is skipped for an offset none of its 32 rows uses (wave-uniform), as before.  Same channel ownership and
+// summation order per row as the register-A kernel: bit-identical results.
+template <int NT, int C4>
+__global__ __launch_bounds__(256) void sc_implicit_gemm_rega2_kernel(const float *__restrict__ in, const int *__restrict__ nbr, int n_out,
+                                                                     int K, int Cout, const float *__restrict__ Wt,
+                                                                     const float *__restrict__ bias, const float *__restrict__ residual,
+                                                                     int relu, float *__restrict__ out,
+                                                                     const int *__restrict__ row_mask, const int *__restrict__ out_row) {
+    constexpr int Cin = C4 * 4, HALF = Cin / 2, CW = NT * 32, CW4 = CW / 4;
+    constexpr int NG = HALF / 4;                          // float4 gathers per lane, row and stage
+    constexpr int NW = (Cin * CW4 + 255) / 256;           // float4 weight pieces per thread per stage
+    extern __shared__ float s_mem[];                      // W stage buffers: [2][Cin][CW]
+    const int t = threadIdx.x, l = t & 63, wv = t >> 6;
+    const int row0 = blockIdx.x * (2 * IG_ROWS) + wv * 64;
+    const int ar = l & 31, ak = l >> 5;
+    int myrow[2], trow[2];
+#pragma unroll
+    for (int rt = 0; rt < 2; ++rt) {
+        myrow[rt] = row0 + 32 * rt + ar;
+        trow[rt] = (out_row && myrow[rt] < n_out) ? out_row[myrow[rt]] : myrow[rt];
+    }
+    const int Co4 = Cout >> 2;
+    f32x16 acc[2][NT];
+#pragma unroll
+    for (int rt = 0; rt < 2; ++rt)
+#pragma unroll
+        for (int q = 0; q < NT; ++q)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[rt][q][r] = 0.f;
+    __shared__ unsigned s_wmask[4];
+    unsigned tile_mask[2] = {0xffffffffu, 0xffffffffu}, wg_mask = 0xffffffffu;
+    if (row_mask) {
+#pragma unroll
+        for (int rt = 0; rt < 2; ++rt) {
+            unsigned m = (myrow[rt] < n_out) ? (unsigned)row_mask[trow[rt]] : 0u;
+#pragma unroll
+            for (int d = 1; d < 64; d <<= 1) m |= (unsigned)__shfl_xor((int)m, d, 64);
+            tile_mask[rt] = m;
+        }
+        if (l == 0) s_wmask[wv] = tile_mask[0] | tile_mask[1];
+        __syncthreads();
+        wg_mask = s_wmask[0] | s_wmask[1] | s_wmask[2] | s_wmask[3];
+    }
+    auto next_k = [&](int k) {
+        if (!row_mask) return k + 1;
+        const unsigned rest = (k + 1 < 32) ? (wg_mask >> (k + 1)) : 0u;
+        return rest ? k + 1 + __builtin_ctz(rest) : K;
+    };
+    auto load_src = [&](int rt, int k) { return (myrow[rt] < n_out && k < K) ? nbr[(size_t)trow[rt] * K + k] : -1; };
+    auto tile_uses = [&](int rt, int k, int src) { return row_mask ? ((tile_mask[rt] >> k) & 1u) != 0u : __ballot(src >= 0) != 0ull; };
+    float4 wr[NW], ga[2][NG], gn[2][NG];
+    auto fetch_w = [&](int k) {
+#pragma unroll
+        for (int q = 0; q < NW; ++q) {
+            const int e = q * 256 + t, ci = e / CW4, q4 = e - ci * CW4;
+            wr[q] = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (e < Cin * CW4 && q4 < Co4) wr[q] = reinterpret_cast<const float4 *>(Wt + ((size_t)k * Cin + ci) * Cout)[q4];
+        }
+    };
+    auto store_w = [&](int buf) {
+        float4 *dst = reinterpret_cast<float4 *>(s_mem + (size_t)buf * Cin * CW);
+#pragma unroll
+        for (int q = 0; q < NW; ++q) {
+            const int e = q * 256 + t;
+            if (e < Cin * CW4) dst[e] = wr[q];
+        }
+    };
+    auto fetch_a = [&](float4 (&g)[NG], int src, bool any) {
+        const float4 *rowp = reinterpret_cast<const float4 *>(in + (size_t)max(src, 0) * Cin) + ak;      // pieces ak, ak + 2, ...
+#pragma unroll
+        for (int u = 0; u < NG; ++u) {
+            g[u] = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (any && src >= 0) g[u] = rowp[2 * u];
+        }
+    };
+    int k = next_k(-1), buf = 0;
+    if (k >= K) k = K;
+    int src_cur[2] = {load_src(0, k), load_src(1, k)}, src_ahead[2] = {-1, -1};
+    bool any[2] = {false, false};
+    if (k < K) {
+        fetch_w(k);
+#pragma unroll
+        for (int rt = 0; rt < 2; ++rt) {
+            any[rt] = tile_uses(rt, k, src_cur[rt]);
+            fetch_a(ga[rt], src_cur[rt], any[rt]);
+            src_ahead[rt] = load_src(rt, next_k(k));
+        }
+        store_w(0);
+    }
+    for (; k < K;) {
+        const int kn = next_k(k);
+        __syncthreads();                                  // W of this stage is visible; the other buffer's readers are done
+        int src_next[2] = {src_cur[0], src_cur[1]};
+        bool any_next[2] = {false, false};
+        if (kn < K) {                                     // in flight while the MFMAs below run
+            const int kk = next_k(kn);
+            fetch_w(kn);
+#pragma unroll
+            for (int rt = 0; rt < 2; ++rt) {
+                src_next[rt] = src_ahead[rt];
+                src_ahead[rt] = load_src(rt, kk);
+                any_next[rt] = tile_uses(rt, kn, src_next[rt]);
+                fetch_a(gn[rt], src_next[rt], any_next[rt]);
+            }
+        }
+        const float *Wb = s_mem + (size_t)buf * Cin * CW + (size_t)ak * 4 * CW + ar;
+        if (any[0] && any[1]) {                           // the usual case: one B read, two MFMAs
+#pragma unroll
+            for (int u = 0; u < NG; ++u) {
+                const float a0[4] = {ga[0][u].x, ga[0][u].y, ga[0][u].z, ga[0][u].w};
+                const float a1[4] = {ga[1][u].x, ga[1][u].y, ga[1][u].z, ga[1][u].w};
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+#pragma unroll
+                    for (int q = 0; q < NT; ++q) {
+                        const float b = Wb[(u * 8 + j) * CW + q * 32];
+                        acc[0][q] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0[j], b, acc[0][q], 0, 0, 0);
+                        acc[1][q] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1[j], b, acc[1][q], 0, 0, 0);
+                    }
+                }
+            }
+        } else {
+#pragma unroll
+            for (int rt = 0; rt < 2; ++rt) {
+                if (!any[rt]) continue;                   // wave-uniform
+#pragma unroll
+                for (int u = 0; u < NG; ++u) {
+                    const float av[4] = {ga[rt][u].x, ga[rt][u].y, ga[rt][u].z, ga[rt][u].w};
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) {
+#pragma unroll
+                        for (int q = 0; q < NT; ++q)
+                            acc[rt][q] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[j], Wb[(u * 8 + j) * CW + q * 32], acc[rt][q], 0, 0, 0);
+                    }
+                }
+            }
+        }
+        if (kn < K) {
+            store_w(buf ^ 1);
+#pragma unroll
+            for (int rt = 0; rt < 2; ++rt)
+#pragma unroll
+                for (int u = 0; u < NG; ++u) ga[rt][u] = gn[rt][u];
+        }
+#pragma unroll
+        for (int rt = 0; rt < 2; ++rt) {
+            src_cur[rt] = src_next[rt];
+            any[rt] = any_next[rt];
+        }
+        k = kn;
+        buf ^= 1;
+    }
+    const int last = n_out - 1;                           // n_out >= 1 (checked by the launcher)
+    // fused epilogue, per row tile: (+ bias) (+ residual) (ReLU); sorted tables scatter rows (as in the register-A kernel)
+#pragma unroll
+    for (int rt = 0; rt < 2; ++rt) {
+        const int rbase = row0 + 32 * rt;
+#pragma unroll
+        for (int hh = 0; hh < 2; ++hh) {
+            int orow[8];
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                const int r = hh * 8 + j;
+                const int row = min(rbase + (r & 3) + 8 * (r >> 2) + 4 * (l >> 5), last);
+                orow[j] = out_row ? out_row[row] : row;
+            }
+#pragma unroll
+            for (int q = 0; q < NT; ++q) {
+                const int col = q * 32 + (l & 31);
+                const int cc = min(col, Cout - 1);
+                const float bv = bias ? bias[cc] : 0.f;
+                float res[8];
+#pragma unroll
+                for (int j = 0; j < 8; ++j) res[j] = 0.f;
+                if (residual) {
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) res[j] = residual[(size_t)orow[j] * Cout + cc];
+                }
+#pragma unroll
+                for (int j = 0; j < 8; ++j) {
+                    const int r = hh * 8 + j;
+                    const int row = rbase + (r & 3) + 8 * (r >> 2) + 4 * (l >> 5);
+                    if (row < n_out && col < Cout) {
+                        const float v = acc[rt][q][r] + bv + res[j];
+                        out[(size_t)orow[j] * Cout + col] = relu ? fmaxf(v, 0.f) : v;
+                    }
+                }
+            }
+        }
+    }
+}
+
 // Packed-weight variant of the register-A kernel (r04; same shapes, same channel ownership, same summation order: results are
 // bit-identical to the register-A kernel's).  What changes is how W[k] reaches the matrix cores.  The register-A kernel fetched
 // W[k+1] into registers (wr[NW]), stored it to LDS behind the MFMAs (store_w) and read it back ONE FLOAT PER MFMA (64 ds_read_b32
@@ -1228,6 +1427,19 @@ static int sc_gemm_launch(const float *in_features, const int *nbr, int n_out, i
 #undef IGK_NT
 #undef IGK
         return lidar_check_launch("lidar_spconv_implicit_gemm(packed)");
+    }
+    // A/B switch, default OFF: LIDAR_SPCONV_RT2=1 selects the two-row-tile kernel for Cin 32 / 64.  Measured (profiles/r04/
+    // spconv_gemm_rt2.log, SECOND stack): 2.89 vs 1.99 ms — at 272 registers one workgroup per CU is left, and this kernel family hides its
+    // stage barrier and gather latency behind the OTHER resident workgroup, not behind a software pipeline of its own.
+    static const bool rt2_on = getenv("LIDAR_SPCONV_RT2") && atoi(getenv("LIDAR_SPCONV_RT2")) != 0;
+    const bool rt2_off = !rt2_on;
+    if (pipe && !rt2_off && !use_pipe && !use_wave && (Cin == 64 || Cin == 32) && nt <= 2 && n_out >= 8 * 2 * IG_ROWS) {
+        const dim3 grid2(divup(n_out, 2 * IG_ROWS));
+#define IGR2(NT, C4) hipLaunchKernelGGL((sc_implicit_gemm_rega2_kernel<NT, C4>), grid2, dim3(256), lds_rega, s, in_features, nbr, n_out, K, Cout, weight, bias, residual, relu, out_features, row_mask, out_row)
+        if (Cin == 64) { if (nt == 1) IGR2(1, 16); else IGR2(2, 16); }
+        else { if (nt == 1) IGR2(1, 8); else IGR2(2, 8); }
+#undef IGR2
+        return lidar_check_launch("lidar_spconv_implicit_gemm(two row tiles)");
     }
     if (pipe) {
         const int c4 = Cin / 4;

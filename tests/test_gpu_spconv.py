@@ -630,3 +630,39 @@ def test_grid_pool_budget_holds_when_every_grid_still_holds_rows(dev):
     finally:
         ops.GridPool.MAX_TOTAL_BYTES = keep
         ops.GRIDS.reset()
+
+
+def test_two_row_tile_gemm_kernel_is_bit_identical(dev, tmp_path):
+    """LIDAR_SPCONV_RT2=1 (csrc/sparse_conv.hip sc_implicit_gemm_rega2_kernel: 64 rows per wave, every B operand read feeds two MFMAs) —
+    measured slower than the default kernel and therefore off, but kept under test: a child process (the switch is read once per
+    process) runs the same mask-sorted 64 -> 64 and 32 -> 64 layers and must produce the default kernel's bits"""
+    import os
+    import subprocess
+    import sys
+    code = r"""
+import sys, torch
+from lidardetection_amd.spconv import ops
+dev = torch.device("cuda:0")
+outs = []
+for cin, cout, n_out in ((64, 64, 5000), (32, 64, 4099), (64, 48, 2300)):
+    g = torch.Generator(device="cpu").manual_seed(cin + cout + n_out)
+    nbr = torch.randint(0, 777, (n_out, 27), generator=g, dtype=torch.int32)
+    nbr[torch.rand(n_out, 27, generator=g) >= 0.3] = -1
+    f = torch.randn(777, cin, generator=g).to(dev); w = (torch.randn(27, cin, cout, generator=g) * 0.2).to(dev)
+    b = torch.randn(cout, generator=g).to(dev); r = torch.randn(n_out, cout, generator=g).to(dev)
+    nd = nbr.to(dev)
+    st = ops.mask_order(nd)
+    outs.append(ops.indice_conv_fused(f, nd, w, b, r, True, st).cpu())
+    outs.append(ops.indice_conv_fused(f, nd, w, None, None, False, None).cpu())
+torch.save(outs, sys.argv[1])
+"""
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    res = []
+    for flag in ("0", "1"):
+        out = str(tmp_path / f"rt2_{flag}.pt")
+        env = dict(os.environ, LIDAR_SPCONV_RT2=flag, PYTHONPATH=root + os.pathsep + os.environ.get("PYTHONPATH", ""))
+        subprocess.run([sys.executable, "-c", code, out], check=True, env=env, timeout=300)
+        res.append(torch.load(out, weights_only=True))
+    assert len(res[0]) == 6
+    for a, b in zip(*res):
+        assert torch.equal(a, b)
