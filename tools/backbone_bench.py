@@ -29,7 +29,7 @@ with torch.no_grad():
 print("max abs diff cls %.2e box %.2e dir %.2e" % tuple((p - q).abs().max().item() for p, q in zip(a, b)))
 # probe: MIOpen fusion plan conv+bias+relu through torch
 try:
-    w, bb, stride, pad = bev.stages[0][0][1]
+    w, bb, stride, pad = bev.stages[0][0][1][:4]
     y0 = F.conv2d(x, bev.stages[0][0][0][0], None, 2, 1)
     from lidardetection_amd.bev_backbone import bias_act_
     bias_act_(y0, bev.stages[0][0][0][1])
